@@ -1,0 +1,38 @@
+# Builds the product library (libeddsa_amd/libeddsa_amd.so: C host code + HIP kernels for gfx950)
+# and the test-only oracle (oracle/).  No GPU is needed to build: hipcc cross-compiles.
+ROCM    ?= /opt/rocm
+HIPCC   ?= $(ROCM)/bin/hipcc
+CC      ?= gcc
+ARCH    ?= gfx950
+CSRC    := libeddsa_amd/csrc
+BUILD   := build
+LIB     := libeddsa_amd/libeddsa_amd.so
+
+HIPFLAGS := -O3 --offload-arch=$(ARCH) -fPIC -fvisibility=hidden -DEDDSA_BUILD -Iinclude -I$(CSRC)
+CFLAGS   := -std=c11 -O2 -fPIC -fvisibility=hidden -Wall -Wextra -DEDDSA_BUILD -Iinclude -I$(CSRC) -I$(ROCM)/include
+
+all: $(LIB) oracle
+
+$(BUILD)/kernels.o: $(CSRC)/kernels.hip $(wildcard $(CSRC)/*.h)
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(BUILD)/eddsa_amd.o: $(CSRC)/eddsa_amd.c $(CSRC)/eddsa_kernels.h include/eddsa.h include/eddsa_amd.h
+	@mkdir -p $(BUILD)
+	$(CC) $(CFLAGS) -c $< -o $@
+
+$(LIB): $(BUILD)/kernels.o $(BUILD)/eddsa_amd.o
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -lpthread
+
+oracle:
+	$(MAKE) -C oracle all
+
+microbench:
+	$(HIPCC) -O3 --offload-arch=$(ARCH) tools/microbench/valu_rates.hip -o tools/microbench/valu_rates.bin
+	$(HIPCC) -O3 --offload-arch=$(ARCH) -I$(CSRC) tools/microbench/fe_rates.hip -o tools/microbench/fe_rates.bin
+
+clean:
+	rm -rf $(BUILD) $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle microbench clean

@@ -1,0 +1,92 @@
+/*
+ * eddsa_amd.h - batched entry points of the MI355X Ed25519 / X25519 engine.
+ *
+ * Plain C ABI (pointers and sizes only).  Every function is the batched form of one function
+ * of the reference's public header and returns, item by item, exactly what a loop over the
+ * reference function returns:
+ *
+ *   ed25519_verify_batch   loop of ed25519_verify        reference lib/eddsa.h:52
+ *   ed25519_sign_batch     loop of ed25519_sign          reference lib/eddsa.h:47
+ *   ed25519_genpub_batch   loop of ed25519_genpub        reference lib/eddsa.h:44
+ *   x25519_batch           loop of x25519                reference lib/eddsa.h:67
+ *   x25519_base_batch      loop of x25519_base           reference lib/eddsa.h:64
+ *   pk_ed25519_to_x25519_batch / sk_ed25519_to_x25519_batch   reference lib/eddsa.h:77, :80
+ *
+ * Data layout: packed, item-major, no padding: item i of a 32-byte field lives at base + 32*i
+ * (signatures: base + 64*i).  Messages are either fixed-length (msg_off == NULL: item i is
+ * msgs[i*msg_len .. (i+1)*msg_len)) or ragged (msg_off[0..n]: item i is
+ * msgs[msg_off[i] .. msg_off[i+1])).  Verdicts are one byte per item (1 = accept, 0 = reject).
+ *
+ * Two flavours of every entry point:
+ *   *_batch      host pointers; copies in, runs, copies out, returns when done.
+ *   *_batch_dev  device pointers (HBM-resident buffers, e.g. torch tensors' data_ptr());
+ *                enqueues on `stream` (a hipStream_t passed as void*, NULL = default stream)
+ *                and returns without synchronising.
+ *
+ * Return value: 0 on success, otherwise the negated hipError_t of the failing HIP call (the
+ * reference has no error channel; a loop over it cannot fail).  On error the outputs are
+ * unspecified.  Ownership: the caller owns every buffer; the library keeps no pointer after a
+ * host-pointer call returns / after the stream work of a device-pointer call completes.
+ * Threading: calls may be issued from several host threads; calls that target the same device
+ * serialise on that device's workspace.
+ */
+#ifndef EDDSA_AMD_H
+#define EDDSA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__) && defined(EDDSA_BUILD)
+#define EDDSA_AMD_DECL __attribute__((visibility("default")))
+#else
+#define EDDSA_AMD_DECL
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Bind the calling process to HIP device `device` (>= 0), build the base-point tables there
+ * (what the reference ships as lib/ed_lookup64.h) and allocate the workspace.  Idempotent.
+ * The eddsa.h single-item functions and the *_batch functions call it with the current HIP
+ * device if it was never called. */
+EDDSA_AMD_DECL int eddsa_amd_init(int device);
+EDDSA_AMD_DECL void eddsa_amd_shutdown(void);
+/* human-readable text for a negative return value */
+EDDSA_AMD_DECL const char *eddsa_amd_strerror(int err);
+/* copy the device's generated tables out for inspection: base8 = 129 entries k*B, comb = 256
+ * entries (k+1)*256^i*B in the order of the reference's ed_lookup[i][k]; each entry 32 words:
+ * 10 radix-2^25.5 limbs of y-x, y+x, 2dxy, then 2 words of padding. */
+EDDSA_AMD_DECL int eddsa_amd_dump_tables(uint32_t *base8_words, uint32_t *comb_words);
+
+/* ---- host-pointer entry points ---- */
+EDDSA_AMD_DECL int ed25519_verify_batch(uint8_t *ok, const uint8_t *sigs, const uint8_t *pubs,
+                                        const uint8_t *msgs, const uint64_t *msg_off, size_t msg_len,
+                                        size_t n);
+EDDSA_AMD_DECL int ed25519_sign_batch(uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs,
+                                      const uint8_t *msgs, const uint64_t *msg_off, size_t msg_len,
+                                      size_t n);
+EDDSA_AMD_DECL int ed25519_genpub_batch(uint8_t *pubs, const uint8_t *secs, size_t n);
+EDDSA_AMD_DECL int x25519_batch(uint8_t *out, const uint8_t *scalars, const uint8_t *points, size_t n);
+EDDSA_AMD_DECL int x25519_base_batch(uint8_t *out, const uint8_t *scalars, size_t n);
+EDDSA_AMD_DECL int pk_ed25519_to_x25519_batch(uint8_t *out, const uint8_t *in, size_t n);
+EDDSA_AMD_DECL int sk_ed25519_to_x25519_batch(uint8_t *out, const uint8_t *in, size_t n);
+
+/* ---- device-pointer entry points (asynchronous on `stream`) ---- */
+EDDSA_AMD_DECL int ed25519_verify_batch_dev(uint8_t *ok, const uint8_t *sigs, const uint8_t *pubs,
+                                            const uint8_t *msgs, const uint64_t *msg_off,
+                                            size_t msg_len, size_t n, void *stream);
+EDDSA_AMD_DECL int ed25519_sign_batch_dev(uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs,
+                                          const uint8_t *msgs, const uint64_t *msg_off,
+                                          size_t msg_len, size_t n, void *stream);
+EDDSA_AMD_DECL int ed25519_genpub_batch_dev(uint8_t *pubs, const uint8_t *secs, size_t n, void *stream);
+EDDSA_AMD_DECL int x25519_batch_dev(uint8_t *out, const uint8_t *scalars, const uint8_t *points,
+                                    size_t n, void *stream);
+EDDSA_AMD_DECL int x25519_base_batch_dev(uint8_t *out, const uint8_t *scalars, size_t n, void *stream);
+EDDSA_AMD_DECL int pk_ed25519_to_x25519_batch_dev(uint8_t *out, const uint8_t *in, size_t n, void *stream);
+EDDSA_AMD_DECL int sk_ed25519_to_x25519_batch_dev(uint8_t *out, const uint8_t *in, size_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDDSA_AMD_H */

@@ -1,0 +1,406 @@
+/*
+ * eddsa_amd.c - host side of libeddsa_amd.so, plain C.
+ *
+ * Exports the thirteen symbols of the reference's public header (include/eddsa.h, reference
+ * lib/eddsa.h:44-113) and the batched entry points of include/eddsa_amd.h.  Everything is
+ * computed by the HIP kernels in kernels.hip; there is no CPU arithmetic in this file and no
+ * fallback: without a usable gfx950 device every entry point fails (batch API: negative return;
+ * eddsa.h API, which has no error channel: message on stderr + abort()).
+ */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "eddsa.h"
+#include "eddsa_amd.h"
+#include "eddsa_kernels.h"
+
+#define CHUNK_MAX ((size_t)1 << 20)   /* verify items per workspace pass: 1.6 GB of HBM workspace */
+
+struct engine {
+    int ready;
+    int device;
+    uint32_t *base8, *comb;           /* generated base-point tables (HBM) */
+    edk_verify_ws ws;                 /* verify workspace, grown on demand up to CHUNK_MAX items */
+    hipEvent_t ws_free;               /* recorded after the last kernel that touches ws */
+};
+
+static struct engine g_eng;
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+
+#define TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = -(int)e_; goto out; } } while (0)
+
+const char *eddsa_amd_strerror(int err)
+{
+    if (err == 0) return "success";
+    if (err == -100000) return "eddsa_amd: device is not gfx950 (MI355X); no code object for it";
+    return hipGetErrorString((hipError_t)(-err));
+}
+
+static void ws_release(struct engine *e)
+{
+    if (e->ws.digits) (void)hipFree(e->ws.digits);
+    if (e->ws.table) (void)hipFree(e->ws.table);
+    if (e->ws.acc) (void)hipFree(e->ws.acc);
+    if (e->ws.flags) (void)hipFree(e->ws.flags);
+    memset(&e->ws, 0, sizeof(e->ws));
+}
+
+/* caller holds g_lock */
+static int ws_reserve(struct engine *e, size_t items)
+{
+    int rc = 0;
+    size_t cap = (items + VERIFY_TILE - 1) / VERIFY_TILE * VERIFY_TILE;
+    if (cap <= e->ws.capacity) return 0;
+    /* the old buffers may still be in use by enqueued kernels */
+    TRY(hipEventSynchronize(e->ws_free));
+    ws_release(e);
+    TRY(hipMalloc((void **)&e->ws.digits, cap * 16 * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&e->ws.table, cap / VERIFY_TILE * (size_t)VERIFY_TABLE_WORDS_PER_TILE * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&e->ws.acc, cap * 30 * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&e->ws.flags, cap));
+    e->ws.capacity = cap;
+out:
+    if (rc) ws_release(e);
+    return rc;
+}
+
+int eddsa_amd_init(int device)
+{
+    int rc = 0;
+    hipDeviceProp_t prop;
+    pthread_mutex_lock(&g_lock);
+    if (g_eng.ready && g_eng.device == device) goto out;
+    if (g_eng.ready) {                /* re-bind to another device */
+        ws_release(&g_eng);
+        (void)hipFree(g_eng.base8); (void)hipFree(g_eng.comb); (void)hipEventDestroy(g_eng.ws_free);
+        memset(&g_eng, 0, sizeof(g_eng));
+    }
+    TRY(hipSetDevice(device));
+    TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { rc = -100000; goto out; }
+    TRY(hipMalloc((void **)&g_eng.base8, TABLE_BASE8_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&g_eng.comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t)));
+    TRY(hipEventCreateWithFlags(&g_eng.ws_free, hipEventDisableTiming));
+    TRY(edk_init_tables(g_eng.base8, g_eng.comb, NULL));
+    TRY(hipEventRecord(g_eng.ws_free, NULL));
+    TRY(hipDeviceSynchronize());
+    g_eng.device = device;
+    g_eng.ready = 1;
+out:
+    pthread_mutex_unlock(&g_lock);
+    return rc;
+}
+
+void eddsa_amd_shutdown(void)
+{
+    pthread_mutex_lock(&g_lock);
+    if (g_eng.ready) {
+        (void)hipDeviceSynchronize();
+        ws_release(&g_eng);
+        (void)hipFree(g_eng.base8); (void)hipFree(g_eng.comb); (void)hipEventDestroy(g_eng.ws_free);
+        memset(&g_eng, 0, sizeof(g_eng));
+    }
+    pthread_mutex_unlock(&g_lock);
+}
+
+static int ensure_init(void)
+{
+    int dev = 0;
+    if (g_eng.ready) return 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return -(int)e;
+    return eddsa_amd_init(dev);
+}
+
+int eddsa_amd_dump_tables(uint32_t *base8_words, uint32_t *comb_words)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    TRY(hipMemcpy(base8_words, g_eng.base8, TABLE_BASE8_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    TRY(hipMemcpy(comb_words, g_eng.comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
+out:
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * device-pointer entry points
+ * ---------------------------------------------------------------------------------------- */
+
+int ed25519_verify_batch_dev(uint8_t *ok, const uint8_t *sigs, const uint8_t *pubs, const uint8_t *msgs,
+                             const uint64_t *msg_off, size_t msg_len, size_t n, void *stream)
+{
+    int rc = ensure_init();
+    hipStream_t st = (hipStream_t)stream;
+    if (rc || n == 0) return rc;
+    pthread_mutex_lock(&g_lock);
+    rc = ws_reserve(&g_eng, n < CHUNK_MAX ? n : CHUNK_MAX);
+    if (rc) goto out;
+    /* the workspace is shared: order this call behind the previous one even across streams */
+    TRY(hipStreamWaitEvent(st, g_eng.ws_free, 0));
+    for (size_t done = 0; done < n; done += CHUNK_MAX) {
+        size_t m = n - done < CHUNK_MAX ? n - done : CHUNK_MAX;
+        const uint8_t *mp = msgs;
+        const uint64_t *op = NULL;
+        if (msg_off) op = msg_off + done; else mp = msgs + done * msg_len;
+        TRY(edk_verify(ok + done, sigs + 64 * done, pubs + 32 * done, mp, op, msg_len, m, g_eng.base8,
+                       &g_eng.ws, st));
+    }
+    TRY(hipEventRecord(g_eng.ws_free, st));
+out:
+    pthread_mutex_unlock(&g_lock);
+    return rc;
+}
+
+int ed25519_sign_batch_dev(uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs, const uint8_t *msgs,
+                           const uint64_t *msg_off, size_t msg_len, size_t n, void *stream)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    TRY(edk_sign(sigs, secs, pubs, msgs, msg_off, msg_len, n, g_eng.comb, (hipStream_t)stream));
+out:
+    return rc;
+}
+
+int ed25519_genpub_batch_dev(uint8_t *pubs, const uint8_t *secs, size_t n, void *stream)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    TRY(edk_genpub(pubs, secs, n, g_eng.comb, (hipStream_t)stream));
+out:
+    return rc;
+}
+
+int x25519_batch_dev(uint8_t *out, const uint8_t *scalars, const uint8_t *points, size_t n, void *stream)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    TRY(edk_x25519(out, scalars, points, n, (hipStream_t)stream));
+out:
+    return rc;
+}
+
+int x25519_base_batch_dev(uint8_t *out, const uint8_t *scalars, size_t n, void *stream)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    TRY(edk_x25519_base(out, scalars, n, g_eng.comb, (hipStream_t)stream));
+out:
+    return rc;
+}
+
+int pk_ed25519_to_x25519_batch_dev(uint8_t *out, const uint8_t *in, size_t n, void *stream)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    TRY(edk_pk_to_x(out, in, n, (hipStream_t)stream));
+out:
+    return rc;
+}
+
+int sk_ed25519_to_x25519_batch_dev(uint8_t *out, const uint8_t *in, size_t n, void *stream)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    TRY(edk_sk_to_x(out, in, n, (hipStream_t)stream));
+out:
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * host-pointer entry points: stage through HBM, run the device-pointer form, copy back
+ * ---------------------------------------------------------------------------------------- */
+
+#define MAX_BUFS 6
+struct staging { void *dev[MAX_BUFS]; int count; };
+
+static void staging_free(struct staging *s)
+{
+    for (int i = 0; i < s->count; i++) if (s->dev[i]) (void)hipFree(s->dev[i]);
+    s->count = 0;
+}
+
+/* allocate `bytes` (at least 16, so that empty inputs still give a valid pointer) and upload */
+static int staging_in(struct staging *s, void **out, const void *host, size_t bytes)
+{
+    void *d = NULL;
+    hipError_t e = hipMalloc(&d, bytes ? bytes : 16);
+    if (e != hipSuccess) return -(int)e;
+    s->dev[s->count++] = d;
+    if (host && bytes) {
+        e = hipMemcpy(d, host, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return -(int)e;
+    }
+    *out = d;
+    return 0;
+}
+
+#define STAGE(ptr, host, bytes) do { rc = staging_in(&st, (void **)&(ptr), (host), (bytes)); if (rc) goto out; } while (0)
+
+static size_t msgs_total(const uint64_t *msg_off, size_t msg_len, size_t n)
+{
+    return msg_off ? (size_t)msg_off[n] : msg_len * n;
+}
+
+int ed25519_verify_batch(uint8_t *ok, const uint8_t *sigs, const uint8_t *pubs, const uint8_t *msgs,
+                         const uint64_t *msg_off, size_t msg_len, size_t n)
+{
+    struct staging st = { {0}, 0 };
+    uint8_t *d_ok, *d_sig, *d_pub, *d_msg; uint64_t *d_off = NULL;
+    int rc = ensure_init();
+    if (rc || n == 0) return rc;
+    STAGE(d_ok, NULL, n);
+    STAGE(d_sig, sigs, 64 * n);
+    STAGE(d_pub, pubs, 32 * n);
+    STAGE(d_msg, msgs, msgs_total(msg_off, msg_len, n));
+    if (msg_off) STAGE(d_off, msg_off, (n + 1) * sizeof(uint64_t));
+    rc = ed25519_verify_batch_dev(d_ok, d_sig, d_pub, d_msg, d_off, msg_len, n, NULL);
+    if (rc) goto out;
+    TRY(hipMemcpy(ok, d_ok, n, hipMemcpyDeviceToHost));
+out:
+    staging_free(&st);
+    return rc;
+}
+
+int ed25519_sign_batch(uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs, const uint8_t *msgs,
+                       const uint64_t *msg_off, size_t msg_len, size_t n)
+{
+    struct staging st = { {0}, 0 };
+    uint8_t *d_sig, *d_sec, *d_pub, *d_msg; uint64_t *d_off = NULL;
+    int rc = ensure_init();
+    if (rc || n == 0) return rc;
+    STAGE(d_sig, NULL, 64 * n);
+    STAGE(d_sec, secs, 32 * n);
+    STAGE(d_pub, pubs, 32 * n);
+    STAGE(d_msg, msgs, msgs_total(msg_off, msg_len, n));
+    if (msg_off) STAGE(d_off, msg_off, (n + 1) * sizeof(uint64_t));
+    rc = ed25519_sign_batch_dev(d_sig, d_sec, d_pub, d_msg, d_off, msg_len, n, NULL);
+    if (rc) goto out;
+    TRY(hipMemcpy(sigs, d_sig, 64 * n, hipMemcpyDeviceToHost));
+out:
+    staging_free(&st);
+    return rc;
+}
+
+/* 32 bytes in -> 32 bytes out, one or two inputs */
+typedef int (*dev1_fn)(uint8_t *, const uint8_t *, size_t, void *);
+
+static int run_1in(dev1_fn fn, uint8_t *out, const uint8_t *in, size_t n)
+{
+    struct staging st = { {0}, 0 };
+    uint8_t *d_out, *d_in;
+    int rc = ensure_init();
+    if (rc || n == 0) return rc;
+    STAGE(d_out, NULL, 32 * n);
+    STAGE(d_in, in, 32 * n);
+    rc = fn(d_out, d_in, n, NULL);
+    if (rc) goto out;
+    TRY(hipMemcpy(out, d_out, 32 * n, hipMemcpyDeviceToHost));
+out:
+    staging_free(&st);
+    return rc;
+}
+
+int ed25519_genpub_batch(uint8_t *pubs, const uint8_t *secs, size_t n)
+{
+    return run_1in(ed25519_genpub_batch_dev, pubs, secs, n);
+}
+
+int x25519_base_batch(uint8_t *out, const uint8_t *scalars, size_t n)
+{
+    return run_1in(x25519_base_batch_dev, out, scalars, n);
+}
+
+int pk_ed25519_to_x25519_batch(uint8_t *out, const uint8_t *in, size_t n)
+{
+    return run_1in(pk_ed25519_to_x25519_batch_dev, out, in, n);
+}
+
+int sk_ed25519_to_x25519_batch(uint8_t *out, const uint8_t *in, size_t n)
+{
+    return run_1in(sk_ed25519_to_x25519_batch_dev, out, in, n);
+}
+
+int x25519_batch(uint8_t *out, const uint8_t *scalars, const uint8_t *points, size_t n)
+{
+    struct staging st = { {0}, 0 };
+    uint8_t *d_out, *d_s, *d_p;
+    int rc = ensure_init();
+    if (rc || n == 0) return rc;
+    STAGE(d_out, NULL, 32 * n);
+    STAGE(d_s, scalars, 32 * n);
+    STAGE(d_p, points, 32 * n);
+    rc = x25519_batch_dev(d_out, d_s, d_p, n, NULL);
+    if (rc) goto out;
+    TRY(hipMemcpy(out, d_out, 32 * n, hipMemcpyDeviceToHost));
+out:
+    staging_free(&st);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * the eddsa.h surface: batches of one.  No error channel in these signatures, so fail loudly.
+ * ---------------------------------------------------------------------------------------- */
+
+static void must(int rc, const char *what)
+{
+    if (rc == 0) return;
+    fprintf(stderr, "libeddsa_amd: %s failed on the GPU path: %s (no CPU fallback exists)\n", what,
+            eddsa_amd_strerror(rc));
+    abort();
+}
+
+void ed25519_genpub(uint8_t pub[32], const uint8_t sec[32])
+{
+    must(ed25519_genpub_batch(pub, sec, 1), "ed25519_genpub");
+}
+
+void ed25519_sign(uint8_t sig[64], const uint8_t sec[32], const uint8_t pub[32], const uint8_t *data, size_t len)
+{
+    must(ed25519_sign_batch(sig, sec, pub, data, NULL, len, 1), "ed25519_sign");
+}
+
+bool ed25519_verify(const uint8_t sig[64], const uint8_t pub[32], const uint8_t *data, size_t len)
+{
+    uint8_t ok = 0;
+    must(ed25519_verify_batch(&ok, sig, pub, data, NULL, len, 1), "ed25519_verify");
+    return ok != 0;
+}
+
+void x25519_base(uint8_t out[32], const uint8_t scalar[32])
+{
+    must(x25519_base_batch(out, scalar, 1), "x25519_base");
+}
+
+void x25519(uint8_t out[32], const uint8_t scalar[32], const uint8_t point[32])
+{
+    must(x25519_batch(out, scalar, point, 1), "x25519");
+}
+
+void pk_ed25519_to_x25519(uint8_t out[32], const uint8_t in[32])
+{
+    must(pk_ed25519_to_x25519_batch(out, in, 1), "pk_ed25519_to_x25519");
+}
+
+void sk_ed25519_to_x25519(uint8_t out[32], const uint8_t in[32])
+{
+    must(sk_ed25519_to_x25519_batch(out, in, 1), "sk_ed25519_to_x25519");
+}
+
+/* reference lib/ed25519-sha512.c:270-324 and lib/x25519.c:232-243: the obsolete names */
+void eddsa_genpub(uint8_t pub[32], const uint8_t sec[32]) { ed25519_genpub(pub, sec); }
+void eddsa_sign(uint8_t sig[64], const uint8_t sec[32], const uint8_t pub[32], const uint8_t *data, size_t len)
+{
+    ed25519_sign(sig, sec, pub, data, len);
+}
+bool eddsa_verify(const uint8_t sig[64], const uint8_t pub[32], const uint8_t *data, size_t len)
+{
+    return ed25519_verify(sig, pub, data, len);
+}
+void DH(uint8_t out[32], const uint8_t sec[32], const uint8_t point[32]) { x25519(out, sec, point); }
+void eddsa_pk_eddsa_to_dh(uint8_t out[32], const uint8_t in[32]) { pk_ed25519_to_x25519(out, in); }
+void eddsa_sk_eddsa_to_dh(uint8_t out[32], const uint8_t in[32]) { sk_ed25519_to_x25519(out, in); }

@@ -1,0 +1,46 @@
+// eddsa_kernels.h - internal interface between the C host library (eddsa_amd.c) and the HIP
+// translation unit (kernels.hip).  Not installed; the public contract is include/eddsa_amd.h.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define TABLE_BASE8_ENTRIES 129   /* k*B, k = 0..128 */
+#define TABLE_COMB_ENTRIES 256    /* (k+1)*256^i*B, i < 32, k < 8: ed.c:41-43 ed_lookup */
+#define TABLE_ENTRY_WORDS 32      /* 3 x 10 limbs + 2 padding words */
+#define VERIFY_TABLE_ENTRIES 9    /* 0..8 times -A, cached form */
+#define VERIFY_TABLE_WORDS_PER_TILE (VERIFY_TABLE_ENTRIES * 40 * 256)
+#define VERIFY_TILE 256            /* items per tile = threads per block */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+hipError_t edk_init_tables(uint32_t* base8, uint32_t* comb, hipStream_t stream);
+hipError_t edk_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* points, size_t n,
+                      hipStream_t stream);
+/* verify workspace for up to `capacity` items (a multiple of VERIFY_TILE), all in HBM */
+typedef struct edk_verify_ws {
+  size_t capacity;
+  uint32_t* digits;   /* capacity * 16 words */
+  uint32_t* table;    /* capacity / 256 tiles * VERIFY_TABLE_WORDS_PER_TILE words */
+  uint32_t* acc;      /* capacity * 30 words */
+  uint8_t* flags;     /* capacity bytes */
+} edk_verify_ws;
+
+hipError_t edk_verify(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs,
+                      const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* base8,
+                      const edk_verify_ws* ws, hipStream_t stream);
+
+hipError_t edk_genpub(uint8_t* pubs, const uint8_t* secs, size_t n, const uint32_t* comb, hipStream_t stream);
+hipError_t edk_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, const uint8_t* msgs,
+                    const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* comb,
+                    hipStream_t stream);
+hipError_t edk_x25519_base(uint8_t* out, const uint8_t* scalars, size_t n, const uint32_t* comb,
+                           hipStream_t stream);
+hipError_t edk_pk_to_x(uint8_t* out, const uint8_t* in, size_t n, hipStream_t stream);
+hipError_t edk_sk_to_x(uint8_t* out, const uint8_t* in, size_t n, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif

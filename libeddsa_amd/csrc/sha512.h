@@ -1,0 +1,112 @@
+// sha512.h - SHA-512 on the device, one message per lane.
+//
+// Replaces the reference's lib/sha512.c (compress: sha512.c:83-124; padding and the 128-bit length
+// field: sha512.c:176-210) for the three hashes of the Ed25519 path:
+//   key setup   SHA-512(sk)                 ed25519-sha512.c:31-47
+//   nonce       SHA-512(h[32..64) || M)     ed25519-sha512.c:101-106
+//   challenge   SHA-512(R || A || M)        ed25519-sha512.c:113-118 and :166-171
+// i.e. always "a prefix of NPRE little-endian 32-bit words held in registers, then a message in
+// global memory".  All 80 rounds are unrolled so the 16-word schedule ring stays in registers.
+#pragma once
+#include "fe25519.h"
+
+namespace ed {
+
+__device__ __constant__ uint64_t SHA512_K[80] = {
+    0x428a2f98d728ae22ULL, 0x7137449123ef65cdULL, 0xb5c0fbcfec4d3b2fULL, 0xe9b5dba58189dbbcULL,
+    0x3956c25bf348b538ULL, 0x59f111f1b605d019ULL, 0x923f82a4af194f9bULL, 0xab1c5ed5da6d8118ULL,
+    0xd807aa98a3030242ULL, 0x12835b0145706fbeULL, 0x243185be4ee4b28cULL, 0x550c7dc3d5ffb4e2ULL,
+    0x72be5d74f27b896fULL, 0x80deb1fe3b1696b1ULL, 0x9bdc06a725c71235ULL, 0xc19bf174cf692694ULL,
+    0xe49b69c19ef14ad2ULL, 0xefbe4786384f25e3ULL, 0x0fc19dc68b8cd5b5ULL, 0x240ca1cc77ac9c65ULL,
+    0x2de92c6f592b0275ULL, 0x4a7484aa6ea6e483ULL, 0x5cb0a9dcbd41fbd4ULL, 0x76f988da831153b5ULL,
+    0x983e5152ee66dfabULL, 0xa831c66d2db43210ULL, 0xb00327c898fb213fULL, 0xbf597fc7beef0ee4ULL,
+    0xc6e00bf33da88fc2ULL, 0xd5a79147930aa725ULL, 0x06ca6351e003826fULL, 0x142929670a0e6e70ULL,
+    0x27b70a8546d22ffcULL, 0x2e1b21385c26c926ULL, 0x4d2c6dfc5ac42aedULL, 0x53380d139d95b3dfULL,
+    0x650a73548baf63deULL, 0x766a0abb3c77b2a8ULL, 0x81c2c92e47edaee6ULL, 0x92722c851482353bULL,
+    0xa2bfe8a14cf10364ULL, 0xa81a664bbc423001ULL, 0xc24b8b70d0f89791ULL, 0xc76c51a30654be30ULL,
+    0xd192e819d6ef5218ULL, 0xd69906245565a910ULL, 0xf40e35855771202aULL, 0x106aa07032bbd1b8ULL,
+    0x19a4c116b8d2d0c8ULL, 0x1e376c085141ab53ULL, 0x2748774cdf8eeb99ULL, 0x34b0bcb5e19b48a8ULL,
+    0x391c0cb3c5c95a63ULL, 0x4ed8aa4ae3418acbULL, 0x5b9cca4f7763e373ULL, 0x682e6ff3d6b2b8a3ULL,
+    0x748f82ee5defb2fcULL, 0x78a5636f43172f60ULL, 0x84c87814a1f0ab72ULL, 0x8cc702081a6439ecULL,
+    0x90befffa23631e28ULL, 0xa4506cebde82bde9ULL, 0xbef9a3f7b2c67915ULL, 0xc67178f2e372532bULL,
+    0xca273eceea26619cULL, 0xd186b8c721c0c207ULL, 0xeada7dd6cde0eb1eULL, 0xf57d4f7fee6ed178ULL,
+    0x06f067aa72176fbaULL, 0x0a637dc5a2c898a6ULL, 0x113f9804bef90daeULL, 0x1b710b35131c471bULL,
+    0x28db77f523047d84ULL, 0x32caab7b40c72493ULL, 0x3c9ebe0a15c9bebcULL, 0x431d67c49c100d4cULL,
+    0x4cc5d4becb3e42b6ULL, 0x597f299cfc657e2aULL, 0x5fcb6fab3ad6faecULL, 0x6c44198c4a475817ULL};
+
+ED_DEV uint64_t rotr64(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+
+// sha512.c:83-124 compress; w[] is consumed (used as the schedule ring)
+ED_DEV void sha512_compress(uint64_t st[8], uint64_t w[16]) {
+  uint64_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll
+  for (int r = 0; r < 80; r++) {
+    if (r >= 16) {
+      const uint64_t w15 = w[(r + 1) & 15], w2 = w[(r + 14) & 15];
+      w[r & 15] += (rotr64(w15, 1) ^ rotr64(w15, 8) ^ (w15 >> 7)) + w[(r + 9) & 15] +
+                   (rotr64(w2, 19) ^ rotr64(w2, 61) ^ (w2 >> 6));
+    }
+    const uint64_t t1 = h + (rotr64(e, 14) ^ rotr64(e, 18) ^ rotr64(e, 41)) + ((e & f) ^ (~e & g)) +
+                        SHA512_K[r] + w[r & 15];
+    const uint64_t t2 = (rotr64(a, 28) ^ rotr64(a, 34) ^ rotr64(a, 39)) + ((a & b) ^ (a & c) ^ (b & c));
+    h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+  }
+  st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+
+ED_DEV uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
+
+// little-endian 32-bit word number idx of the padded message tail: bytes of msg, then 0x80, then 0
+ED_DEV uint32_t sha_msg_word(const uint8_t* msg, size_t len, bool aligned, size_t idx) {
+  const size_t off = 4 * idx;
+  if (off + 4 <= len) {
+    if (aligned) return *reinterpret_cast<const uint32_t*>(msg + off);
+    return (uint32_t)msg[off] | ((uint32_t)msg[off + 1] << 8) | ((uint32_t)msg[off + 2] << 16) |
+           ((uint32_t)msg[off + 3] << 24);
+  }
+  uint32_t v = 0;
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const size_t pos = off + t;
+    const uint32_t byte = pos < len ? (uint32_t)msg[pos] : (pos == len ? 0x80u : 0u);
+    v |= byte << (8 * t);
+  }
+  return v;
+}
+
+// out[16] (little-endian words of the 64-byte digest) = SHA-512(pre[0..NPRE) || msg[0..len)).
+// NPRE is 0, 8 or 16 (so NPRE words never straddle the first block).
+template <int NPRE>
+ED_DEV void sha512_prefix_msg(uint32_t out[16], const uint32_t* pre, const uint8_t* msg, size_t len) {
+  uint64_t st[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL,
+                    0xa54ff53a5f1d36f1ULL, 0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL,
+                    0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+  const size_t total = 4 * (size_t)NPRE + len;
+  const size_t nblk = (total + 17 + 127) >> 7;
+  const bool aligned = (reinterpret_cast<uintptr_t>(msg) & 3) == 0;
+  uint64_t w[16];
+  for (size_t b = 0; b < nblk; b++) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      uint32_t lo32, hi32;   // stream words 2k (first in byte order) and 2k+1 of this block
+      if (b == 0 && 2 * k + 1 < NPRE) {
+        hi32 = pre[2 * k];
+        lo32 = pre[2 * k + 1];
+      } else {
+        const size_t g = 32 * b + 2 * k - NPRE;
+        hi32 = sha_msg_word(msg, len, aligned, g);
+        lo32 = sha_msg_word(msg, len, aligned, g + 1);
+      }
+      w[k] = ((uint64_t)bswap32(hi32) << 32) | bswap32(lo32);
+    }
+    if (b == nblk - 1) w[15] = (uint64_t)total << 3;   // sha512.c:196-203 (high 64 bits are 0)
+    sha512_compress(st, w);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    out[2 * k] = bswap32((uint32_t)(st[k] >> 32));
+    out[2 * k + 1] = bswap32((uint32_t)st[k]);
+  }
+}
+
+}  // namespace ed
