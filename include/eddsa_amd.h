@@ -59,6 +59,12 @@ EDDSA_AMD_DECL const char *eddsa_amd_strerror(int err);
  * 10 radix-2^25.5 limbs of y-x, y+x, 2dxy, then 2 words of padding. */
 EDDSA_AMD_DECL int eddsa_amd_dump_tables(uint32_t *base8_words, uint32_t *comb_words);
 
+/* measurement aid: when on, HIP events are recorded on the launch stream around the three kernels
+ * of every verify pass (up to 256 passes); eddsa_amd_verify_phase_ms() waits for them and returns
+ * the average duration of each kernel (prepare, main, finish) in milliseconds. */
+EDDSA_AMD_DECL void eddsa_amd_set_profiling(int on);
+EDDSA_AMD_DECL int eddsa_amd_verify_phase_ms(float out[3]);
+
 /* ---- host-pointer entry points ---- */
 EDDSA_AMD_DECL int ed25519_verify_batch(uint8_t *ok, const uint8_t *sigs, const uint8_t *pubs,
                                         const uint8_t *msgs, const uint64_t *msg_off, size_t msg_len,

@@ -1,0 +1,42 @@
+"""libeddsa_amd - Python host mirror of the MI355X Ed25519 / X25519 engine.
+
+Thin ctypes binding over the C-ABI library ``libeddsa_amd.so`` (include/eddsa.h,
+include/eddsa_amd.h).  Names, argument meaning and error behaviour mirror the reference's
+public header (reference lib/eddsa.h:44-113); the ``*_batch`` functions are the batched
+forms.  There is no CPU implementation behind any of them: importing works anywhere, but the
+first call that needs the GPU raises :class:`EddsaAmdError` if the library or a gfx950
+device is missing.
+"""
+from .api import (  # noqa: F401
+    EddsaAmdError,
+    DH,
+    ed25519_genpub,
+    ed25519_genpub_batch,
+    ed25519_sign,
+    ed25519_sign_batch,
+    ed25519_verify,
+    ed25519_verify_batch,
+    eddsa_genpub,
+    eddsa_pk_eddsa_to_dh,
+    eddsa_sign,
+    eddsa_sk_eddsa_to_dh,
+    eddsa_verify,
+    init,
+    library,
+    library_path,
+    pk_ed25519_to_x25519,
+    pk_ed25519_to_x25519_batch,
+    sk_ed25519_to_x25519,
+    set_profiling,
+    sk_ed25519_to_x25519_batch,
+    verify_phase_ms,
+    x25519,
+    x25519_base,
+    x25519_base_batch,
+    x25519_batch,
+)
+from .sharding import gather_bytes, shard_bounds  # noqa: F401
+
+ED25519_KEY_LEN = 32
+ED25519_SIG_LEN = 64
+X25519_KEY_LEN = 32

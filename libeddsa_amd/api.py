@@ -1,0 +1,343 @@
+"""ctypes binding of libeddsa_amd.so.
+
+Batch functions accept either
+  * torch CUDA tensors (dtype uint8, contiguous): the device-pointer entry points are used,
+    work is enqueued on torch's current stream and the result tensor is returned without a
+    host synchronisation; or
+  * numpy uint8 arrays / bytes: the host-pointer entry points are used (copy in, run, copy out).
+Item layout is the packed item-major layout of include/eddsa_amd.h.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_c_size = ctypes.c_size_t
+_c_ptr = ctypes.c_void_p
+
+
+class EddsaAmdError(RuntimeError):
+    """A HIP call behind the engine failed (or the engine library is missing)."""
+
+
+def library_path():
+    return os.path.join(_HERE, "libeddsa_amd.so")
+
+
+def library():
+    """Load libeddsa_amd.so (built in-tree by `make` / __graft_entry__.build())."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise EddsaAmdError(
+                f"{path} is missing: build it with `make` (hipcc --offload-arch=gfx950); "
+                "there is no CPU fallback")
+        lib = ctypes.CDLL(path)
+        lib.eddsa_amd_strerror.restype = ctypes.c_char_p
+        lib.ed25519_verify.restype = ctypes.c_bool
+        lib.eddsa_verify.restype = ctypes.c_bool
+        _LIB = lib
+    return _LIB
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = library().eddsa_amd_strerror(rc).decode()
+        raise EddsaAmdError(f"{what}: {msg} (rc={rc}); the engine has no CPU fallback")
+
+
+def init(device=None):
+    """Bind the engine to a HIP device (default: torch's / HIP's current device)."""
+    if device is None:
+        try:
+            import torch
+            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        except ImportError:
+            device = 0
+    _check(library().eddsa_amd_init(int(device)), "eddsa_amd_init")
+
+
+def verify_phase_ms():
+    """(prepare, main, finish) kernel durations in ms of the last profiled verify pass, measured
+    with HIP events on the launch stream (enable with set_profiling(True))."""
+    out = (ctypes.c_float * 3)()
+    _check(library().eddsa_amd_verify_phase_ms(out), "eddsa_amd_verify_phase_ms")
+    return tuple(out)
+
+
+def set_profiling(on):
+    library().eddsa_amd_set_profiling(int(bool(on)))
+
+
+# ---------------------------------------------------------------------------------------------
+# argument plumbing
+# ---------------------------------------------------------------------------------------------
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _as_np(x, width, name):
+    a = np.frombuffer(x, dtype=np.uint8) if isinstance(x, (bytes, bytearray, memoryview)) else np.asarray(x)
+    if a.dtype != np.uint8:
+        raise TypeError(f"{name}: expected uint8 data")
+    a = np.ascontiguousarray(a)
+    if width and a.size % width:
+        raise ValueError(f"{name}: size {a.size} is not a multiple of {width}")
+    return a
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(_c_ptr)
+
+
+def _torch_check(t, width, name):
+    import torch
+    if t.dtype != torch.uint8 or not t.is_cuda or not t.is_contiguous():
+        raise TypeError(f"{name}: expected a contiguous CUDA uint8 tensor")
+    if width and t.numel() % width:
+        raise ValueError(f"{name}: size {t.numel()} is not a multiple of {width}")
+    return t
+
+
+def _stream():
+    import torch
+    return _c_ptr(torch.cuda.current_stream().cuda_stream)
+
+
+def _msg_args(msgs, msg_off, msg_len, n, on_device):
+    """-> (msgs_ptr_holder, off_ptr_holder, msg_len)"""
+    if msg_off is None:
+        if msg_len is None:
+            total = msgs.numel() if on_device else msgs.size
+            if n == 0:
+                msg_len = 0
+            elif total % n:
+                raise ValueError("msgs: size is not a multiple of the batch size; pass msg_len or msg_off")
+            else:
+                msg_len = total // n
+        return msgs, None, int(msg_len)
+    return msgs, msg_off, 0
+
+
+def _run_32(fn_host, fn_dev, what, inputs, out_width, n_from):
+    """common driver for fixed-width kernels: inputs = [(array, width, name), ...]"""
+    lib = library()
+    first = inputs[0][0]
+    if _is_torch(first):
+        import torch
+        ts = [_torch_check(t, w, nm) for t, w, nm in inputs]
+        n = ts[0].numel() // n_from
+        for t, (_, w, nm) in zip(ts, inputs):
+            if t.numel() // w != n:
+                raise ValueError(f"{what}: {nm} holds {t.numel() // w} items, expected {n}")
+        out = torch.empty((n, out_width), dtype=torch.uint8, device=ts[0].device)
+        args = [_c_ptr(out.data_ptr())] + [_c_ptr(t.data_ptr()) for t in ts] + [_c_size(n), _stream()]
+        _check(getattr(lib, fn_dev)(*args), what)
+        return out
+    arrs = [_as_np(a, w, nm) for a, w, nm in inputs]
+    n = arrs[0].size // n_from
+    for a, (_, w, nm) in zip(arrs, inputs):
+        if a.size // w != n:
+            raise ValueError(f"{what}: {nm} holds {a.size // w} items, expected {n}")
+    out = np.zeros((n, out_width), dtype=np.uint8)
+    args = [_np_ptr(out)] + [_np_ptr(a) for a in arrs] + [_c_size(n)]
+    _check(getattr(lib, fn_host)(*args), what)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# batched entry points (include/eddsa_amd.h)
+# ---------------------------------------------------------------------------------------------
+
+def x25519_batch(scalars, points):
+    """loop of x25519 (reference lib/eddsa.h:67) -> (n, 32) uint8"""
+    return _run_32("x25519_batch", "x25519_batch_dev", "x25519_batch",
+                   [(scalars, 32, "scalars"), (points, 32, "points")], 32, 32)
+
+
+def x25519_base_batch(scalars):
+    """loop of x25519_base (reference lib/eddsa.h:64)"""
+    return _run_32("x25519_base_batch", "x25519_base_batch_dev", "x25519_base_batch",
+                   [(scalars, 32, "scalars")], 32, 32)
+
+
+def ed25519_genpub_batch(secs):
+    """loop of ed25519_genpub (reference lib/eddsa.h:44)"""
+    return _run_32("ed25519_genpub_batch", "ed25519_genpub_batch_dev", "ed25519_genpub_batch",
+                   [(secs, 32, "secs")], 32, 32)
+
+
+def pk_ed25519_to_x25519_batch(pubs):
+    """loop of pk_ed25519_to_x25519 (reference lib/eddsa.h:77)"""
+    return _run_32("pk_ed25519_to_x25519_batch", "pk_ed25519_to_x25519_batch_dev",
+                   "pk_ed25519_to_x25519_batch", [(pubs, 32, "pubs")], 32, 32)
+
+
+def sk_ed25519_to_x25519_batch(secs):
+    """loop of sk_ed25519_to_x25519 (reference lib/eddsa.h:80)"""
+    return _run_32("sk_ed25519_to_x25519_batch", "sk_ed25519_to_x25519_batch_dev",
+                   "sk_ed25519_to_x25519_batch", [(secs, 32, "secs")], 32, 32)
+
+
+def ed25519_verify_batch(sigs, pubs, msgs, msg_off=None, msg_len=None):
+    """loop of ed25519_verify (reference lib/eddsa.h:52) -> (n,) uint8, 1 = accept.
+
+    msgs is the concatenation of all messages; either every message has msg_len bytes
+    (default: len(msgs) / n) or msg_off[0..n] (uint64) gives the ragged boundaries."""
+    lib = library()
+    if _is_torch(sigs):
+        import torch
+        sigs = _torch_check(sigs, 64, "sigs"); pubs = _torch_check(pubs, 32, "pubs")
+        msgs = _torch_check(msgs, 0, "msgs")
+        n = sigs.numel() // 64
+        if pubs.numel() // 32 != n:
+            raise ValueError("ed25519_verify_batch: sigs and pubs disagree on the batch size")
+        _, off, mlen = _msg_args(msgs, msg_off, msg_len, n, True)
+        if off is not None and (off.dtype != torch.int64 and off.dtype != torch.uint64 or off.numel() != n + 1):
+            raise ValueError("msg_off: expected n+1 int64/uint64 offsets on the device")
+        ok = torch.empty((n,), dtype=torch.uint8, device=sigs.device)
+        _check(lib.ed25519_verify_batch_dev(_c_ptr(ok.data_ptr()), _c_ptr(sigs.data_ptr()), _c_ptr(pubs.data_ptr()),
+                                            _c_ptr(msgs.data_ptr()), _c_ptr(off.data_ptr()) if off is not None else None,
+                                            _c_size(mlen), _c_size(n), _stream()), "ed25519_verify_batch")
+        return ok
+    sigs = _as_np(sigs, 64, "sigs"); pubs = _as_np(pubs, 32, "pubs"); msgs = _as_np(msgs, 0, "msgs")
+    n = sigs.size // 64
+    if pubs.size // 32 != n:
+        raise ValueError("ed25519_verify_batch: sigs and pubs disagree on the batch size")
+    _, off, mlen = _msg_args(msgs, msg_off, msg_len, n, False)
+    if off is not None:
+        off = np.ascontiguousarray(np.asarray(off, dtype=np.uint64))
+        if off.size != n + 1 or (n and int(off[-1]) > msgs.size):
+            raise ValueError("msg_off: expected n+1 offsets within msgs")
+    ok = np.zeros((n,), dtype=np.uint8)
+    _check(lib.ed25519_verify_batch(_np_ptr(ok), _np_ptr(sigs), _np_ptr(pubs), _np_ptr(msgs),
+                                    _np_ptr(off) if off is not None else None, _c_size(mlen), _c_size(n)),
+           "ed25519_verify_batch")
+    return ok
+
+
+def ed25519_sign_batch(secs, pubs, msgs, msg_off=None, msg_len=None):
+    """loop of ed25519_sign (reference lib/eddsa.h:47) -> (n, 64) uint8"""
+    lib = library()
+    if _is_torch(secs):
+        import torch
+        secs = _torch_check(secs, 32, "secs"); pubs = _torch_check(pubs, 32, "pubs")
+        msgs = _torch_check(msgs, 0, "msgs")
+        n = secs.numel() // 32
+        if pubs.numel() // 32 != n:
+            raise ValueError("ed25519_sign_batch: secs and pubs disagree on the batch size")
+        _, off, mlen = _msg_args(msgs, msg_off, msg_len, n, True)
+        sig = torch.empty((n, 64), dtype=torch.uint8, device=secs.device)
+        _check(lib.ed25519_sign_batch_dev(_c_ptr(sig.data_ptr()), _c_ptr(secs.data_ptr()), _c_ptr(pubs.data_ptr()),
+                                          _c_ptr(msgs.data_ptr()), _c_ptr(off.data_ptr()) if off is not None else None,
+                                          _c_size(mlen), _c_size(n), _stream()), "ed25519_sign_batch")
+        return sig
+    secs = _as_np(secs, 32, "secs"); pubs = _as_np(pubs, 32, "pubs"); msgs = _as_np(msgs, 0, "msgs")
+    n = secs.size // 32
+    if pubs.size // 32 != n:
+        raise ValueError("ed25519_sign_batch: secs and pubs disagree on the batch size")
+    _, off, mlen = _msg_args(msgs, msg_off, msg_len, n, False)
+    if off is not None:
+        off = np.ascontiguousarray(np.asarray(off, dtype=np.uint64))
+        if off.size != n + 1 or (n and int(off[-1]) > msgs.size):
+            raise ValueError("msg_off: expected n+1 offsets within msgs")
+    sig = np.zeros((n, 64), dtype=np.uint8)
+    _check(lib.ed25519_sign_batch(_np_ptr(sig), _np_ptr(secs), _np_ptr(pubs), _np_ptr(msgs),
+                                  _np_ptr(off) if off is not None else None, _c_size(mlen), _c_size(n)),
+           "ed25519_sign_batch")
+    return sig
+
+
+# ---------------------------------------------------------------------------------------------
+# the eddsa.h surface (single items; bytes in, bytes out), reference lib/eddsa.h:44-113
+# ---------------------------------------------------------------------------------------------
+
+def _b(x, n, name):
+    x = bytes(x)
+    if len(x) != n:
+        raise ValueError(f"{name}: expected {n} bytes, got {len(x)}")
+    return x
+
+
+def ed25519_genpub(sec):
+    out = ctypes.create_string_buffer(32)
+    library().ed25519_genpub(out, _b(sec, 32, "sec"))
+    return out.raw
+
+
+def ed25519_sign(sec, pub, data):
+    out = ctypes.create_string_buffer(64)
+    data = bytes(data)
+    library().ed25519_sign(out, _b(sec, 32, "sec"), _b(pub, 32, "pub"), data, _c_size(len(data)))
+    return out.raw
+
+
+def ed25519_verify(sig, pub, data):
+    data = bytes(data)
+    return bool(library().ed25519_verify(_b(sig, 64, "sig"), _b(pub, 32, "pub"), data, _c_size(len(data))))
+
+
+def x25519_base(scalar):
+    out = ctypes.create_string_buffer(32)
+    library().x25519_base(out, _b(scalar, 32, "scalar"))
+    return out.raw
+
+
+def x25519(scalar, point):
+    out = ctypes.create_string_buffer(32)
+    library().x25519(out, _b(scalar, 32, "scalar"), _b(point, 32, "point"))
+    return out.raw
+
+
+def pk_ed25519_to_x25519(pub):
+    out = ctypes.create_string_buffer(32)
+    library().pk_ed25519_to_x25519(out, _b(pub, 32, "pub"))
+    return out.raw
+
+
+def sk_ed25519_to_x25519(sec):
+    out = ctypes.create_string_buffer(32)
+    library().sk_ed25519_to_x25519(out, _b(sec, 32, "sec"))
+    return out.raw
+
+
+# obsolete names kept by the reference (lib/eddsa.h:92-113)
+def eddsa_genpub(sec):
+    out = ctypes.create_string_buffer(32)
+    library().eddsa_genpub(out, _b(sec, 32, "sec"))
+    return out.raw
+
+
+def eddsa_sign(sec, pub, data):
+    out = ctypes.create_string_buffer(64)
+    data = bytes(data)
+    library().eddsa_sign(out, _b(sec, 32, "sec"), _b(pub, 32, "pub"), data, _c_size(len(data)))
+    return out.raw
+
+
+def eddsa_verify(sig, pub, data):
+    data = bytes(data)
+    return bool(library().eddsa_verify(_b(sig, 64, "sig"), _b(pub, 32, "pub"), data, _c_size(len(data))))
+
+
+def DH(sec, point):
+    out = ctypes.create_string_buffer(32)
+    library().DH(out, _b(sec, 32, "sec"), _b(point, 32, "point"))
+    return out.raw
+
+
+def eddsa_pk_eddsa_to_dh(pub):
+    out = ctypes.create_string_buffer(32)
+    library().eddsa_pk_eddsa_to_dh(out, _b(pub, 32, "pub"))
+    return out.raw
+
+
+def eddsa_sk_eddsa_to_dh(sec):
+    out = ctypes.create_string_buffer(32)
+    library().eddsa_sk_eddsa_to_dh(out, _b(sec, 32, "sec"))
+    return out.raw

@@ -20,6 +20,7 @@
 #include "eddsa_kernels.h"
 
 #define CHUNK_MAX ((size_t)1 << 20)   /* verify items per workspace pass: 1.6 GB of HBM workspace */
+#define MARK_SLOTS 256                /* profiled verify passes kept for eddsa_amd_verify_phase_ms */
 
 struct engine {
     int ready;
@@ -27,6 +28,9 @@ struct engine {
     uint32_t *base8, *comb;           /* generated base-point tables (HBM) */
     edk_verify_ws ws;                 /* verify workspace, grown on demand up to CHUNK_MAX items */
     hipEvent_t ws_free;               /* recorded after the last kernel that touches ws */
+    int profiling;                    /* record marks around the three verify kernels */
+    int marks_used;                   /* passes recorded since profiling was switched on */
+    hipEvent_t marks[MARK_SLOTS][4];
 };
 
 static struct engine g_eng;
@@ -86,6 +90,8 @@ int eddsa_amd_init(int device)
     TRY(hipMalloc((void **)&g_eng.base8, TABLE_BASE8_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&g_eng.comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t)));
     TRY(hipEventCreateWithFlags(&g_eng.ws_free, hipEventDisableTiming));
+    for (int s = 0; s < MARK_SLOTS; s++)
+        for (int i = 0; i < 4; i++) TRY(hipEventCreate(&g_eng.marks[s][i]));
     TRY(edk_init_tables(g_eng.base8, g_eng.comb, NULL));
     TRY(hipEventRecord(g_eng.ws_free, NULL));
     TRY(hipDeviceSynchronize());
@@ -127,6 +133,34 @@ out:
     return rc;
 }
 
+/* per-kernel timing of the verify pass, for bench.py's roofline line: HIP events recorded on the
+ * launch stream around k_verify_prepare / k_verify_main / k_verify_finish of the LAST chunk */
+void eddsa_amd_set_profiling(int on)
+{
+    g_eng.profiling = on != 0;
+    g_eng.marks_used = 0;
+}
+
+/* average duration (ms) of each of the three kernels over the passes recorded since profiling was
+ * switched on (at most MARK_SLOTS; later passes are not recorded) */
+int eddsa_amd_verify_phase_ms(float out[3])
+{
+    int rc = 0;
+    int used = g_eng.marks_used < MARK_SLOTS ? g_eng.marks_used : MARK_SLOTS;
+    if (!g_eng.ready || used == 0) return -(int)hipErrorNotReady;
+    out[0] = out[1] = out[2] = 0.0f;
+    for (int s = 0; s < used; s++) {
+        TRY(hipEventSynchronize(g_eng.marks[s][3]));
+        for (int i = 0; i < 3; i++) {
+            float ms = 0.0f;
+            TRY(hipEventElapsedTime(&ms, g_eng.marks[s][i], g_eng.marks[s][i + 1]));
+            out[i] += ms / (float)used;
+        }
+    }
+out:
+    return rc;
+}
+
 /* ------------------------------------------------------------------------------------------
  * device-pointer entry points
  * ---------------------------------------------------------------------------------------- */
@@ -147,8 +181,10 @@ int ed25519_verify_batch_dev(uint8_t *ok, const uint8_t *sigs, const uint8_t *pu
         const uint8_t *mp = msgs;
         const uint64_t *op = NULL;
         if (msg_off) op = msg_off + done; else mp = msgs + done * msg_len;
+        hipEvent_t *marks = NULL;
+        if (g_eng.profiling && g_eng.marks_used < MARK_SLOTS) marks = g_eng.marks[g_eng.marks_used++];
         TRY(edk_verify(ok + done, sigs + 64 * done, pubs + 32 * done, mp, op, msg_len, m, g_eng.base8,
-                       &g_eng.ws, st));
+                       &g_eng.ws, marks, st));
     }
     TRY(hipEventRecord(g_eng.ws_free, st));
 out:

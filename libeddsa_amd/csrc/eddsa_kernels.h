@@ -30,7 +30,8 @@ typedef struct edk_verify_ws {
 
 hipError_t edk_verify(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs,
                       const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* base8,
-                      const edk_verify_ws* ws, hipStream_t stream);
+                      const edk_verify_ws* ws, hipEvent_t* marks /* 4 events or NULL */,
+                      hipStream_t stream);
 
 hipError_t edk_genpub(uint8_t* pubs, const uint8_t* secs, size_t n, const uint32_t* comb, hipStream_t stream);
 hipError_t edk_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, const uint8_t* msgs,

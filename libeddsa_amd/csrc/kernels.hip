@@ -545,14 +545,18 @@ hipError_t edk_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* point
 
 hipError_t edk_verify(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs,
                       const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* base8,
-                      const edk_verify_ws* ws, hipStream_t stream) {
+                      const edk_verify_ws* ws, hipEvent_t* marks, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   const unsigned blocks = (unsigned)((n + BLOCK - 1) / BLOCK);
+  if (marks) (void)hipEventRecord(marks[0], stream);
   hipLaunchKernelGGL(k_verify_prepare, dim3(blocks), dim3(BLOCK), 0, stream, sigs, pubs, msgs, msg_off,
                      msg_len, n, ws->digits, ws->table, ws->flags);
+  if (marks) (void)hipEventRecord(marks[1], stream);
   hipLaunchKernelGGL(k_verify_main, dim3(blocks), dim3(BLOCK), 0, stream, ws->digits, ws->table, base8,
                      ws->acc, n);
+  if (marks) (void)hipEventRecord(marks[2], stream);
   hipLaunchKernelGGL(k_verify_finish, dim3(blocks), dim3(BLOCK), 0, stream, ok, sigs, ws->acc, ws->flags, n);
+  if (marks) (void)hipEventRecord(marks[3], stream);
   return hipGetLastError();
 }
 
