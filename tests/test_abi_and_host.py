@@ -1,0 +1,150 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol the public
+headers declare, fails loudly without a GPU (no CPU fallback), and the host-side logic (argument
+checks, sharding, workload generator, multi-rank gather over gloo) behaves."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib_path():
+    path = os.path.join(ROOT, "libeddsa_amd", "libeddsa_amd.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", ROOT, "libeddsa_amd/libeddsa_amd.so"])
+    return path
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"EDDSA(?:_AMD)?_DECL\s+[\w\s\*]+?\b(\w+)\s*\(", text))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_lib_path())
+    names = _declared("eddsa.h") | _declared("eddsa_amd.h")
+    assert {"ed25519_genpub", "ed25519_sign", "ed25519_verify", "x25519_base", "x25519", "pk_ed25519_to_x25519",
+            "sk_ed25519_to_x25519", "eddsa_genpub", "eddsa_sign", "eddsa_verify", "DH", "eddsa_pk_eddsa_to_dh",
+            "eddsa_sk_eddsa_to_dh"} <= names                      # the reference's 13 (lib/eddsa.h:44-113)
+    assert len(names) >= 13 + 14 + 5
+    for n in names:
+        assert hasattr(lib, n), n
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib_path()], text=True)
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert exported == names, exported ^ names                    # nothing else leaks out
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import libeddsa_amd as ed
+    with pytest.raises(ed.EddsaAmdError):
+        ed.x25519_batch(np.zeros((4, 32), np.uint8), np.zeros((4, 32), np.uint8))
+    with pytest.raises(ed.EddsaAmdError):
+        ed.ed25519_verify_batch(np.zeros((1, 64), np.uint8), np.zeros((1, 32), np.uint8), np.zeros((1, 8), np.uint8))
+    # the eddsa.h single-item functions have no error channel: they abort the process
+    code = ("import libeddsa_amd as ed; ed.x25519(bytes(32), bytes(32))")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr
+
+
+def test_product_does_not_reference_the_oracle():
+    """no file of the product imports, links or loads anything under oracle/"""
+    for base, _, files in os.walk(os.path.join(ROOT, "libeddsa_amd")):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip")):
+                text = open(os.path.join(base, f)).read()
+                assert "liboracle" not in text and "orc_" not in text and "_ref" not in text, f
+    out = subprocess.check_output(["ldd", _lib_path()], text=True)
+    assert "oracle" not in out
+
+
+def test_argument_validation():
+    import libeddsa_amd as ed
+    with pytest.raises(ValueError):
+        ed.x25519_batch(np.zeros(33, np.uint8), np.zeros(33, np.uint8))
+    with pytest.raises(ValueError):
+        ed.x25519_batch(np.zeros((2, 32), np.uint8), np.zeros((3, 32), np.uint8))
+    with pytest.raises(TypeError):
+        ed.ed25519_genpub_batch(np.zeros((2, 32), np.int32))
+    with pytest.raises(ValueError):
+        ed.ed25519_verify_batch(np.zeros((2, 64), np.uint8), np.zeros((2, 32), np.uint8), np.zeros(5, np.uint8))
+    with pytest.raises(ValueError):
+        ed.ed25519_verify_batch(np.zeros((2, 64), np.uint8), np.zeros((2, 32), np.uint8), np.zeros(5, np.uint8),
+                                msg_off=[0, 3, 9])
+    with pytest.raises(ValueError):
+        ed.ed25519_sign(bytes(31), bytes(32), b"")
+
+
+def test_shard_bounds_partition():
+    from libeddsa_amd import shard_bounds
+    for n in (0, 1, 7, 8, 1000, 1 << 24):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_bounds(1 << 24, 3, 8) == (3 << 21, 4 << 21)       # config 4: 2^21 per GPU
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
+
+
+def test_workload_is_deterministic_and_shardable():
+    import workload
+    a, b = workload.x25519_inputs(1000)
+    a2, b2 = workload.x25519_inputs(300, first=500)
+    assert np.array_equal(a[500:800], a2) and np.array_equal(b[500:800], b2)
+    assert a[0, :4].tolist() == [23, 167, 82, 220]                 # pinned first bytes of the stream
+    sig = np.zeros((64, 64), np.uint8); pub = np.zeros((64, 32), np.uint8); msg = np.zeros((64, 32), np.uint8)
+    exp = workload.corrupt_for_verify(sig, pub, msg)
+    assert exp.sum() == 60 and [i for i in range(64) if not exp[i]] == [5, 21, 37, 53]
+    flipped = [int(np.count_nonzero(x)) for x in (sig[:, :32], sig[:, 32:], pub, msg)]
+    assert flipped == [1, 1, 1, 1]                                  # R, S, A, msg round-robin
+
+
+_WORKER = r'''
+import os, sys, ctypes
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["REPO"]); sys.path.insert(0, os.path.join(os.environ["REPO"], "tools"))
+import workload
+from libeddsa_amd import shard_bounds, gather_bytes
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n = 1003                                   # ragged: shards of 502 and 501
+lo, hi = shard_bounds(n, rank, world)
+sc, pt = workload.x25519_inputs(hi - lo, first=lo)
+orc = ctypes.CDLL(os.path.join(os.environ["REPO"], "oracle", "liboracle.so"))
+out = np.zeros((hi - lo, 32), np.uint8)
+P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+orc.orc_x25519_batch(P(out), P(sc), P(pt), ctypes.c_size_t(hi - lo), 2)   # stand-in for the GPU shard
+full = gather_bytes(torch.from_numpy(out), n)
+sc_all, pt_all = workload.x25519_inputs(n)
+want = np.zeros((n, 32), np.uint8)
+orc.orc_x25519_batch(P(want), P(sc_all), P(pt_all), ctypes.c_size_t(n), 2)
+assert full.shape == (n, 32) and np.array_equal(full.numpy(), want), "gathered batch differs"
+ok = torch.from_numpy((np.arange(lo, hi) % 16 != 5).astype(np.uint8))
+allok = gather_bytes(ok, n)
+assert allok.shape == (n,) and int(allok.sum()) == int((np.arange(n) % 16 != 5).sum())
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_two_rank_shard_and_gather_over_gloo(oracle, tmp_path):
+    """N > 1 path: contiguous shards, independent compute, one all-gather of the result bytes."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, REPO=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29513", str(script)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout

@@ -1,0 +1,211 @@
+"""GPU parity tests: every entry point of the C-ABI (through the ctypes mirror) against the
+committed golden vectors and against the oracle on seeded random batches.  Bit-exact."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from gen_golden import golden_msg  # tools/ is on sys.path (conftest)
+
+pytestmark = pytest.mark.gpu
+H = bytes.fromhex
+L = 2**252 + 27742317777372353535851937790883648493
+P = 2**255 - 19
+
+
+def arr(rows):
+    return np.frombuffer(b"".join(rows), np.uint8).reshape(len(rows), -1).copy()
+
+
+def ragged(msgs):
+    off = np.zeros(len(msgs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(m) for m in msgs])
+    blob = np.frombuffer(b"".join(msgs), np.uint8).copy() if off[-1] else np.zeros(0, np.uint8)
+    return blob, off
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ---------------------------------------------------------------- golden vectors
+
+def test_x25519_reference_table(engine, golden):
+    raw = np.frombuffer(golden("x25519_table.bin"), np.uint8).reshape(1024, 96)
+    pt, sc, res = raw[:, :32].copy(), raw[:, 32:64].copy(), raw[:, 64:].copy()
+    assert np.array_equal(engine.x25519_batch(sc, pt), res)                    # host-pointer path
+    assert np.array_equal(engine.x25519_batch(dev(sc), dev(pt)).cpu().numpy(), res)   # device-pointer path
+    for i in (0, 1, 2, 500, 1023):                                             # eddsa.h surface
+        assert engine.x25519(sc[i].tobytes(), pt[i].tobytes()) == res[i].tobytes()
+        assert engine.DH(sc[i].tobytes(), pt[i].tobytes()) == res[i].tobytes()
+
+
+def test_ed25519_table(engine, golden):
+    raw = np.frombuffer(golden("ed25519_table.bin"), np.uint8).reshape(1024, 128)
+    sk, pk, sig = raw[:, :32].copy(), raw[:, 32:64].copy(), raw[:, 64:].copy()
+    msgs = [golden_msg(i) for i in range(1024)]          # entry i signs a message of i bytes
+    blob, off = ragged(msgs)
+    assert np.array_equal(engine.ed25519_genpub_batch(sk), pk)
+    assert np.array_equal(engine.ed25519_sign_batch(sk, pk, blob, msg_off=off), sig)
+    assert engine.ed25519_verify_batch(sig, pk, blob, msg_off=off).all()
+    import torch
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    assert np.array_equal(engine.ed25519_sign_batch(dev(sk), dev(pk), dev(blob), msg_off=d_off).cpu().numpy(), sig)
+    assert engine.ed25519_verify_batch(dev(sig), dev(pk), dev(blob), msg_off=d_off).all()
+    for i in (0, 1, 47, 48, 111, 112, 1023):
+        s, p_, g = sk[i].tobytes(), pk[i].tobytes(), sig[i].tobytes()
+        assert engine.ed25519_genpub(s) == p_ and engine.eddsa_genpub(s) == p_
+        assert engine.ed25519_sign(s, p_, msgs[i]) == g and engine.eddsa_sign(s, p_, msgs[i]) == g
+        assert engine.ed25519_verify(g, p_, msgs[i]) and engine.eddsa_verify(g, p_, msgs[i])
+        assert not engine.ed25519_verify(g, p_, msgs[i] + b"x")
+
+
+def test_verify_edge_cases(engine, golden):
+    cases = golden("verify_edges.json")
+    blob, off = ragged([H(c["msg"]) for c in cases])
+    got = engine.ed25519_verify_batch(arr([H(c["sig"]) for c in cases]), arr([H(c["pub"]) for c in cases]),
+                                      blob, msg_off=off)
+    want = np.array([c["accept"] for c in cases], np.uint8)
+    bad = [cases[i]["name"] for i in np.nonzero(got != want)[0]]
+    assert not bad, bad
+    assert want.sum() >= 30 and (1 - want).sum() >= 100
+
+
+def test_layer_kats_through_the_abi(engine, golden):
+    k = golden("layer_kats.json")
+    for name, fn in (("pk_to_x", engine.pk_ed25519_to_x25519_batch), ("sk_to_x", engine.sk_ed25519_to_x25519_batch),
+                     ("x25519_base", engine.x25519_base_batch)):
+        ins, outs = arr([H(a) for a, _ in k[name]]), arr([H(r) for _, r in k[name]])
+        assert np.array_equal(fn(ins), outs), name
+        assert np.array_equal(fn(dev(ins)).cpu().numpy(), outs), name
+    a, r = k["pk_to_x"][5]
+    assert engine.pk_ed25519_to_x25519(H(a)) == H(r) and engine.eddsa_pk_eddsa_to_dh(H(a)) == H(r)
+    a, r = k["sk_to_x"][5]
+    assert engine.sk_ed25519_to_x25519(H(a)) == H(r) and engine.eddsa_sk_eddsa_to_dh(H(a)) == H(r)
+    a, r = k["x25519_base"][5]
+    assert engine.x25519_base(H(a)) == H(r)
+
+
+def test_device_tables_equal_the_reference_table(engine, golden):
+    """the comb table generated on the device == the points of the reference's lib/ed_lookup64.h"""
+    import ctypes
+    base8 = np.zeros((129, 32), np.uint32); comb = np.zeros((256, 32), np.uint32)
+    rc = engine.library().eddsa_amd_dump_tables(base8.ctypes.data_as(ctypes.c_void_p), comb.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    pos = [0, 26, 51, 77, 102, 128, 153, 179, 204, 230]
+
+    def val(limbs):
+        return sum(int(v) << s for v, s in zip(limbs, pos))
+
+    def enc(entry):
+        ymx, ypx = val(entry[0:10]), val(entry[10:20])
+        inv2 = pow(2, P - 2, P)
+        y, x = (ypx + ymx) * inv2 % P, (ypx - ymx) * inv2 % P
+        d = (-121665 * pow(121666, P - 2, P)) % P
+        assert val(entry[20:30]) == 2 * d * x * y % P
+        return (y | (x & 1) << 255).to_bytes(32, "little")
+
+    pts = golden("comb_points.bin")
+    for e in range(256):
+        assert enc(comb[e]) == pts[32 * e:32 * e + 32], e
+    for k in range(1, 9):                                  # base8[k] = k*B = comb row 0
+        assert enc(base8[k]) == pts[32 * (k - 1):32 * k]
+    assert val(base8[0][0:10]) == 1 and val(base8[0][10:20]) == 1 and val(base8[0][20:30]) == 0
+
+
+# ---------------------------------------------------------------- seeded random batches vs the oracle
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 1000, 5000])
+def test_x25519_random(engine, oracle, n):
+    rng = np.random.default_rng(100 + n)
+    sc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    pt = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    for i, v in enumerate([0, 1, 9, P - 1, P, P + 1, 2**255 - 1, 2**255, 2**256 - 1,
+                           325606250916557431795983626356110631294008115727848805560023387167927233504,  # order 8
+                           39382357235489614581723060781553021112529911719440698176882885853963445705823][:n]):
+        pt[i] = np.frombuffer(int(v).to_bytes(32, "little"), np.uint8)
+    want = oracle.x25519_batch(sc, pt)
+    assert np.array_equal(engine.x25519_batch(sc, pt), want)
+    assert np.array_equal(engine.x25519_batch(dev(sc), dev(pt)).cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("mlen", [0, 1, 31, 32, 47, 48, 63, 64, 111, 112, 175, 176, 300])
+def test_sign_verify_random_fixed_length(engine, oracle, mlen):
+    n = 700
+    rng = np.random.default_rng(200 + mlen)
+    sk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    msg = rng.integers(0, 256, (n, max(mlen, 1)), dtype=np.uint8)[:, :mlen].copy()
+    pk = oracle.genpub_batch(sk)
+    assert np.array_equal(engine.ed25519_genpub_batch(sk), pk)
+    sig = oracle.sign_batch(sk, pk, msg, mlen)
+    assert np.array_equal(engine.ed25519_sign_batch(sk, pk, msg, msg_len=mlen), sig)
+    assert np.array_equal(engine.ed25519_sign_batch(dev(sk), dev(pk), dev(msg), msg_len=mlen).cpu().numpy(), sig)
+    # corrupt a third of the items in assorted places, add garbage and S + l
+    s2, p2, m2 = sig.copy(), pk.copy(), msg.copy()
+    for i in range(n):
+        k = i % 9
+        if k == 1: s2[i, rng.integers(0, 32)] ^= 1 << rng.integers(0, 8)
+        elif k == 2: s2[i, 32 + rng.integers(0, 32)] ^= 1 << rng.integers(0, 8)
+        elif k == 3: p2[i, rng.integers(0, 32)] ^= 1 << rng.integers(0, 8)
+        elif k == 4 and mlen: m2[i, rng.integers(0, mlen)] ^= 1 << rng.integers(0, 8)
+        elif k == 5: s2[i] = rng.integers(0, 256, 64); p2[i] = rng.integers(0, 256, 32)
+        elif k == 6:
+            s = int.from_bytes(s2[i, 32:].tobytes(), "little") + L * int(rng.integers(1, 15))
+            if s < 2**256: s2[i, 32:] = np.frombuffer(s.to_bytes(32, "little"), np.uint8)
+    want = oracle.verify_batch(s2, p2, m2, mlen)
+    assert np.array_equal(engine.ed25519_verify_batch(s2, p2, m2, msg_len=mlen), want)
+    assert np.array_equal(engine.ed25519_verify_batch(dev(s2), dev(p2), dev(m2), msg_len=mlen).cpu().numpy(), want)
+    assert 0 < want.sum() < n
+
+
+def test_unaligned_device_buffers(engine, oracle):
+    """device pointers that are not 16-byte aligned take the byte-wise load/store path"""
+    import torch
+    n = 300
+    rng = np.random.default_rng(77)
+    sc = rng.integers(0, 256, (n, 32), dtype=np.uint8); pt = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    want = oracle.x25519_batch(sc, pt)
+    for shift in (1, 3, 4, 8):
+        bs = torch.zeros(n * 32 + 16, dtype=torch.uint8, device="cuda"); bp = torch.zeros_like(bs)
+        s = bs[shift:shift + n * 32]; p_ = bp[shift:shift + n * 32]
+        s.copy_(dev(sc).view(-1)); p_.copy_(dev(pt).view(-1))
+        assert np.array_equal(engine.x25519_batch(s, p_).cpu().numpy(), want), shift
+    sk = rng.integers(0, 256, (n, 32), dtype=np.uint8); msg = rng.integers(0, 256, (n, 33), dtype=np.uint8)
+    pk = oracle.genpub_batch(sk); sig = oracle.sign_batch(sk, pk, msg, 33)     # 33-byte stride: unaligned msgs
+    assert np.array_equal(engine.ed25519_sign_batch(dev(sk), dev(pk), dev(msg), msg_len=33).cpu().numpy(), sig)
+    assert engine.ed25519_verify_batch(dev(sig), dev(pk), dev(msg), msg_len=33).all()
+
+
+def test_empty_batches(engine):
+    z32, z64 = np.zeros((0, 32), np.uint8), np.zeros((0, 64), np.uint8)
+    assert engine.x25519_batch(z32, z32).shape == (0, 32)
+    assert engine.ed25519_verify_batch(z64, z32, np.zeros(0, np.uint8)).shape == (0,)
+    assert engine.ed25519_sign_batch(z32, z32, np.zeros(0, np.uint8)).shape == (0, 64)
+    assert engine.ed25519_genpub_batch(z32).shape == (0, 32)
+
+
+def test_reference_selftest_consistency(engine):
+    """the reference's consistency selftests on the device (test/selftest-x25519_base.c:11-45 and
+    test/selftest-convert.c:9-80): x25519_base(x) == x25519(x, 9) and
+    x25519_base(sk_to_x(sk)) == pk_to_x(genpub(sk))"""
+    n = 1024
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    nine = np.zeros((n, 32), np.uint8); nine[:, 0] = 9
+    assert np.array_equal(engine.x25519_base_batch(x), engine.x25519_batch(x, nine))
+    lhs = engine.x25519_base_batch(engine.sk_ed25519_to_x25519_batch(x))
+    rhs = engine.pk_ed25519_to_x25519_batch(engine.ed25519_genpub_batch(x))
+    assert np.array_equal(lhs, rhs)
+
+
+def test_small_batch_digests(engine, golden):
+    import workload
+    d = golden("batch_digests.json")
+    n = 1 << 14
+    sc, pt = workload.x25519_inputs(n)
+    assert hashlib.sha512(engine.x25519_batch(sc, pt).tobytes()).hexdigest() == d["x25519_2^14"]
+    sk, msg = workload.sign_inputs(n)
+    pk = engine.ed25519_genpub_batch(sk)
+    assert hashlib.sha512(pk.tobytes()).hexdigest() == d["genpub_2^14"]
+    assert hashlib.sha512(engine.ed25519_sign_batch(sk, pk, msg).tobytes()).hexdigest() == d["sign_2^14"]

@@ -1,0 +1,335 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the REFERENCE (run in the build container only).
+
+Sources of truth, in order:
+  * the reference's own test data file test/x25519-table.h (1024 KATs), re-emitted as binary;
+  * the reference itself, compiled from its sources in place by oracle/Makefile into
+    oracle/_ref/libeddsa_ref.so (64-bit limbs) and libeddsa_ref32.so (32-bit limbs), called
+    through ctypes; both builds must agree on every vector written here;
+  * independent cross-checks: RFC 8032 section 7.1 TEST 1, hashlib SHA-512.
+Only data (inputs + expected outputs) is written; no reference text is copied.
+
+    python tools/gen_golden.py            # rewrites tests/golden/
+"""
+import ctypes
+import hashlib
+import json
+import os
+import re
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import workload  # noqa: E402
+
+REF = os.environ.get("EDDSA_REFERENCE", "/root/reference")
+GOLD = os.path.join(ROOT, "tests", "golden")
+P = 2**255 - 19
+L = 2**252 + 27742317777372353535851937790883648493
+
+ref = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libeddsa_ref.so"))
+ref32 = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libeddsa_ref32.so"))
+drv = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_driver.so"))
+for lib in (ref, ref32):
+    lib.ed25519_verify.restype = ctypes.c_bool
+BUF = ctypes.create_string_buffer
+PTR = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+CORES = os.cpu_count() or 1
+
+
+def both(fn_name, out_len, *args):
+    """call a void reference function writing out_len bytes, on both limb builds"""
+    o1, o2 = BUF(out_len), BUF(out_len)
+    getattr(ref, fn_name)(o1, *args)
+    getattr(ref32, fn_name)(o2, *args)
+    assert o1.raw == o2.raw, fn_name
+    return o1.raw
+
+
+def verify(sig, pub, msg):
+    a = bool(ref.ed25519_verify(sig, pub, msg, ctypes.c_size_t(len(msg))))
+    b = bool(ref32.ed25519_verify(sig, pub, msg, ctypes.c_size_t(len(msg))))
+    assert a == b
+    return a
+
+
+def le(x, n=32):
+    return int(x).to_bytes(n, "little")
+
+
+# ---------------------------------------------------------------- 1. the reference's own x25519 table
+def gen_x25519_table():
+    text = open(os.path.join(REF, "test", "x25519-table.h")).read()
+    vals = [int(v, 16) for v in re.findall(r"0x([0-9a-fA-F]{2})", text)]
+    raw = bytes(vals)
+    assert len(raw) == 1024 * 96, len(raw)
+    # re-run the reference on the table's inputs: field order is point, scalar, result
+    for i in range(1024):
+        pt, sc, res = raw[96 * i:96 * i + 32], raw[96 * i + 32:96 * i + 64], raw[96 * i + 64:96 * i + 96]
+        assert both("x25519", 32, sc, pt) == res, i
+    open(os.path.join(GOLD, "x25519_table.bin"), "wb").write(raw)
+    print("x25519_table.bin: 1024 vectors (point|scalar|result), re-verified against the compiled reference")
+
+
+# ---------------------------------------------------------------- 2. regenerated ed25519 table
+def golden_sk(i):
+    return hashlib.sha256(b"libeddsa-amd golden sk" + i.to_bytes(4, "little")).digest()
+
+
+def golden_msg(i):
+    out = b""
+    c = 0
+    while len(out) < i:
+        out += hashlib.sha512(b"libeddsa-amd golden msg" + i.to_bytes(4, "little") + c.to_bytes(4, "little")).digest()
+        c += 1
+    return out[:i]
+
+
+def gen_ed25519_table():
+    rows = bytearray()
+    for i in range(1024):
+        sk = bytes.fromhex("9d61b19deffd5a60ba844af492ec2cc44449c5697b326919703bac031cae7f60") if i == 0 else golden_sk(i)
+        msg = golden_msg(i)
+        pk = both("ed25519_genpub", 32, sk)
+        sig = both("ed25519_sign", 64, sk, pk, msg, ctypes.c_size_t(len(msg)))
+        assert verify(sig, pk, msg)
+        rows += sk + pk + sig
+    # RFC 8032 7.1 TEST 1 (empty message)
+    assert rows[32:64].hex() == "d75a980182b10ab7d54bfed3c964073a0ee172f3daa62325af021a68f707511a"
+    assert rows[64:128].hex() == ("e5564300c360ac729086e2cc806e828a84877f1eb8e5d974d873e06522490155"
+                                  "5fb8821590a33bacc61e39701cf9b46bd25bf5f0595bbe24655141438e7a100b")
+    open(os.path.join(GOLD, "ed25519_table.bin"), "wb").write(rows)
+    print("ed25519_table.bin: 1024 x (sk|pk|sig); message i = golden_msg(i), i bytes; entry 0 = RFC 8032 TEST 1")
+
+
+# ---------------------------------------------------------------- 3. verify edge cases
+def small_order_points():
+    """the eight points of order dividing 8, canonical encodings"""
+    out = [le(1), le(P - 1), le(0), le(1 << 255)]                      # (0,1) (0,-1) (i,0)? see below
+    # order 4: x^2 = -1 -> y = 0 ; order 8: y^2 = ... take the well known encodings
+    out = [
+        "0100000000000000000000000000000000000000000000000000000000000000",
+        "ecffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff7f",
+        "0000000000000000000000000000000000000000000000000000000000000000",
+        "0000000000000000000000000000000000000000000000000000000000000080",
+        "26e8958fc2b227b045c3f489f2ef98f0d5dfac05d3c63339b13802886d53fc05",
+        "26e8958fc2b227b045c3f489f2ef98f0d5dfac05d3c63339b13802886d53fc85",
+        "c7176a703d4dd84fba3c0b760d10670f2a2053fa2c39ccc64ec7fd7792ac037a",
+        "c7176a703d4dd84fba3c0b760d10670f2a2053fa2c39ccc64ec7fd7792ac03fa",
+    ]
+    return [bytes.fromhex(h) for h in out]
+
+
+def gen_verify_edges():
+    cases = []
+
+    def add(name, sig, pub, msg):
+        cases.append({"name": name, "sig": sig.hex(), "pub": pub.hex(), "msg": msg.hex(),
+                      "accept": verify(sig, pub, msg)})
+
+    sk = golden_sk(7001)
+    pk = both("ed25519_genpub", 32, sk)
+    msg = b"edge-case message for libeddsa-amd"
+    sig = both("ed25519_sign", 64, sk, pk, msg, ctypes.c_size_t(len(msg)))
+    add("valid", sig, pk, msg)
+    S = int.from_bytes(sig[32:], "little")
+    for k in (1, 2, 3, 7, 14, 15):
+        if S + k * L < 2**256:
+            add(f"S+{k}l (S not range-checked: accepted)", sig[:32] + le(S + k * L), pk, msg)
+    add("S-1", sig[:32] + le((S - 1) % 2**256), pk, msg)
+    add("S=0", sig[:32] + le(0), pk, msg)
+    add("S=l", sig[:32] + le(L), pk, msg)
+    add("S=2^256-1", sig[:32] + b"\xff" * 32, pk, msg)
+    for pos in (0, 7, 100, 255, 256, 300, 511):
+        b = bytearray(sig); b[pos // 8] ^= 1 << (pos % 8)
+        add(f"sig bit {pos} flipped", bytes(b), pk, msg)
+    for pos in (0, 128, 254, 255):
+        b = bytearray(pk); b[pos // 8] ^= 1 << (pos % 8)
+        add(f"pub bit {pos} flipped", sig, bytes(b), msg)
+    add("message truncated", sig, pk, msg[:-1])
+    add("message extended", sig, pk, msg + b"\x00")
+    add("empty message, wrong", sig, pk, b"")
+    # non-canonical R: y + p encoding of the same point (only possible for y < 19)
+    Ry = int.from_bytes(sig[:32], "little") & (2**255 - 1)
+    # (only representable when y < 19; otherwise this is just the valid signature again)
+    add("R with y+p if representable", (le((Ry + P) % 2**255 | (sig[31] >> 7) << 255) if Ry < 19 else sig[:32]) + sig[32:], pk, msg)
+    # R = identity written non-canonically as y = p + 1, against the canonical form, under a small-order A
+    for enc in (le(1), le(P + 1)):
+        add(f"R=identity as y={'1' if enc == le(1) else 'p+1'}, A=identity, S=0", enc + le(0), le(1), b"nc-R probe")
+    # signatures under small-order / degenerate public keys: A of small order makes t*A vanish
+    # for suitable t, so probe several messages and report what the reference says
+    for pi, A in enumerate(small_order_points()):
+        for mi in range(6):
+            m = b"small-order probe %d" % mi
+            # R = S*B with S = 0 -> R = identity encoding; also a random-looking R
+            add(f"small-order A#{pi} R=identity S=0 m{mi}", le(1) + le(0), A, m)
+            r_sk = golden_sk(8000 + mi)
+            Rpt = both("ed25519_genpub", 32, r_sk)   # some valid point encoding
+            add(f"small-order A#{pi} R=point S=0 m{mi}", Rpt + le(0), A, m)
+    # non-canonical A encodings: y >= p (y = p + k, k < 19), both sign bits
+    for k in range(0, 19, 3):
+        for sign in (0, 1):
+            A = le((P + k) | (sign << 255))
+            for mi in range(3):
+                add(f"non-canonical A y=p+{k} sign={sign} m{mi}", le(1) + le(0), A, b"nc probe %d" % mi)
+    # A = identity with the sign bit set (x = 0 with sign 1 is accepted by ed_import)
+    add("A=identity|sign, R=identity, S=0", le(1) + le(0), le(1 | 1 << 255), b"x")
+    add("A=identity, R=identity, S=0", le(1) + le(0), le(1), b"x")
+    # off-curve A: y = 2..40 (about half are not on the curve)
+    for y in range(2, 40):
+        add(f"A with y={y} (possibly off-curve), genuine-looking sig", sig, le(y), msg)
+        add(f"A with y={y}, R=identity S=0", le(1) + le(0), le(y), b"off-curve probe")
+    # valid signatures for assorted message lengths around SHA-512 block boundaries
+    for n in (0, 1, 47, 48, 63, 64, 111, 112, 127, 128, 175, 176, 239, 240, 1023):
+        m = golden_msg(n)
+        s = both("ed25519_sign", 64, sk, pk, m, ctypes.c_size_t(n))
+        add(f"valid, len={n}", s, pk, m)
+        if n:
+            bad = bytearray(m); bad[n // 2] ^= 0x10
+            add(f"message bit flipped, len={n}", s, pk, bytes(bad))
+    json.dump(cases, open(os.path.join(GOLD, "verify_edges.json"), "w"), indent=0)
+    acc = sum(c["accept"] for c in cases)
+    print(f"verify_edges.json: {len(cases)} cases, {acc} accepted by the reference")
+
+
+# ---------------------------------------------------------------- 4. layer KATs
+class Ed(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64 * 5) for n in ("x", "y", "t", "z")]
+
+
+def fld_call(name, *ins):
+    """a, b bytes -> fld op -> canonical bytes (64-bit build's internal layer)"""
+    limbs = []
+    for b in ins:
+        f = (ctypes.c_int64 * 5)()
+        ref.fld_import(f, b)
+        limbs.append(f)
+    out = (ctypes.c_int64 * 5)()
+    getattr(ref, name)(out, *limbs)
+    o = BUF(32)
+    ref.fld_export(o, out)
+    return o.raw
+
+
+def gen_layer_kats():
+    rng = np.random.default_rng(20240601)
+    rb = lambda n: bytes(rng.integers(0, 256, n, dtype=np.uint8))  # noqa: E731
+    specials = [le(0), le(1), le(2), le(P - 1), le(P), le(P + 1), le(2**255 - 1), le(2**255), le(2**256 - 1),
+                le(19), le(2**255 + 18), le((1 << 51) - 1), le(1 << 51)]
+    fe_in = specials + [rb(32) for _ in range(64)]
+    out = {"fld_mul": [], "fld_sq": [], "fld_inv": [], "fld_pow2523": [], "sc_import": [], "sc_muladd": [],
+           "ed_import_export": [], "ed_scale_base": [], "ed_dual_scale": [], "sha512": [],
+           "pk_to_x": [], "sk_to_x": [], "x25519_base": []}
+    for i, a in enumerate(fe_in):
+        b = fe_in[(i * 7 + 3) % len(fe_in)]
+        out["fld_mul"].append([a.hex(), b.hex(), fld_call("fld_mul", a, b).hex()])
+        out["fld_sq"].append([a.hex(), fld_call("fld_sq", a).hex()])
+        out["fld_inv"].append([a.hex(), fld_call("fld_inv", a).hex()])
+        out["fld_pow2523"].append([a.hex(), fld_call("fld_pow2523", a).hex()])
+    sc_in = [le(0), le(1), le(L - 1), le(L), le(L + 1), le(2**252), le(2**253 - 1), le(2**256 - 1),
+             le(2**512 - 1, 64), le(L * L, 64), le(2**511, 64), le(L << 259, 64)] + \
+            [rb(32) for _ in range(24)] + [rb(64) for _ in range(24)]
+    for s in sc_in:
+        x = (ctypes.c_int64 * 5)()
+        ref.sc_import(x, s, ctypes.c_size_t(len(s)))
+        o = BUF(32); ref.sc_export(o, x)
+        assert int.from_bytes(o.raw, "little") == int.from_bytes(s, "little") % L
+        out["sc_import"].append([s.hex(), o.raw.hex()])
+    for _ in range(24):
+        a, b, c = rb(32), rb(32), rb(32)
+        r = (int.from_bytes(a, "little") * int.from_bytes(b, "little") + int.from_bytes(c, "little")) % L
+        out["sc_muladd"].append([a.hex(), b.hex(), c.hex(), le(r).hex()])
+    pts = specials + small_order_points() + [rb(32) for _ in range(64)]
+    for p in pts:
+        e = Ed(); ref.ed_import(ctypes.byref(e), p)
+        o = BUF(32); ref.ed_export(o, ctypes.byref(e))
+        out["ed_import_export"].append([p.hex(), o.raw.hex()])
+        out["pk_to_x"].append([p.hex(), both("pk_ed25519_to_x25519", 32, p).hex()])
+    for s in [le(0), le(1), le(8), le(L - 1), le(2**252)] + [rb(32) for _ in range(32)]:
+        x = (ctypes.c_int64 * 5)(); ref.sc_import(x, s, ctypes.c_size_t(32))
+        e = Ed(); ref.ed_scale_base(ctypes.byref(e), x)
+        o = BUF(32); ref.ed_export(o, ctypes.byref(e))
+        out["ed_scale_base"].append([s.hex(), o.raw.hex()])
+        out["x25519_base"].append([s.hex(), both("x25519_base", 32, s).hex()])
+        out["sk_to_x"].append([s.hex(), both("sk_ed25519_to_x25519", 32, s).hex()])
+    for i in range(64):
+        s, t, q = rb(32), rb(32), (pts[i % len(pts)] if i < 40 else rb(32))
+        if i == 0: s, t = le(0), le(0)
+        if i == 1: t = le(0)
+        if i == 2: s = le(0)
+        S = (ctypes.c_int64 * 5)(); T = (ctypes.c_int64 * 5)(); Q = Ed(); R = Ed()
+        ref.sc_import(S, s, ctypes.c_size_t(32)); ref.sc_import(T, t, ctypes.c_size_t(32))
+        ref.ed_import(ctypes.byref(Q), q)
+        ref.ed_dual_scale(ctypes.byref(R), S, T, ctypes.byref(Q))
+        o = BUF(32); ref.ed_export(o, ctypes.byref(R))
+        out["ed_dual_scale"].append([s.hex(), t.hex(), q.hex(), o.raw.hex()])
+    class Sha(ctypes.Structure):
+        _fields_ = [("state", ctypes.c_uint64 * 8), ("count", ctypes.c_uint64), ("buffer", ctypes.c_uint8 * 128),
+                    ("fill", ctypes.c_size_t)]
+    for n in list(range(0, 300)) + [1000, 4096]:
+        m = golden_msg(n)
+        ctx = Sha(); ref.sha512_init(ctypes.byref(ctx)); ref.sha512_add(ctypes.byref(ctx), m, ctypes.c_size_t(n))
+        o = BUF(64); ref.sha512_final(ctypes.byref(ctx), o)
+        assert o.raw == hashlib.sha512(m).digest()
+        out["sha512"].append([n, o.raw.hex()])
+    json.dump(out, open(os.path.join(GOLD, "layer_kats.json"), "w"), indent=0)
+    print("layer_kats.json:", {k: len(v) for k, v in out.items()})
+
+
+# ---------------------------------------------------------------- 5. the reference's lookup table
+def gen_table_digest():
+    """lib/ed_lookup64.h is generated data; pin the CONTENT by value: canonical bytes of every entry,
+    read out of the compiled reference through scale16's public consumer ed_scale_base:
+    (k+1) * 256^i * B  ==  ed_scale_base((k+1) << 8i)."""
+    rows = bytearray()
+    for i in range(32):
+        for k in range(8):
+            s = le(((k + 1) << (8 * i)) % L)
+            x = (ctypes.c_int64 * 5)(); ref.sc_import(x, s, ctypes.c_size_t(32))
+            e = Ed(); ref.ed_scale_base(ctypes.byref(e), x)
+            o = BUF(32); ref.ed_export(o, ctypes.byref(e))
+            rows += o.raw
+    open(os.path.join(GOLD, "comb_points.bin"), "wb").write(rows)
+    print("comb_points.bin: 256 compressed points (k+1)*256^i*B from the reference")
+
+
+# ---------------------------------------------------------------- 6. full-size batch digests
+def gen_batch_digests():
+    out = {}
+    for log2n in (14, 20):
+        n = 1 << log2n
+        sc, pt = workload.x25519_inputs(n)
+        res = np.zeros((n, 32), np.uint8)
+        drv.refdrv_x25519_batch(PTR(res), PTR(sc), PTR(pt), ctypes.c_size_t(n), CORES)
+        out[f"x25519_2^{log2n}"] = hashlib.sha512(res.tobytes()).hexdigest()
+        sk, msg = workload.sign_inputs(n)
+        pk = np.zeros((n, 32), np.uint8)
+        drv.refdrv_genpub_batch(PTR(pk), PTR(sk), ctypes.c_size_t(n), CORES)
+        sig = np.zeros((n, 64), np.uint8)
+        drv.refdrv_sign_batch(PTR(sig), PTR(sk), PTR(pk), PTR(msg), ctypes.c_size_t(32), ctypes.c_size_t(n), CORES)
+        out[f"genpub_2^{log2n}"] = hashlib.sha512(pk.tobytes()).hexdigest()
+        out[f"sign_2^{log2n}"] = hashlib.sha512(sig.tobytes()).hexdigest()
+        # verify workload (config 2): keys/messages from stream (seed 1, config 2)
+        sk, msg = workload.sign_inputs(n, seed=1, config=2)
+        drv.refdrv_genpub_batch(PTR(pk), PTR(sk), ctypes.c_size_t(n), CORES)
+        drv.refdrv_sign_batch(PTR(sig), PTR(sk), PTR(pk), PTR(msg), ctypes.c_size_t(32), ctypes.c_size_t(n), CORES)
+        expect = workload.corrupt_for_verify(sig, pk, msg)
+        ok = np.zeros(n, np.uint8)
+        drv.refdrv_verify_batch(PTR(ok), PTR(sig), PTR(pk), PTR(msg), ctypes.c_size_t(32), ctypes.c_size_t(n), CORES)
+        assert np.array_equal(ok, expect), "reference verdicts differ from the construction"
+        out[f"verify_2^{log2n}"] = {"inputs_sha512": hashlib.sha512(sig.tobytes() + pk.tobytes() + msg.tobytes()).hexdigest(),
+                                    "verdicts_sha512": hashlib.sha512(ok.tobytes()).hexdigest(), "accepted": int(ok.sum())}
+        print(f"batch digests for n=2^{log2n} done")
+    json.dump(out, open(os.path.join(GOLD, "batch_digests.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    gen_x25519_table()
+    gen_ed25519_table()
+    gen_verify_edges()
+    gen_layer_kats()
+    gen_table_digest()
+    gen_batch_digests()
