@@ -76,10 +76,22 @@ def run_step(op, w):
     return ed.ed25519_sign_batch(w["secs"], w["pubs"], w["msgs"], msg_len=32)
 
 
+def usable_cores():
+    """host cores this process may actually use: affinity mask, capped by the cgroup CPU quota"""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def cpu_baseline(op, w, gpu_out, sample):
     """Time the reference (oracle/_ref, kind "reference"; else the C restatement, kind "port") on
     all host cores over the first `sample` items of the same workload; check the GPU against it."""
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     refdrv = os.path.join(ROOT, "oracle", "_ref", "libref_driver.so")
     if os.path.exists(refdrv):
         lib, kind = ctypes.CDLL(refdrv), "reference"

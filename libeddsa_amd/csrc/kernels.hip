@@ -183,29 +183,36 @@ __global__ void __launch_bounds__(64) k_init_tables(uint32_t* base8, uint32_t* c
 //   k_verify_prepare  hash, scalars -> digit words, decompress -A, table of 0..8 * -A
 //   k_verify_main     the 252 doublings + 96 additions            (~85 % of the time)
 //   k_verify_finish   invert Z, encode, compare with R
-// Workspace (HBM, lane-interleaved so that every access is coalesced, tile = 256 items):
+// Workspace (HBM; tile = 256 items):
 //   digits [item][16]                 t + 0x88.., S + 0x80.. as little-endian words
-//   table  [tile][entry 9][word 40][lane 256]
+//   table  [item][entry 9][word 40]         1440 contiguous bytes per item
 //   acc    [tile][word 30][lane 256]   X, Y, Z of the result
 //   flags  [item]                      1 = A decoded to a curve point
 
-ED_DEV uint32_t* tile_table(uint32_t* table, size_t tile) {
-  return table + tile * VERIFY_TABLE_WORDS_PER_TILE + threadIdx.x;
-}
+// table entry = 40 words (ymx | ypx | t2d | z2), contiguous per item so that one lookup reads
+// 160 contiguous bytes (ten 16-byte loads) instead of touching one 128-byte line per word.
 ED_DEV void cached_store(uint32_t* tab, int entry, const ge_cached& c) {
-  uint32_t* p = tab + (size_t)entry * 40 * BLOCK;
+  uint4* p = reinterpret_cast<uint4*>(tab + entry * 40);
+  const fe* f[4] = {&c.ymx, &c.ypx, &c.t2d, &c.z2};
+  uint32_t w[40];
 #pragma unroll
-  for (int j = 0; j < 10; j++) {
-    p[(j)*BLOCK] = c.ymx.v[j]; p[(10 + j) * BLOCK] = c.ypx.v[j];
-    p[(20 + j) * BLOCK] = c.t2d.v[j]; p[(30 + j) * BLOCK] = c.z2.v[j];
-  }
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int j = 0; j < 10; j++) w[10 * k + j] = f[k]->v[j];
+#pragma unroll
+  for (int q = 0; q < 10; q++) p[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
 }
 ED_DEV void cached_load(ge_cached& c, const uint32_t* tab, uint32_t entry) {
-  const uint32_t* p = tab + (size_t)entry * 40 * BLOCK;
+  const uint4* p = reinterpret_cast<const uint4*>(tab + entry * 40);
+  uint32_t w[40];
+#pragma unroll
+  for (int q = 0; q < 10; q++) {
+    const uint4 v = p[q];
+    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+  }
 #pragma unroll
   for (int j = 0; j < 10; j++) {
-    c.ymx.v[j] = p[(j)*BLOCK]; c.ypx.v[j] = p[(10 + j) * BLOCK];
-    c.t2d.v[j] = p[(20 + j) * BLOCK]; c.z2.v[j] = p[(30 + j) * BLOCK];
+    c.ymx.v[j] = w[j]; c.ypx.v[j] = w[10 + j]; c.t2d.v[j] = w[20 + j]; c.z2.v[j] = w[30 + j];
   }
 }
 
@@ -244,7 +251,7 @@ k_verify_prepare(const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs,
   }
 
   // -A and its multiples 0..8, cached form
-  uint32_t* tab = tile_table(table, blockIdx.x);
+  uint32_t* tab = table + i * (VERIFY_TABLE_ENTRIES * 40);
   bool oncurve;
   ge a, p, q;
   ge_cached c1, c;
@@ -278,7 +285,7 @@ k_verify_main(const uint32_t* digits, const uint32_t* table, const uint32_t* bas
 
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const size_t item = i < n ? i : n - 1;
-  const uint32_t* tab = table + (size_t)blockIdx.x * VERIFY_TABLE_WORDS_PER_TILE + threadIdx.x;
+  const uint32_t* tab = table + i * (VERIFY_TABLE_ENTRIES * 40);
   uint32_t tw[8], sw[8];
   {
     const uint4* d = reinterpret_cast<const uint4*>(digits + 16 * item);
