@@ -39,7 +39,16 @@ constexpr uint32_t M25 = (1u << 25) - 1;
 ED_DEV constexpr int limb_bits(int i) { return (i & 1) ? 25 : 26; }
 ED_DEV constexpr uint32_t limb_mask(int i) { return (i & 1) ? M25 : M26; }
 
-ED_DEV uint64_t mad(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
+// One multiply-accumulate of a product column: v_mad_u64_u32.  The assumption (true: the limb
+// bounds keep every column below 2^64, so the sum never wraps) gives each partial sum a second
+// use in the IR, which stops LLVM's reassociation from moving the carry-in to the END of the
+// chain -- there it costs a v_mul plus a 64-bit add per column instead of being the free initial
+// addend.  It emits no code and, unlike an asm barrier, does not pin the instruction order.
+ED_DEV uint64_t mad(uint32_t a, uint32_t b, uint64_t c) {
+  const uint64_t r = (uint64_t)a * b + c;
+  __builtin_assume(r >= c);
+  return r;
+}
 
 ED_DEV void fe_set(fe& h, uint32_t x) {
   h.v[0] = x;

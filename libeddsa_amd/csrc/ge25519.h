@@ -103,10 +103,11 @@ ED_DEV void ge_dbl(ge& r, const ge& p, bool need_t) {
   fe_sub(g, yy, xx);                            // 3u
   fe_sub(f, xx, yy);
   fe_add(f, f, zz2);                            // 5u: first operand only
+  // second operands are e (X, T) and g (Y, Z): their 19x premultiplies are computed once each
   fe_mul(r.X, f, e);
-  fe_mul(r.Y, g, h);
+  fe_mul(r.Y, h, g);
   fe_mul(r.Z, f, g);
-  if (need_t) fe_mul(r.T, e, h);
+  if (need_t) fe_mul(r.T, h, e);
 }
 
 // r = p + q, q cached.  add-2008-hwcd-3 (the shape of ed.c:175-203 with 2dT2 and 2Z2 premultiplied)
@@ -122,9 +123,10 @@ ED_DEV void ge_add_cached(ge& r, const ge& p, const ge_cached& q, bool need_t) {
   fe_sub(f, d, c);                              // 3u
   fe_add(g, d, c);                              // 2u
   fe_add(h, b, a);                              // 2u
+  // second operands are f (X, Z) and h (Y, T): shared 19x premultiplies
   fe_mul(r.X, e, f);
   fe_mul(r.Y, g, h);
-  fe_mul(r.Z, f, g);
+  fe_mul(r.Z, g, f);
   if (need_t) fe_mul(r.T, e, h);
 }
 
@@ -141,10 +143,11 @@ ED_DEV void ge_add_niels(ge& r, const ge& p, const ge_niels& q, bool need_t) {
   fe_sub(f, d, c);                              // 4u: first operand only
   fe_add(g, d, c);                              // 3u
   fe_add(h, b, a);                              // 2u
+  // second operands are e (X, T) and g (Y, Z): shared 19x premultiplies
   fe_mul(r.X, f, e);
   fe_mul(r.Y, h, g);
   fe_mul(r.Z, f, g);
-  if (need_t) fe_mul(r.T, e, h);
+  if (need_t) fe_mul(r.T, h, e);
 }
 
 // cached form of p, every coordinate tight (ed.c:436-442 ed_precompute, plus 2Z)

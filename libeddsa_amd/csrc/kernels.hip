@@ -329,23 +329,76 @@ k_verify_main(const uint32_t* digits, const uint32_t* table, const uint32_t* bas
 
 // encode and compare with R as bytes (ed25519-sha512.c:176-180): a non-canonical R can never
 // match.  An off-curve A is rejected outright: DESIGN.md "Off-curve public keys".
-__global__ void __launch_bounds__(BLOCK, 2)
-k_verify_finish(uint8_t* ok, const uint8_t* sigs, const uint32_t* accin, const uint8_t* flags, size_t n) {
-  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t* o = accin + (size_t)blockIdx.x * (30 * BLOCK) + threadIdx.x;
-  ge acc;
+//
+// The inversion of ed_export (ed.c:161, 254 S + 11 M) is shared by FINISH_K items per lane with
+// Montgomery's trick: one inversion of the product of their Z plus 3 multiplications per item.
+// Lane t of block b handles lane t of tiles b*K .. b*K+K-1, so every access stays coalesced.
+// Z = 0 cannot occur for a curve point (the a = -1 law is complete); items whose key is off the
+// curve are rejected anyway, and their Z is replaced by 1 so that it cannot poison the product.
+constexpr int FINISH_K = 8;
+
+// Z of lane threadIdx.x of tile blockIdx.x*K + k, or 1 when that item does not exist, its key is
+// off the curve, or Z = 0
+ED_DEV void finish_load_z(fe& zsel, bool& good, int k, const uint32_t* accin, const uint8_t* flags,
+                          size_t n) {
+  const size_t tile = (size_t)blockIdx.x * FINISH_K + k;
+  const size_t i = tile * BLOCK + threadIdx.x;
+  fe z;
+  fe_set(z, 1);
+  good = false;
+  if (i < n) {
+    const uint32_t* o = accin + tile * (30 * BLOCK) + threadIdx.x;
 #pragma unroll
-  for (int j = 0; j < 10; j++) {
-    acc.X.v[j] = o[j * BLOCK]; acc.Y.v[j] = o[(10 + j) * BLOCK]; acc.Z.v[j] = o[(20 + j) * BLOCK];
+    for (int j = 0; j < 10; j++) z.v[j] = o[(20 + j) * BLOCK];
+    good = flags[i] != 0 && !fe_iszero(z);
   }
+  fe_set(zsel, 1);
+  fe_cmov(zsel, z, good);
+}
+
+ED_DEV void finish_item(int k, const fe& zinv, bool good, uint8_t* ok, const uint8_t* sigs,
+                        const uint32_t* accin, size_t n) {
+  const size_t tile = (size_t)blockIdx.x * FINISH_K + k;
+  const size_t i = tile * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* o = accin + tile * (30 * BLOCK) + threadIdx.x;
+  fe x, y;
+#pragma unroll
+  for (int j = 0; j < 10; j++) { x.v[j] = o[j * BLOCK]; y.v[j] = o[(10 + j) * BLOCK]; }
+  fe_mul(x, x, zinv);
+  fe_mul(y, y, zinv);
   uint32_t cw[8], rw[8];
+  fe_tobytes(cw, y);
+  cw[7] |= fe_parity(x) << 31;
   load32(rw, sigs, i, 64);
-  ge_tobytes(cw, acc);
   uint32_t diff = 0;
 #pragma unroll
-  for (int k = 0; k < 8; k++) diff |= cw[k] ^ rw[k];
-  ok[i] = (uint8_t)((diff == 0) && (flags[i] != 0));
+  for (int q = 0; q < 8; q++) diff |= cw[q] ^ rw[q];
+  ok[i] = (uint8_t)((diff == 0) && good);
+}
+
+__global__ void __launch_bounds__(BLOCK, 2)
+k_verify_finish(uint8_t* ok, const uint8_t* sigs, const uint32_t* accin, const uint8_t* flags, size_t n) {
+  // straight-line on purpose: an fe[8] array indexed in a loop ends up in scratch
+  fe z0, z1, z2, z3, z4, z5, z6, z7, p1, p2, p3, p4, p5, p6, p7, u, zi;
+  bool g0, g1, g2, g3, g4, g5, g6, g7;
+  finish_load_z(z0, g0, 0, accin, flags, n);
+  finish_load_z(z1, g1, 1, accin, flags, n); fe_mul(p1, z0, z1);
+  finish_load_z(z2, g2, 2, accin, flags, n); fe_mul(p2, p1, z2);
+  finish_load_z(z3, g3, 3, accin, flags, n); fe_mul(p3, p2, z3);
+  finish_load_z(z4, g4, 4, accin, flags, n); fe_mul(p4, p3, z4);
+  finish_load_z(z5, g5, 5, accin, flags, n); fe_mul(p5, p4, z5);
+  finish_load_z(z6, g6, 6, accin, flags, n); fe_mul(p6, p5, z6);
+  finish_load_z(z7, g7, 7, accin, flags, n); fe_mul(p7, p6, z7);
+  fe_inv(u, p7);                                 // u = 1 / (z0 ... z7)
+  fe_mul(zi, u, p6); finish_item(7, zi, g7, ok, sigs, accin, n); fe_mul(u, u, z7);
+  fe_mul(zi, u, p5); finish_item(6, zi, g6, ok, sigs, accin, n); fe_mul(u, u, z6);
+  fe_mul(zi, u, p4); finish_item(5, zi, g5, ok, sigs, accin, n); fe_mul(u, u, z5);
+  fe_mul(zi, u, p3); finish_item(4, zi, g4, ok, sigs, accin, n); fe_mul(u, u, z4);
+  fe_mul(zi, u, p2); finish_item(3, zi, g3, ok, sigs, accin, n); fe_mul(u, u, z3);
+  fe_mul(zi, u, p1); finish_item(2, zi, g2, ok, sigs, accin, n); fe_mul(u, u, z2);
+  fe_mul(zi, u, z0); finish_item(1, zi, g1, ok, sigs, accin, n); fe_mul(u, u, z1);
+  finish_item(0, u, g0, ok, sigs, accin, n);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -562,7 +615,8 @@ hipError_t edk_verify(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, con
   hipLaunchKernelGGL(k_verify_main, dim3(blocks), dim3(BLOCK), 0, stream, ws->digits, ws->table, base8,
                      ws->acc, n);
   if (marks) (void)hipEventRecord(marks[2], stream);
-  hipLaunchKernelGGL(k_verify_finish, dim3(blocks), dim3(BLOCK), 0, stream, ok, sigs, ws->acc, ws->flags, n);
+  hipLaunchKernelGGL(k_verify_finish, dim3((blocks + FINISH_K - 1) / FINISH_K), dim3(BLOCK), 0, stream, ok, sigs,
+                     ws->acc, ws->flags, n);
   if (marks) (void)hipEventRecord(marks[3], stream);
   return hipGetLastError();
 }
