@@ -28,7 +28,9 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import libeddsa_amd as ed  # noqa: E402
+import workload  # noqa: E402
 
 # canonical 32x32->64 multiply counts per item (BASELINE.md "Work per item")
 MUL32_VERIFY = 312370
@@ -42,30 +44,43 @@ PEAK_TMUL32 = 256 * 4 * 16 * 2.4e9 / 1e12
 PEAK_HBM_GBS = 8000.0
 
 
-def make_workload(op, n, seed, device):
-    """seeded synthetic batch.  verify: 32-byte messages, random keys, items with
-    i % 16 == 5 corrupted by one flipped bit in R, S, A or the message (round-robin)."""
-    rng = np.random.Generator(np.random.PCG64(seed))
+def make_workload(op, n, rank, device):
+    """SURVEY 8(d) seeded synthetic batch from tools/workload.py (SplitMix64 streams; rank r owns
+    items r*n .. (r+1)*n-1 of the stream).  verify: 32-byte messages, random keys, items with
+    i % 16 == 5 corrupted by one flipped bit in R, S, A or the message (round-robin).  Signatures
+    and public keys come from the engine's own sign/genpub kernels (parity-tested separately; the
+    2^20 batches are the ones whose digests tests/golden/batch_digests.json pins)."""
+    first = rank * n
+    up = lambda a: torch.from_numpy(a).to(device)  # noqa: E731
     if op == "x25519":
-        sc = torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)).to(device)
-        pt = torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)).to(device)
-        return {"scalars": sc, "points": pt}
-    sk = torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)).to(device)
-    msg = torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)).to(device)
-    pk = ed.ed25519_genpub_batch(sk)
+        sc, pt = workload.x25519_inputs(n, first=first)
+        return {"scalars": up(sc), "points": up(pt)}
     if op == "sign":
-        return {"secs": sk, "pubs": pk, "msgs": msg}
-    sig = ed.ed25519_sign_batch(sk, pk, msg)
-    idx = torch.arange(5, n, 16, device=device)
-    which = (torch.arange(idx.numel(), device=device) % 4)
-    bitpos = torch.from_numpy(rng.integers(0, 256, idx.numel(), dtype=np.int64)).to(device)
-    byte, bit = bitpos // 8, (1 << (bitpos % 8)).to(torch.uint8)
-    for w, (buf, off) in enumerate(((sig, 0), (sig, 32), (pk, 0), (msg, 0))):
-        sel = which == w
-        buf[idx[sel], off + byte[sel]] ^= bit[sel]
-    expect = torch.ones(n, dtype=torch.uint8, device=device)
-    expect[idx] = 0
-    return {"sigs": sig, "pubs": pk, "msgs": msg, "expect": expect}
+        sk, msg = workload.sign_inputs(n, first=first)
+        sk, msg = up(sk), up(msg)
+        return {"secs": sk, "pubs": ed.ed25519_genpub_batch(sk), "msgs": msg}
+    sk, msg = workload.sign_inputs(n, seed=1, config=2, first=first)
+    d_sk = up(sk)
+    pk = ed.ed25519_genpub_batch(d_sk)
+    sig = ed.ed25519_sign_batch(d_sk, pk, up(msg)).cpu().numpy()
+    pk = pk.cpu().numpy()
+    expect = workload.corrupt_for_verify(sig, pk, msg, first=first)
+    return {"sigs": up(sig), "pubs": up(pk), "msgs": up(msg), "expect": up(expect)}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of tools/profile.sh (same
+    command, separate passes), as committed in profiles/: WRITE_SIZE (KB, exact) + 2 x FETCH_SIZE
+    (KB; gfx950 reports half the bytes of 16-byte-per-lane reads, MI355X_MICROARCH.md, HBM).
+    None when no profile has been committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    try:
+        k = json.load(open(path))["ed::" + kernel]
+        return {"bytes": (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0,
+                "fetch_size_kb_raw": k["FETCH_SIZE"], "write_size_kb_raw": k["WRITE_SIZE"],
+                "source": "profiles/pmc_summary.json (rocprofv3 --pmc, separate passes)"}
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def run_step(op, w):
@@ -144,7 +159,7 @@ def main():
     ed.init(local)
 
     op, n = args.op, 1 << args.log2n
-    w = make_workload(op, n, seed={"verify": 1, "x25519": 2, "sign": 4}[op] + 1000 * rank, device=device)
+    w = make_workload(op, n, rank, device)
     torch.cuda.synchronize()
 
     def step():
@@ -191,7 +206,7 @@ def main():
         achieved = n * k_mul32 / (k_ms * 1e-3) / 1e12
         roofline = {
             "bound": "valu", "kernel": kernel, "achieved": achieved, "peak": PEAK_TMUL32,
-            "unit": "Tmul32/s", "frac": achieved / PEAK_TMUL32, "traffic": None,
+            "unit": "Tmul32/s", "frac": achieved / PEAK_TMUL32, "traffic": pmc_traffic(kernel),
             "kernel_ms": k_ms, "canonical_mul32_per_item": k_mul32,
             "note": "integer-VALU multiply-issue roofline (SURVEY 8d): canonical 32x32->64 products of the "
                     "reference's radix-2^25.5 schoolbook per item / v_mad_u64_u32 issue peak; the path is not "

@@ -1,17 +1,19 @@
 #!/bin/bash
-# rocprofv3 profiles of the default bench command (run on the GPU box through gpurun).
-#   tools/profile.sh <tag>   -> gpurun_out/prof_<tag>/{stats,pmc_*}/...
-# Counters are collected in their own passes (never combined with tracing).
+# rocprofv3 profiles of the default bench command (run on the GPU box through gpurun):
+#   tools/profile.sh <tag>   -> gpurun_out/prof_<tag>/...   then   tools/summarize_profile.py <tag>
+# --kernel-trace --stats and every --pmc group run as SEPARATE passes (never combined).
 set -u
 TAG=${1:-r01}
-cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/prof_$TAG
-mkdir -p $OUT
+rm -rf $OUT && mkdir -p $OUT
 CMD="python3 $REPO/bench.py --steps 5 --warmup 1 --cpu-sample 4096"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/bench_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_x25519 -- $CMD --op x25519 > $OUT/bench_stats_x25519.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_sign -- $CMD --op sign > $OUT/bench_stats_sign.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/bench_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT/bench_sq.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_I8 --output-format csv -d $OUT/pmc_misc -- $CMD > $OUT/bench_misc.log 2>&1
-find $OUT -name "*.csv" | head -40
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES --output-format csv -d $OUT/pmc_misc -- $CMD > $OUT/bench_misc.log 2>&1
+python3 $REPO/tools/summarize_profile.py $TAG
