@@ -5,10 +5,13 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#ifndef TABLE_BASE8_ENTRIES       /* also defined, identically, by lanes.h for the device side */
 #define TABLE_BASE8_ENTRIES 129   /* k*B, k = 0..128 */
 #define TABLE_COMB_ENTRIES 256    /* (k+1)*256^i*B, i < 32, k < 8: ed.c:41-43 ed_lookup */
 #define TABLE_ENTRY_WORDS 32      /* 3 x 10 limbs + 2 padding words */
 #define VERIFY_TABLE_ENTRIES 9    /* 0..8 times -A, cached form */
+#define VERIFY_ENTRY_WORDS 40     /* ymx | ypx | t2d | z2 */
+#endif
 #define VERIFY_TABLE_WORDS_PER_TILE (VERIFY_TABLE_ENTRIES * 40 * 256)
 #define VERIFY_TILE 256            /* items per tile = threads per block */
 

@@ -14,22 +14,35 @@
 //              must fit 32 bits); every 64-bit column then stays below 2^64.
 //   fe_sub(a,b) = a + 2p - b needs b < 2u - 38 (so b tight, or tight + tight is NOT allowed);
 //              fe_sub4(a,b) = a + 4p - b takes b up to 4u - 76.
-// Every call site states its bounds; tests/test_fe_bounds.py replays the call graph with
-// interval arithmetic.
+// Every call site states its bounds, and they are CHECKED: with -DED_HOST_CHECK this same source
+// compiles for the host CPU (tests/host_check/, a test binary, never part of the product) with an
+// assertion at every precondition and on every 64-bit column sum; tests/test_device_source_on_host.py
+// drives it with random and extreme inputs and compares with the oracle.
 #pragma once
-#include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace ed {
-
+#ifdef ED_HOST_CHECK
+// test build of the device source for the host CPU
+#include <stddef.h>
+namespace ed { void bound_violation(const char* file, int line, const char* what); }
+#define ED_DEV inline
+#define ED_SCHED_FENCE() ((void)0)
+#define ED_CHECK(cond) do { if (!(cond)) ::ed::bound_violation(__FILE__, __LINE__, #cond); } while (0)
+#define ED_CONSTANT_MEM static const
+#define ED_ASSUME(cond) ((void)0)
+#else
+#include <hip/hip_runtime.h>
 #define ED_DEV __device__ __forceinline__
-
 // Each fe_mul / fe_sq ends with a scheduling fence: without it hipcc interleaves independent
 // multiplications for ILP, which pushes the big kernels past 256 VGPRs into scratch spills;
 // two to four waves per SIMD already hide the dependent-issue latency (profiles/r01_fe_rates.txt).
-#ifndef ED_SCHED_FENCE
 #define ED_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define ED_CHECK(cond) ((void)0)
+#define ED_CONSTANT_MEM __device__ __constant__
+#define ED_ASSUME(cond) __builtin_assume(cond)
 #endif
+
+namespace ed {
 
 struct fe { uint32_t v[10]; };
 
@@ -46,7 +59,8 @@ ED_DEV constexpr uint32_t limb_mask(int i) { return (i & 1) ? M25 : M26; }
 // addend.  It emits no code and, unlike an asm barrier, does not pin the instruction order.
 ED_DEV uint64_t mad(uint32_t a, uint32_t b, uint64_t c) {
   const uint64_t r = (uint64_t)a * b + c;
-  __builtin_assume(r >= c);
+  ED_CHECK(r >= c);                              // the column sum did not wrap
+  ED_ASSUME(r >= c);
   return r;
 }
 
@@ -59,7 +73,10 @@ ED_DEV void fe_set(fe& h, uint32_t x) {
 // fld.h:84 fld_add: limb-wise, no carry.  bounds add.
 ED_DEV void fe_add(fe& h, const fe& f, const fe& g) {
 #pragma unroll
-  for (int i = 0; i < 10; i++) h.v[i] = f.v[i] + g.v[i];
+  for (int i = 0; i < 10; i++) {
+    ED_CHECK(f.v[i] <= 0xffffffffu - g.v[i]);
+    h.v[i] = f.v[i] + g.v[i];
+  }
 }
 
 // fld.h:91 fld_sub, with a 2p bias instead of signed limbs.  needs g < 2u-38; result < f + 2u.
@@ -67,6 +84,7 @@ ED_DEV void fe_sub(fe& h, const fe& f, const fe& g) {
 #pragma unroll
   for (int i = 0; i < 10; i++) {
     const uint32_t bias = (i == 0) ? 2 * (M26 - 18) : 2 * limb_mask(i);
+    ED_CHECK(g.v[i] <= bias && f.v[i] <= 0xffffffffu - bias);
     h.v[i] = f.v[i] + bias - g.v[i];
   }
 }
@@ -76,6 +94,7 @@ ED_DEV void fe_sub4(fe& h, const fe& f, const fe& g) {
 #pragma unroll
   for (int i = 0; i < 10; i++) {
     const uint32_t bias = (i == 0) ? 4 * (M26 - 18) : 4 * limb_mask(i);
+    ED_CHECK(g.v[i] <= bias && f.v[i] <= 0xffffffffu - bias);
     h.v[i] = f.v[i] + bias - g.v[i];
   }
 }
@@ -85,6 +104,7 @@ ED_DEV void fe_neg(fe& h, const fe& f) {
 #pragma unroll
   for (int i = 0; i < 10; i++) {
     const uint32_t bias = (i == 0) ? 2 * (M26 - 18) : 2 * limb_mask(i);
+    ED_CHECK(f.v[i] <= bias);
     h.v[i] = bias - f.v[i];
   }
 }
@@ -96,6 +116,7 @@ ED_DEV void fe_carry(fe& h) {
   for (int i = 0; i < 9; i++) {
     c = h.v[i] >> limb_bits(i);
     h.v[i] &= limb_mask(i);
+    ED_CHECK(h.v[i + 1] <= 0xffffffffu - c);
     h.v[i + 1] += c;
   }
   c = h.v[9] >> 25;
@@ -109,6 +130,7 @@ ED_DEV void fe_carry(fe& h) {
 // shared tail of fe_mul / fe_sq: r[] are the masked columns, top (< 2^39) the carry out of limb 9;
 // fold 19*top into limb 0 and carry once more into limb 1.  h may alias the inputs of the caller.
 ED_DEV void fe_fold_top(fe& h, const uint32_t r[10], uint64_t top) {
+  ED_CHECK((top >> 32) < 128);
   uint64_t t = mad((uint32_t)top, 19u, (uint64_t)r[0]) + ((uint64_t)(19u * (uint32_t)(top >> 32)) << 32);
   h.v[0] = (uint32_t)t & M26;
   h.v[1] = r[1] + (uint32_t)(t >> 26);
@@ -121,9 +143,9 @@ ED_DEV void fe_fold_top(fe& h, const uint32_t r[10], uint64_t top) {
 ED_DEV void fe_mul(fe& h, const fe& f, const fe& g) {
   uint32_t g19[10], f2[10], r[10];
 #pragma unroll
-  for (int j = 1; j < 10; j++) g19[j] = 19u * g.v[j];
+  for (int j = 1; j < 10; j++) { ED_CHECK(g.v[j] <= 0xffffffffu / 19u); g19[j] = 19u * g.v[j]; }
 #pragma unroll
-  for (int i = 1; i < 10; i += 2) f2[i] = 2u * f.v[i];
+  for (int i = 1; i < 10; i += 2) { ED_CHECK(f.v[i] <= 0x7fffffffu); f2[i] = 2u * f.v[i]; }
   uint64_t acc = 0;
 #pragma unroll
   for (int k = 0; k < 10; k++) {
@@ -144,9 +166,13 @@ ED_DEV void fe_mul(fe& h, const fe& f, const fe& g) {
 ED_DEV void fe_sq(fe& h, const fe& f) {
   uint32_t f2[10], f19[10], f38[10], r[10];
 #pragma unroll
-  for (int i = 0; i < 9; i++) f2[i] = 2u * f.v[i];
+  for (int i = 0; i < 9; i++) { ED_CHECK(f.v[i] <= 0x7fffffffu); f2[i] = 2u * f.v[i]; }
 #pragma unroll
-  for (int j = 5; j < 10; j++) { f19[j] = 19u * f.v[j]; f38[j] = 2u * f19[j]; }
+  for (int j = 5; j < 10; j++) {
+    ED_CHECK(f.v[j] <= 0xffffffffu / ((j & 1) ? 38u : 19u));
+    f19[j] = 19u * f.v[j];
+    f38[j] = 2u * f19[j];
+  }
   uint64_t acc = 0;
 #pragma unroll
   for (int k = 0; k < 10; k++) {

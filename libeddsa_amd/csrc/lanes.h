@@ -1,0 +1,387 @@
+// lanes.h - what ONE lane computes in each kernel of kernels.hip, as plain functions over
+// pointers (no threadIdx/blockIdx), so that the very same source also compiles for the host CPU
+// under -DED_HOST_CHECK and is checked there against the oracle with every bound asserted
+// (tests/host_check/, tests/test_device_source_on_host.py).
+//
+//   x25519_lane            x25519.c:129-150 do_x25519
+//   table_entry_lane       one entry of the generated lib/ed_lookup64.h
+//   verify_prepare_lane    ed25519-sha512.c:148-172 (hash, scalars, import of -A) + table 0..8 * -A
+//   verify_main_lane       ed.c:455-507 ed_dual_scale (windowed, uniform control flow)
+//   verify_encode_lane     ed.c:155-169 ed_export + ed25519-sha512.c:176-180 (given 1/Z)
+//   scale_base_lane        ed.c:397-430 ed_scale_base (comb, constant-time select)
+//   genpub_lane, sign_lane ed25519-sha512.c:53-123
+//   x25519_base_lane       x25519.c:158-197
+//   pk_to_x_lane, sk_to_x_lane   ed25519-sha512.c:187-256
+#pragma once
+#include "fe25519.h"
+#include "ge25519.h"
+#include "sc25519.h"
+#include "sha512.h"
+
+#define TABLE_BASE8_ENTRIES 129   /* k*B, k = 0..128 */
+#define TABLE_COMB_ENTRIES 256    /* (k+1)*256^i*B, i < 32, k < 8: ed.c:41-43 ed_lookup */
+#define TABLE_ENTRY_WORDS 32      /* 3 x 10 limbs + 2 padding words */
+#define VERIFY_TABLE_ENTRIES 9    /* 0..8 times -A, cached form */
+#define VERIFY_ENTRY_WORDS 40     /* ymx | ypx | t2d | z2 */
+
+namespace ed {
+
+struct alignas(16) word4 { uint32_t x, y, z, w; };   // one 16-byte load / store
+
+// 256-bit little-endian value << s (s = 1, 4 or 8): the scalar is consumed from the top
+template <int S>
+ED_DEV void shl256(uint32_t w[8]) {
+#pragma unroll
+  for (int i = 7; i > 0; i--) w[i] = (w[i] << S) | (w[i - 1] >> (32 - S));
+  w[0] <<= S;
+}
+
+// x25519.c:137-140: clamp copy
+ED_DEV void clamp(uint32_t s[8]) {
+  s[0] &= 0xfffffff8u;
+  s[7] = (s[7] & 0x7fffffffu) | 0x40000000u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// X25519: x25519.c:60-150 (montgomery, mg_scale, do_x25519)
+// ---------------------------------------------------------------------------------------------
+
+ED_DEV void x25519_lane(uint32_t out[8], uint32_t s[8], const uint32_t pt[8]) {
+  fe x1, x2, z2, x3, z3;
+  clamp(s);
+  fe_frombytes(x1, pt);                          // bit 255 folded in as +19, not masked (fld.c:153)
+  fe_set(x2, 1); fe_set(z2, 0); x3 = x1; fe_set(z3, 1);
+  // bit 255 of the clamped scalar is 0 and the step for it maps (1:0),(x1:1) to itself
+  // projectively, so the ladder starts at bit 254.
+  shl256<1>(s);
+  uint32_t swap = 0;
+#pragma unroll 1
+  for (int t = 254; t >= 0; t--) {
+    const uint32_t bit = s[7] >> 31;
+    shl256<1>(s);
+    swap ^= bit;
+    fe_cswap(x2, x3, swap != 0);
+    fe_cswap(z2, z3, swap != 0);
+    swap = bit;
+    fe a, aa, b, bb, e, c, d, da, cb, t1;
+    fe_add(a, x2, z2);                           // 2u
+    fe_sq(aa, a);
+    fe_sub(b, x2, z2);                           // 3u
+    fe_sq(bb, b);
+    fe_sub(e, aa, bb);                           // 3u
+    fe_add(c, x3, z3);                           // 2u
+    fe_sub(d, x3, z3);                           // 3u
+    fe_mul(da, d, a);
+    fe_mul(cb, c, b);
+    fe_add(t1, da, cb);                          // 2u
+    fe_sq(x3, t1);
+    fe_sub(t1, da, cb);                          // 3u
+    fe_sq(t1, t1);
+    fe_mul(z3, t1, x1);
+    fe_mul(x2, aa, bb);
+    fe_mul121665(t1, e);                         // x25519.c:78 fld_scale(T2, T1, 121665)
+    fe_add(t1, t1, aa);                          // 2u
+    fe_mul(z2, e, t1);
+  }
+  fe_cswap(x2, x3, swap != 0);
+  fe_cswap(z2, z3, swap != 0);
+  fe_inv(z2, z2);                                // z = 0 -> 0 (x25519.c:145)
+  fe_mul(x2, x2, z2);
+  fe_tobytes(out, x2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// base-point tables (what the reference ships as generated data, lib/ed_lookup64.h)
+// ---------------------------------------------------------------------------------------------
+// Entry = 32 words: y-x | y+x | 2dxy (10 canonical limbs each) + 2 words of padding.
+//   base8[k],  k = 0..128 : k * B                  (8-bit signed windows of S in verify)
+//   comb[i][k], i < 32, k < 8 : (k+1) * 256^i * B  (ed.c:41-43 ed_lookup, sign/genpub/x25519_base)
+
+ED_DEV void niels_store(uint32_t* dst, const ge_niels& n) {
+#pragma unroll
+  for (int j = 0; j < 10; j++) { dst[j] = n.ymx.v[j]; dst[10 + j] = n.ypx.v[j]; dst[20 + j] = n.t2d.v[j]; }
+  dst[30] = 0; dst[31] = 0;
+}
+
+ED_DEV void niels_load(ge_niels& n, const uint32_t* src) {
+#pragma unroll
+  for (int j = 0; j < 10; j++) { n.ymx.v[j] = src[j]; n.ypx.v[j] = src[10 + j]; n.t2d.v[j] = src[20 + j]; }
+}
+
+// dst = affine niels form of mult * 2^shift * B
+ED_DEV void table_entry_lane(uint32_t* dst, uint32_t mult, uint32_t shift) {
+  ge b, acc;
+  ge_cached bc;
+  ge_base(b);
+  ge_to_cached(bc, b);
+  ge_neutral(acc);
+  for (int bit = 7; bit >= 0; bit--) {           // acc = mult * B, mult < 256
+    ge_dbl(acc, acc, true);
+    if ((mult >> bit) & 1) ge_add_cached(acc, acc, bc, true);
+  }
+  for (uint32_t s = 0; s < shift; s++) ge_dbl(acc, acc, true);
+  ge_niels n;
+  ge_to_niels_affine(n, acc);                    // identity -> (1, 1, 0)
+  niels_store(dst, n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ed25519 verify: ed25519-sha512.c:148-181
+// ---------------------------------------------------------------------------------------------
+// C = S*B + t*(-A) is evaluated as ONE left-to-right pass over 64 four-bit windows:
+//     acc = 16*acc + d_i*(-A)  [+ e_j*B when i = 2j]
+// with d_i in [-8,7] (ed.c:407-409's x + 0x88..8 recoding) looked up in a per-item table of
+// 0..8 times -A, and e_j in [-128,127] looked up in a 129-entry table of multiples of B.
+// Control flow is uniform; the reference's 9-way data-dependent branch (ed.c:480-501) would
+// serialise all 64 lanes of a wave.  Equality of the result with the reference's:
+// DESIGN.md "Why the windowed evaluation is bit-exact".
+
+// table entry = 40 words (ymx | ypx | t2d | z2), contiguous per item so that one lookup reads
+// 160 contiguous bytes (ten 16-byte loads) instead of touching one 128-byte line per word.
+ED_DEV void cached_store(uint32_t* tab, int entry, const ge_cached& c) {
+  word4* p = reinterpret_cast<word4*>(tab + entry * VERIFY_ENTRY_WORDS);
+  const fe* f[4] = {&c.ymx, &c.ypx, &c.t2d, &c.z2};
+  uint32_t w[40];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int j = 0; j < 10; j++) w[10 * k + j] = f[k]->v[j];
+#pragma unroll
+  for (int q = 0; q < 10; q++) p[q] = word4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+}
+ED_DEV void cached_load(ge_cached& c, const uint32_t* tab, uint32_t entry) {
+  const word4* p = reinterpret_cast<const word4*>(tab + entry * VERIFY_ENTRY_WORDS);
+  uint32_t w[40];
+#pragma unroll
+  for (int q = 0; q < 10; q++) {
+    const word4 v = p[q];
+    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+  }
+#pragma unroll
+  for (int j = 0; j < 10; j++) {
+    c.ymx.v[j] = w[j]; c.ypx.v[j] = w[10 + j]; c.t2d.v[j] = w[20 + j]; c.z2.v[j] = w[30 + j];
+  }
+}
+
+// rw = R, sw = S (raw, replaced by the digit words), aw = A as little-endian words.
+// Writes tw/sw digit words and the 9-entry table at tab; returns whether A is on the curve.
+ED_DEV bool verify_prepare_lane(uint32_t tw[8], uint32_t sw[8], uint32_t* tab, const uint32_t rw[8],
+                                const uint32_t aw[8], const uint8_t* m, size_t mlen) {
+  // t = SHA-512(R || A || M) mod l ; S mod l (not range-checked: sc.c:191-214)
+  {
+    uint32_t pre[16], dig[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { pre[k] = rw[k]; pre[8 + k] = aw[k]; }
+    sha512_prefix_msg<16>(dig, pre, m, mlen);
+    sc t, s;
+    sc_from_words<16>(t, dig);
+    sc_from_words<8>(s, sw);
+    sc_to_words(tw, t);
+    sc_to_words(sw, s);
+    words_add_pattern(tw, 0x88888888u);          // nibble - 8 is the signed digit
+    words_add_pattern(sw, 0x80808080u);          // byte - 128 is the signed digit
+  }
+  // -A and its multiples 0..8, cached form
+  bool oncurve;
+  ge a, p, q;
+  ge_cached c1, c;
+  ge_frombytes(a, oncurve, aw, true);
+  ge_neutral(p);
+  ge_to_cached(c, p);  cached_store(tab, 0, c);
+  ge_to_cached(c1, a); cached_store(tab, 1, c1);
+  ge_dbl(p, a, true);                            // 2
+  ge_to_cached(c, p);  cached_store(tab, 2, c);
+  ge_add_cached(q, p, c1, true);                 // 3
+  ge_to_cached(c, q);  cached_store(tab, 3, c);
+  ge_dbl(p, p, true);                            // 4
+  ge_to_cached(c, p);  cached_store(tab, 4, c);
+  ge_dbl(q, q, true);                            // 6
+  ge_to_cached(c, q);  cached_store(tab, 6, c);
+  ge_add_cached(q, q, c1, true);                 // 7
+  ge_to_cached(c, q);  cached_store(tab, 7, c);
+  ge_add_cached(q, p, c1, true);                 // 5
+  ge_to_cached(c, q);  cached_store(tab, 5, c);
+  ge_dbl(p, p, true);                            // 8
+  ge_to_cached(c, p);  cached_store(tab, 8, c);
+  return oncurve;
+}
+
+// tw, sw: digit words (consumed); tab: this item's table; base8: the k*B table (LDS on the device)
+ED_DEV void verify_main_lane(ge& acc, uint32_t tw[8], uint32_t sw[8], const uint32_t* tab,
+                             const uint32_t* base8) {
+  ge_neutral(acc);
+#pragma unroll 1
+  for (int w = 63; w >= 0; w--) {
+    if (w != 63) {
+#pragma unroll 1
+      for (int k = 0; k < 4; k++) ge_dbl(acc, acc, k == 3);
+    }
+    {
+      const int dig = (int)(tw[7] >> 28) - 8;
+      shl256<4>(tw);
+      const uint32_t mag = (uint32_t)(dig < 0 ? -dig : dig);
+      ge_cached c;
+      cached_load(c, tab, mag);
+      ge_cached_cneg(c, dig < 0);
+      ge_add_cached(acc, acc, c, (w & 1) == 0);
+    }
+    if ((w & 1) == 0) {
+      const int dig = (int)(sw[7] >> 24) - 128;
+      shl256<8>(sw);
+      const uint32_t mag = (uint32_t)(dig < 0 ? -dig : dig);
+      ge_niels nb;
+      niels_load(nb, base8 + TABLE_ENTRY_WORDS * mag);
+      ge_niels_cneg(nb, dig < 0);
+      ge_add_niels(acc, acc, nb, false);
+    }
+  }
+}
+
+// ed_export given zinv = 1/Z, then the byte comparison with R (ed25519-sha512.c:176-180)
+ED_DEV bool verify_encode_lane(const fe& X, const fe& Y, const fe& zinv, const uint32_t rw[8]) {
+  fe x, y;
+  fe_mul(x, X, zinv);
+  fe_mul(y, Y, zinv);
+  uint32_t cw[8];
+  fe_tobytes(cw, y);
+  cw[7] |= fe_parity(x) << 31;
+  uint32_t diff = 0;
+#pragma unroll
+  for (int q = 0; q < 8; q++) diff |= cw[q] ^ rw[q];
+  return diff == 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fixed-base path: ed.c:346-430 (scale16, ed_scale_base) and its callers
+// ---------------------------------------------------------------------------------------------
+// Same comb as the reference: 64 signed 4-bit digits of (x + 0x88..8); even digits accumulate in
+// R0, odd digits in R1, both from row i of comb[32][8] (staged in LDS); R1 <- 16 R1; R0 + R1.
+// The scalar is secret here, so the lookup keeps the reference's constant-time discipline
+// (ed.c:359-390): every lane reads all eight entries of the row (a wave-uniform LDS address,
+// served as a broadcast) and keeps the one it needs with v_cndmask; no secret-dependent address,
+// no secret-dependent branch.
+
+ED_DEV void comb_select(ge_niels& e, const uint32_t* row, int digit) {
+  const uint32_t mag = (uint32_t)(digit < 0 ? -digit : digit);
+  fe_set(e.ymx, 1); fe_set(e.ypx, 1); fe_set(e.t2d, 0);        // ed.c:73 pced_zero
+#pragma unroll
+  for (uint32_t k = 0; k < 8; k++) {
+    ge_niels c;
+    niels_load(c, row + TABLE_ENTRY_WORDS * k);
+    const bool hit = (mag == k + 1);
+    fe_cmov(e.ymx, c.ymx, hit); fe_cmov(e.ypx, c.ypx, hit); fe_cmov(e.t2d, c.t2d, hit);
+  }
+  ge_niels_cneg(e, digit < 0);
+}
+
+// out = x * B for a reduced scalar given as eight little-endian words (consumed)
+ED_DEV void scale_base_lane(ge& out, uint32_t xw[8], const uint32_t* comb) {
+  words_add_pattern(xw, 0x88888888u);            // ed.c:407-409
+  ge r0, r1;
+  ge_neutral(r0); ge_neutral(r1);
+#pragma unroll 1
+  for (int i = 0; i < 32; i++) {
+    const uint32_t byte = xw[0] & 0xffu;
+#pragma unroll
+    for (int k = 0; k < 7; k++) xw[k] = (xw[k] >> 8) | (xw[k + 1] << 24);
+    xw[7] >>= 8;
+    ge_niels e;
+    comb_select(e, comb + TABLE_ENTRY_WORDS * 8 * i, (int)(byte & 15u) - 8);
+    ge_add_niels(r0, r0, e, true);
+    comb_select(e, comb + TABLE_ENTRY_WORDS * 8 * i, (int)(byte >> 4) - 8);
+    ge_add_niels(r1, r1, e, true);
+  }
+#pragma unroll 1
+  for (int k = 0; k < 4; k++) ge_dbl(r1, r1, k == 3);
+  ge_cached c;
+  ge_to_cached(c, r1);
+  ge_add_cached(out, r0, c, false);
+}
+
+// ed25519-sha512.c:31-47 ed25519_key_setup: h = SHA-512(sk), clamped
+ED_DEV void key_setup(uint32_t h[16], const uint32_t sk[8]) {
+  sha512_prefix_msg<8>(h, sk, nullptr, 0);
+  h[0] &= 0xfffffff8u;
+  h[7] = (h[7] & 0x7fffffffu) | 0x40000000u;
+}
+
+// ed25519-sha512.c:53-67 genpub
+ED_DEV void genpub_lane(uint32_t out[8], const uint32_t sk[8], const uint32_t* comb) {
+  uint32_t h[16], aw[8];
+  key_setup(h, sk);
+  sc a;
+  sc_from_words<8>(a, h);
+  sc_to_words(aw, a);
+  ge A;
+  scale_base_lane(A, aw, comb);
+  ge_tobytes(out, A);
+}
+
+// ed25519-sha512.c:84-123 sign: Rw | Sw is the signature
+ED_DEV void sign_lane(uint32_t Rw[8], uint32_t Sw[8], const uint32_t sk[8], const uint32_t pub[8],
+                      const uint8_t* m, size_t mlen, const uint32_t* comb) {
+  uint32_t h[16], dig[16], rw[8];
+  key_setup(h, sk);
+  sc a, r, t, S;
+  sc_from_words<8>(a, h);
+  sha512_prefix_msg<8>(dig, h + 8, m, mlen);     // r = H(h[32..64) || M)
+  sc_from_words<16>(r, dig);
+  sc_to_words(rw, r);
+  {
+    ge R;
+    scale_base_lane(R, rw, comb);
+    ge_tobytes(Rw, R);
+  }
+  {
+    uint32_t pre[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { pre[k] = Rw[k]; pre[8 + k] = pub[k]; }
+    sha512_prefix_msg<16>(dig, pre, m, mlen);    // t = H(R || A || M)
+  }
+  sc_from_words<16>(t, dig);
+  sc_mul(S, t, a);
+  sc_add(S, r, S);
+  sc_to_words(Sw, S);
+}
+
+// x25519.c:158-197 do_x25519_base
+ED_DEV void x25519_base_lane(uint32_t out[8], uint32_t s[8], const uint32_t* comb) {
+  uint32_t xw[8];
+  clamp(s);
+  sc x;
+  sc_from_words<8>(x, s);
+  sc_to_words(xw, x);
+  ge R;
+  scale_base_lane(R, xw, comb);
+  fe u, t;
+  fe_sub(t, R.Z, R.Y);                           // 3u
+  fe_inv(t, t);
+  fe_add(u, R.Z, R.Y);                           // 2u
+  fe_mul(u, u, t);
+  fe_tobytes(out, u);
+}
+
+// ed25519-sha512.c:187-232 pk_ed25519_to_x25519: u = (z + y) / (z - y) of the imported point.
+// ed_import always returns z = 1 and y = the 255 low bits of the input taken mod p; x (and the
+// square root that produces it) never reaches the output, so it is not computed.
+ED_DEV void pk_to_x_lane(uint32_t out[8], uint32_t w[8]) {
+  w[7] &= 0x7fffffffu;
+  fe y, one, u, t;
+  fe_frombytes(y, w);
+  fe_set(one, 1);
+  fe_sub(t, one, y);                             // 3u
+  fe_inv(t, t);                                  // 1 - y = 0 -> 0, as fld_inv
+  fe_add(u, one, y);
+  fe_mul(u, u, t);
+  fe_tobytes(out, u);
+}
+
+// ed25519-sha512.c:239-256 sk_ed25519_to_x25519: the first 32 bytes of the clamped key hash
+ED_DEV void sk_to_x_lane(uint32_t out[8], const uint32_t sk[8]) {
+  uint32_t h[16];
+  key_setup(h, sk);
+#pragma unroll
+  for (int k = 0; k < 8; k++) out[k] = h[k];
+}
+
+}  // namespace ed

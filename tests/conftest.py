@@ -127,3 +127,21 @@ def engine():
     assert torch.cuda.is_available()
     ed.init(0)
     return ed
+
+
+@pytest.fixture(scope="session")
+def hostcheck():
+    """the device source compiled for the host CPU with every bound asserted (tests/host_check/):
+    a test binary that lets the CPU suite run the kernels' exact algorithms; not the product"""
+    d = os.path.join(ROOT, "tests", "host_check")
+    lib = os.path.join(d, "libhostcheck.so")
+    srcs = [os.path.join(d, "host_check.cpp")] + [os.path.join(ROOT, "libeddsa_amd", "csrc", f)
+                                                   for f in ("lanes.h", "fe25519.h", "ge25519.h", "sc25519.h", "sha512.h")]
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DED_HOST_CHECK", "-Wno-unknown-pragmas",
+                               "-I" + os.path.join(ROOT, "libeddsa_amd", "csrc"), srcs[0], "-o", lib])
+    h = ctypes.CDLL(lib)
+    h.hc_first_violation.restype = ctypes.c_char_p
+    h.hc_violations.restype = ctypes.c_long
+    h.hc_reset()
+    return h

@@ -1,0 +1,187 @@
+// host_check.cpp - TEST BINARY: the device source (libeddsa_amd/csrc/lanes.h and the headers it
+// includes) compiled for the host CPU with -DED_HOST_CHECK, i.e. with an assertion on every limb
+// precondition and on every 64-bit column sum.  Lets the CPU test suite run the exact algorithms
+// of the kernels (windowed double-scalar multiplication, comb, ladder, digit recoding, Barrett,
+// SHA-512) against the oracle without a GPU, and proves the bounds quoted in fe25519.h on the
+// inputs it is driven with.  It is not part of the product and nothing in the product loads it.
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "lanes.h"
+
+namespace ed {
+static std::atomic<long> g_violations{0};
+static char g_first[256];
+static std::mutex g_mu;
+void bound_violation(const char* file, int line, const char* what) {
+  if (g_violations.fetch_add(1) == 0) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    snprintf(g_first, sizeof(g_first), "%s:%d: %s", file, line, what);
+  }
+}
+}  // namespace ed
+
+using namespace ed;
+
+static void rd(uint32_t w[8], const uint8_t* p) { memcpy(w, p, 32); }      // little-endian host
+static void wr(uint8_t* p, const uint32_t w[8]) { memcpy(p, w, 32); }
+
+struct Tables {
+  std::vector<uint32_t> base8, comb;
+  Tables() : base8(TABLE_BASE8_ENTRIES * TABLE_ENTRY_WORDS), comb(TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS) {
+    for (int k = 0; k < TABLE_BASE8_ENTRIES; k++) table_entry_lane(&base8[TABLE_ENTRY_WORDS * k], (uint32_t)k, 0);
+    for (int c = 0; c < TABLE_COMB_ENTRIES; c++)
+      table_entry_lane(&comb[TABLE_ENTRY_WORDS * c], (uint32_t)(c & 7) + 1, 8u * (uint32_t)(c >> 3));
+  }
+};
+static const Tables& tables() { static Tables t; return t; }
+
+extern "C" {
+
+long hc_violations(void) { return g_violations.load(); }
+const char* hc_first_violation(void) { return g_first; }
+void hc_reset(void) { g_violations = 0; g_first[0] = 0; }
+
+void hc_tables(uint32_t* base8, uint32_t* comb) {
+  memcpy(base8, tables().base8.data(), tables().base8.size() * 4);
+  memcpy(comb, tables().comb.data(), tables().comb.size() * 4);
+}
+
+void hc_x25519(uint8_t out[32], const uint8_t scalar[32], const uint8_t point[32]) {
+  uint32_t s[8], p[8], o[8];
+  rd(s, scalar); rd(p, point);
+  x25519_lane(o, s, p);
+  wr(out, o);
+}
+
+// the three verify kernels for one item (the finish step without the cross-item batching, plus
+// the same Z = 0 / off-curve rule)
+int hc_verify(const uint8_t sig[64], const uint8_t pub[32], const uint8_t* msg, size_t len) {
+  alignas(16) uint32_t tab[VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS];
+  uint32_t rw[8], sw[8], aw[8], tw[8];
+  rd(rw, sig); rd(sw, sig + 32); rd(aw, pub);
+  const bool oncurve = verify_prepare_lane(tw, sw, tab, rw, aw, msg, len);
+  ge acc;
+  verify_main_lane(acc, tw, sw, tab, tables().base8.data());
+  if (!oncurve || fe_iszero(acc.Z)) return 0;
+  fe zinv;
+  fe_inv(zinv, acc.Z);
+  return verify_encode_lane(acc.X, acc.Y, zinv, rw) ? 1 : 0;
+}
+
+// Montgomery's trick exactly as k_verify_finish applies it, on k <= 8 values: out[j] = 1/z[j]
+void hc_batch_inverse(uint8_t* out, const uint8_t* zs, int k) {
+  fe z[8], p[8], u, zi;
+  uint32_t w[8];
+  for (int j = 0; j < k; j++) { rd(w, zs + 32 * j); fe_frombytes(z[j], w); }
+  p[0] = z[0];
+  for (int j = 1; j < k; j++) fe_mul(p[j], p[j - 1], z[j]);
+  fe_inv(u, p[k - 1]);
+  for (int j = k - 1; j >= 1; j--) {
+    fe_mul(zi, u, p[j - 1]);
+    fe_tobytes(w, zi); wr(out + 32 * j, w);
+    fe_mul(u, u, z[j]);
+  }
+  fe_tobytes(w, u); wr(out, w);
+}
+
+void hc_genpub(uint8_t pub[32], const uint8_t sec[32]) {
+  uint32_t sk[8], o[8];
+  rd(sk, sec);
+  genpub_lane(o, sk, tables().comb.data());
+  wr(pub, o);
+}
+
+void hc_sign(uint8_t sig[64], const uint8_t sec[32], const uint8_t pub[32], const uint8_t* msg, size_t len) {
+  uint32_t sk[8], pk[8], R[8], S[8];
+  rd(sk, sec); rd(pk, pub);
+  sign_lane(R, S, sk, pk, msg, len, tables().comb.data());
+  wr(sig, R); wr(sig + 32, S);
+}
+
+void hc_x25519_base(uint8_t out[32], const uint8_t scalar[32]) {
+  uint32_t s[8], o[8];
+  rd(s, scalar);
+  x25519_base_lane(o, s, tables().comb.data());
+  wr(out, o);
+}
+
+void hc_pk_to_x(uint8_t out[32], const uint8_t in[32]) {
+  uint32_t w[8], o[8];
+  rd(w, in);
+  pk_to_x_lane(o, w);
+  wr(out, o);
+}
+
+void hc_sk_to_x(uint8_t out[32], const uint8_t in[32]) {
+  uint32_t w[8], o[8];
+  rd(w, in);
+  sk_to_x_lane(o, w);
+  wr(out, o);
+}
+
+// ---- layer probes -------------------------------------------------------------------------
+
+void hc_fe_mul(uint8_t out[32], const uint8_t a[32], const uint8_t b[32]) {
+  uint32_t w[8]; fe x, y;
+  rd(w, a); fe_frombytes(x, w); rd(w, b); fe_frombytes(y, w);
+  fe_mul(x, x, y);
+  fe_tobytes(w, x); wr(out, w);
+}
+void hc_fe_sq(uint8_t out[32], const uint8_t a[32]) {
+  uint32_t w[8]; fe x;
+  rd(w, a); fe_frombytes(x, w); fe_sq(x, x); fe_tobytes(w, x); wr(out, w);
+}
+void hc_fe_inv(uint8_t out[32], const uint8_t a[32]) {
+  uint32_t w[8]; fe x;
+  rd(w, a); fe_frombytes(x, w); fe_inv(x, x); fe_tobytes(w, x); wr(out, w);
+}
+void hc_fe_pow2523(uint8_t out[32], const uint8_t a[32]) {
+  uint32_t w[8]; fe x;
+  rd(w, a); fe_frombytes(x, w); fe_pow2523(x, x); fe_tobytes(w, x); wr(out, w);
+}
+// multiplication at the documented operand limits: f = ka * a (limb-wise, ka <= 7), g = kb * b (kb <= 3)
+void hc_fe_mul_loose(uint8_t out[32], const uint8_t a[32], int ka, const uint8_t b[32], int kb) {
+  uint32_t w[8]; fe x, y, fx, gy;
+  rd(w, a); fe_frombytes(x, w); rd(w, b); fe_frombytes(y, w);
+  fe_set(fx, 0); fe_set(gy, 0);
+  for (int i = 0; i < ka; i++) fe_add(fx, fx, x);
+  for (int i = 0; i < kb; i++) fe_add(gy, gy, y);
+  fe_mul(x, fx, gy);
+  fe_tobytes(w, x); wr(out, w);
+}
+void hc_sc_reduce(uint8_t out[32], const uint8_t* in, size_t len) {      // len = 32 or 64
+  uint32_t w[16], o[8]; sc x;
+  memcpy(w, in, len);
+  if (len == 32) sc_from_words<8>(x, w); else sc_from_words<16>(x, w);
+  sc_to_words(o, x); wr(out, o);
+}
+void hc_sc_muladd(uint8_t out[32], const uint8_t a[32], const uint8_t b[32], const uint8_t c[32]) {
+  uint32_t w[8], o[8]; sc x, y, z;
+  rd(w, a); sc_from_words<8>(x, w); rd(w, b); sc_from_words<8>(y, w); rd(w, c); sc_from_words<8>(z, w);
+  sc_mul(x, x, y); sc_add(x, z, x);
+  sc_to_words(o, x); wr(out, o);
+}
+void hc_sha512(uint8_t out[64], const uint8_t* msg, size_t len) {
+  uint32_t d[16];
+  sha512_prefix_msg<0>(d, nullptr, msg, len);
+  memcpy(out, d, 64);
+}
+int hc_ed_import_export(uint8_t out[32], const uint8_t in[32]) {         // returns the on-curve flag
+  uint32_t w[8], o[8]; ge p; bool oc;
+  rd(w, in);
+  ge_frombytes(p, oc, w, false);
+  ge_tobytes(o, p); wr(out, o);
+  return oc ? 1 : 0;
+}
+void hc_scale_base(uint8_t out[32], const uint8_t scalar[32]) {           // scalar reduced mod l first
+  uint32_t w[8], xw[8], o[8]; sc x; ge p;
+  rd(w, scalar); sc_from_words<8>(x, w); sc_to_words(xw, x);
+  scale_base_lane(p, xw, tables().comb.data());
+  ge_tobytes(o, p); wr(out, o);
+}
+
+}  // extern "C"

@@ -142,9 +142,13 @@ def test_two_rank_shard_and_gather_over_gloo(oracle, tmp_path):
     """N > 1 path: contiguous shards, independent compute, one all-gather of the result bytes."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
+    import socket
+    with socket.socket() as sk:                 # a free rendezvous port (avoids TIME_WAIT collisions)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, REPO=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29513", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout

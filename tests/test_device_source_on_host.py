@@ -1,0 +1,153 @@
+"""The DEVICE source (libeddsa_amd/csrc/lanes.h + field/scalar/hash/group headers), compiled for the
+host CPU with -DED_HOST_CHECK, against the golden vectors and the oracle.  Two things are proven
+without a GPU: (1) the kernels' algorithms (windowed double-scalar multiplication with signed
+digits, comb with constant-time select, ladder, Barrett, SHA-512 padding, permissive import) give
+the reference's bytes; (2) no limb precondition and no 64-bit column sum is violated on any input
+driven through here, including the extreme ones (every assertion of fe25519.h is live)."""
+import ctypes
+import hashlib
+
+import numpy as np
+
+from gen_golden import golden_msg
+
+H = bytes.fromhex
+P = 2**255 - 19
+L = 2**252 + 27742317777372353535851937790883648493
+SZ = ctypes.c_size_t
+
+
+def call(h, name, out_len, *args):
+    out = ctypes.create_string_buffer(out_len)
+    getattr(h, name)(out, *args)
+    return out.raw
+
+
+def no_violations(h):
+    assert h.hc_violations() == 0, h.hc_first_violation()
+
+
+def le(x, n=32):
+    return int(x).to_bytes(n, "little")
+
+
+EXTREME = [0, 1, 2, 9, 19, P - 1, P, P + 1, 2**255 - 19 - 1, 2**255 - 1, 2**255, 2**255 + 18, 2**256 - 1,
+           (1 << 26) - 1, 1 << 26, ((1 << 255) - 1) ^ ((1 << 128) - 1), int("aa" * 32, 16), int("55" * 32, 16),
+           L - 1, L, L + 1, 2**252, 2**253 - 1]
+
+
+def test_x25519_table_and_extremes(hostcheck, oracle, golden):
+    raw = golden("x25519_table.bin")
+    for i in range(0, 1024, 3):
+        pt, sc, res = raw[96 * i:96 * i + 32], raw[96 * i + 32:96 * i + 64], raw[96 * i + 64:96 * i + 96]
+        assert call(hostcheck, "hc_x25519", 32, sc, pt) == res, i
+    for a in EXTREME:
+        for b in EXTREME[::2]:
+            assert call(hostcheck, "hc_x25519", 32, le(a), le(b)) == oracle.x25519(le(a), le(b))
+    no_violations(hostcheck)
+
+
+def test_ed25519_table(hostcheck, golden):
+    raw = golden("ed25519_table.bin")
+    for i in list(range(0, 1024, 7)) + [47, 48, 111, 112, 1023]:
+        sk, pk, sig = raw[128 * i:128 * i + 32], raw[128 * i + 32:128 * i + 64], raw[128 * i + 64:128 * i + 128]
+        msg = golden_msg(i)
+        assert call(hostcheck, "hc_genpub", 32, sk) == pk, i
+        assert call(hostcheck, "hc_sign", 64, sk, pk, msg, SZ(len(msg))) == sig, i
+        assert hostcheck.hc_verify(sig, pk, msg, SZ(len(msg))) == 1, i
+    no_violations(hostcheck)
+
+
+def test_verify_edge_cases(hostcheck, golden):
+    for c in golden("verify_edges.json"):
+        msg = H(c["msg"])
+        assert hostcheck.hc_verify(H(c["sig"]), H(c["pub"]), msg, SZ(len(msg))) == int(c["accept"]), c["name"]
+    no_violations(hostcheck)
+
+
+def test_layer_kats_and_loose_operands(hostcheck, golden):
+    k = golden("layer_kats.json")
+    for a, b, r in k["fld_mul"]:
+        assert call(hostcheck, "hc_fe_mul", 32, H(a), H(b)).hex() == r
+        # the same product with operands at the documented limits: f = 7a (< 8u), g = 3b (< 3.36u)
+        want = (7 * int.from_bytes(H(a), "little") * 3 * int.from_bytes(H(b), "little")) % P
+        assert call(hostcheck, "hc_fe_mul_loose", 32, H(a), 7, H(b), 3) == le(want)
+    for name, fn in (("fld_sq", "hc_fe_sq"), ("fld_inv", "hc_fe_inv"), ("fld_pow2523", "hc_fe_pow2523"),
+                     ("ed_import_export", "hc_ed_import_export"), ("ed_scale_base", "hc_scale_base"),
+                     ("pk_to_x", "hc_pk_to_x"), ("sk_to_x", "hc_sk_to_x"), ("x25519_base", "hc_x25519_base")):
+        for a, r in k[name]:
+            assert call(hostcheck, fn, 32, H(a)).hex() == r, (name, a)
+    for s, r in k["sc_import"]:
+        assert call(hostcheck, "hc_sc_reduce", 32, H(s), SZ(len(s) // 2)).hex() == r
+    for a, b, c, r in k["sc_muladd"]:
+        assert call(hostcheck, "hc_sc_muladd", 32, H(a), H(b), H(c)).hex() == r
+    for n, r in k["sha512"]:
+        m = golden_msg(n)
+        assert call(hostcheck, "hc_sha512", 64, m, SZ(n)).hex() == r
+    no_violations(hostcheck)
+
+
+def test_all_ones_operands_stay_in_bounds(hostcheck):
+    """worst-case limbs: every limb of both operands at its maximum, at the loose-operand limits"""
+    ones = b"\xff" * 32
+    for ka in (1, 4, 7):
+        for kb in (1, 2, 3):
+            a = int.from_bytes(ones, "little") % P + 0   # 2^256-1 folds to 2^255-1+19 -> limbs all ones
+            want = (ka * ((2**255 - 1) + 19) * kb * ((2**255 - 1) + 19)) % P
+            assert call(hostcheck, "hc_fe_mul_loose", 32, ones, ka, ones, kb) == le(want)
+    no_violations(hostcheck)
+
+
+def test_batch_inverse_is_the_inverse(hostcheck):
+    rng = np.random.default_rng(8)
+    for k in (1, 2, 5, 8):
+        zs = [int.from_bytes(bytes(rng.integers(0, 256, 32, dtype=np.uint8)), "little") for _ in range(k)]
+        zs[0] = P - 1
+        out = ctypes.create_string_buffer(32 * k)
+        hostcheck.hc_batch_inverse(out, b"".join(le(z) for z in zs), k)
+        for j, z in enumerate(zs):
+            assert int.from_bytes(out.raw[32 * j:32 * j + 32], "little") == pow(z % P, P - 2, P), (k, j)
+    no_violations(hostcheck)
+
+
+def test_random_against_oracle(hostcheck, oracle):
+    rng = np.random.default_rng(21)
+    rb = lambda n: bytes(rng.integers(0, 256, n, dtype=np.uint8))  # noqa: E731
+    for i in range(150):
+        sk, msg = rb(32), rb(int(rng.integers(0, 200)))
+        pk = oracle.genpub(sk)
+        assert call(hostcheck, "hc_genpub", 32, sk) == pk
+        sig = oracle.sign(sk, pk, msg)
+        assert call(hostcheck, "hc_sign", 64, sk, pk, msg, SZ(len(msg))) == sig
+        cases = [(sig, pk), (rb(64), rb(32)), (sig[:32] + le((int.from_bytes(sig[32:], "little") + L) % 2**256), pk),
+                 (sig, rb(32)), (sig[:31] + bytes([sig[31] ^ 0x80]) + sig[32:], pk)]
+        for s, p_ in cases:
+            assert hostcheck.hc_verify(s, p_, msg, SZ(len(msg))) == int(oracle.verify(s, p_, msg))
+        a, b = rb(32), rb(32)
+        assert call(hostcheck, "hc_x25519", 32, a, b) == oracle.x25519(a, b)
+        assert call(hostcheck, "hc_x25519_base", 32, a) == oracle.x25519_base(a)
+        assert call(hostcheck, "hc_pk_to_x", 32, a) == oracle.pk_to_x(a)
+        assert call(hostcheck, "hc_sk_to_x", 32, a) == oracle.sk_to_x(a)
+    no_violations(hostcheck)
+
+
+def test_tables_match_the_reference_points(hostcheck, golden):
+    base8 = np.zeros((129, 32), np.uint32); comb = np.zeros((256, 32), np.uint32)
+    hostcheck.hc_tables(base8.ctypes.data_as(ctypes.c_void_p), comb.ctypes.data_as(ctypes.c_void_p))
+    pos = [0, 26, 51, 77, 102, 128, 153, 179, 204, 230]
+    val = lambda limbs: sum(int(v) << s for v, s in zip(limbs, pos))  # noqa: E731
+    inv2 = pow(2, P - 2, P)
+    pts = golden("comb_points.bin")
+    for e in range(256):
+        ymx, ypx = val(comb[e][0:10]), val(comb[e][10:20])
+        y, x = (ypx + ymx) * inv2 % P, (ypx - ymx) * inv2 % P
+        assert (y | (x & 1) << 255).to_bytes(32, "little") == pts[32 * e:32 * e + 32], e
+    no_violations(hostcheck)
+
+
+def test_the_assertions_are_live(hostcheck):
+    """an operand beyond the documented limit must trip the check (then reset the counter)"""
+    hostcheck.hc_reset()
+    call(hostcheck, "hc_fe_mul_loose", 32, b"\xff" * 32, 7, b"\xff" * 32, 4)      # g = 4u > 3.36u
+    assert hostcheck.hc_violations() > 0 and b"fe25519.h" in hostcheck.hc_first_violation()
+    hostcheck.hc_reset()
