@@ -137,6 +137,38 @@ def cpu_baseline(op, w, gpu_out, sample):
             "per_core": sample / best / cores, "gpu_matches_cpu_on_sample": same}
 
 
+def gather_results(out, world):
+    """N > 1: all-gather the result bytes of every rank's shard (the only exchange of the path)."""
+    if world == 1:
+        return out
+    full = torch.empty((world * out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
+    dist.all_gather_into_tensor(full, out)              # concatenated along dim 0: valid on nccl and gloo
+    return full.view((world,) + tuple(out.shape))
+
+
+def timed_region(step, steps, world, sync, device):
+    """EXACTLY `steps` steps between two (barrier + device sync) brackets; returns the MAX over
+    ranks of the elapsed seconds and the last step's output."""
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,33 +194,23 @@ def main():
     w = make_workload(op, n, rank, device)
     torch.cuda.synchronize()
 
+    marks = []                                          # (start, end) events around each kernel-only part
+
     def step():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         out = run_step(op, w)
-        if world > 1:                                   # the final result gather (RCCL over xGMI)
-            full = torch.empty((world,) + tuple(out.shape), dtype=out.dtype, device=device)
-            dist.all_gather_into_tensor(full, out)
+        e1.record()
+        marks.append((e0, e1))
+        gather_results(out, world)                      # the final result gather (RCCL over xGMI)
         return out
 
     for _ in range(args.warmup):
         out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    marks.clear()
     if op == "verify":
         ed.set_profiling(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, out = timed_region(step, args.steps, world, torch.cuda.synchronize, device)
     phases = ed.verify_phase_ms() if op == "verify" else None
     ed.set_profiling(False)
 
@@ -202,7 +224,8 @@ def main():
         if op == "verify":
             kernel, k_ms, k_mul32 = "k_verify_main", phases[1], MUL32_VERIFY_MAIN
         else:
-            kernel, k_ms, k_mul32 = {"x25519": "k_x25519", "sign": "k_sign"}[op], ms_per_step, mul32
+            k_ms = sum(a.elapsed_time(b) for a, b in marks) / len(marks)      # HIP events, launch stream
+            kernel, k_mul32 = {"x25519": "k_x25519", "sign": "k_sign"}[op], mul32
         achieved = n * k_mul32 / (k_ms * 1e-3) / 1e12
         roofline = {
             "bound": "valu", "kernel": kernel, "achieved": achieved, "peak": PEAK_TMUL32,

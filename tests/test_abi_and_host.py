@@ -138,17 +138,54 @@ print("rank", rank, "ok")
 '''
 
 
-def test_two_rank_shard_and_gather_over_gloo(oracle, tmp_path):
-    """N > 1 path: contiguous shards, independent compute, one all-gather of the result bytes."""
-    script = tmp_path / "worker.py"
-    script.write_text(_WORKER)
+_BENCH_WORKER = r'''
+import os, sys, time
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["REPO"])
+import bench
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+calls = []
+def step():
+    calls.append(1)
+    time.sleep(0.05 * (rank + 1))                       # rank 1 is the slow one
+    out = torch.full((1000,), rank + 1, dtype=torch.uint8)
+    full = bench.gather_results(out, world)
+    assert full.shape == (world, 1000) and [int(full[r, 0]) for r in range(world)] == [1, 2]
+    return out
+elapsed, out = bench.timed_region(step, 4, world, lambda: None, torch.device("cpu"))
+assert len(calls) == 4                                   # exactly K steps
+assert 0.39 < elapsed < 1.5, elapsed                     # the MAX over ranks (4 x 0.1 s), on every rank
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def _torchrun(script, env):
     import socket
     with socket.socket() as sk:                 # a free rendezvous port (avoids TIME_WAIT collisions)
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                          env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_timing_and_gather_helpers_over_gloo(tmp_path):
+    """bench.py's N > 1 plumbing (barrier-bracketed region, max over ranks, result all-gather)"""
+    script = tmp_path / "bench_worker.py"
+    script.write_text(_BENCH_WORKER)
     env = dict(os.environ, REPO=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
-                       env=env, capture_output=True, text=True, timeout=300)
+    r = _torchrun(script, env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+def test_two_rank_shard_and_gather_over_gloo(oracle, tmp_path):
+    """N > 1 path: contiguous shards, independent compute, one all-gather of the result bytes."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, REPO=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = _torchrun(script, env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
