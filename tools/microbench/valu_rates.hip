@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(256) NAME(uint32_t* out, uint64_t* cyc, uint32
   for (int i = 0; i < ITERS; ++i) {                                                 \
     asm volatile(BODY32(INS)                                                        \
       : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
-      : "v"(vx), "v"(vy) : "vcc");                                                  \
+      : "v"(vx), "v"(vy) : "vcc", "s12", "s13");                                    \
   }                                                                                 \
   uint64_t t1 = __builtin_amdgcn_s_memtime();                                       \
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7; \
@@ -80,6 +80,18 @@ __global__ void __launch_bounds__(256) NAME(uint32_t* out, uint64_t* cyc, uint32
 #define I_ADDC(d)     "v_addc_co_u32 " d ", vcc, %8, " d ", vcc\n"
 #define I_FMAF32(d)   "v_fma_f32 " d ", %8, %9, " d "\n"
 #define I_CNDMASK(d)  "v_cndmask_b32 " d ", " d ", %8, vcc\n"
+#define I_CNDMASK64(d) "v_cndmask_b32_e64 " d ", " d ", %8, s[12:13]\n"
+#define I_CNDMASKI(d) "v_cndmask_b32 " d ", %9, %8, vcc\n"
+#define I_BFI(d)      "v_bfi_b32 " d ", %8, %9, " d "\n"
+#define I_AND(d)      "v_and_b32 " d ", %8, " d "\n"
+#define I_OR(d)       "v_or_b32 " d ", %8, " d "\n"
+#define I_LSHL(d)     "v_lshlrev_b32 " d ", 3, " d "\n"
+#define I_LSHR(d)     "v_lshrrev_b32 " d ", 3, " d "\n"
+#define I_SUB(d)      "v_sub_u32 " d ", %8, " d "\n"
+#define I_MOV(d)      "v_mov_b32 " d ", %8\n"
+#define I_XAD(d)      "v_xad_u32 " d ", " d ", %8, %9\n"
+#define I_ADDLSHL(d)  "v_add_lshl_u32 " d ", " d ", %8, 1\n"
+#define I_LSHLOR(d)   "v_lshl_or_b32 " d ", " d ", 3, %8\n"
 
 KERNEL32(k_add, I_ADD)
 KERNEL32(k_xor, I_XOR)
@@ -105,6 +117,18 @@ KERNEL32(k_addco, I_ADDCO)
 KERNEL32(k_addc, I_ADDC)
 KERNEL32(k_fmaf32, I_FMAF32)
 KERNEL32(k_cndmask, I_CNDMASK)
+KERNEL32(k_cndmask64, I_CNDMASK64)
+KERNEL32(k_cndmaski, I_CNDMASKI)
+KERNEL32(k_bfi, I_BFI)
+KERNEL32(k_and, I_AND)
+KERNEL32(k_or, I_OR)
+KERNEL32(k_lshl, I_LSHL)
+KERNEL32(k_lshr, I_LSHR)
+KERNEL32(k_sub, I_SUB)
+KERNEL32(k_mov, I_MOV)
+KERNEL32(k_xad, I_XAD)
+KERNEL32(k_addlshl, I_ADDLSHL)
+KERNEL32(k_lshlor, I_LSHLOR)
 
 // ---- 64-bit destination ops (operands: %8 = vx, %9 = vy (32-bit), %10 = wx, %11 = wy (64-bit))
 #define I_MAD64(d)     "v_mad_u64_u32 " d ", vcc, %8, %9, " d "\n"
@@ -166,7 +190,11 @@ int main() {
   Entry es[] = {
     {"v_add_u32", k_add, 32}, {"v_xor_b32", k_xor, 32}, {"v_add3_u32", k_add3, 32},
     {"v_lshl_add_u32", k_lshladd, 32}, {"v_and_or_b32", k_andor, 32}, {"v_alignbit_b32", k_alignbit, 32},
-    {"v_bfe_u32", k_bfe, 32}, {"v_perm_b32", k_perm, 32}, {"v_cndmask_b32", k_cndmask, 32},
+    {"v_bfe_u32", k_bfe, 32}, {"v_perm_b32", k_perm, 32}, {"v_cndmask_b32(vcc,dep)", k_cndmask, 32},
+    {"v_cndmask_b32_e64(sgpr)", k_cndmask64, 32}, {"v_cndmask_b32(vcc,indep)", k_cndmaski, 32},
+    {"v_bfi_b32", k_bfi, 32}, {"v_and_b32", k_and, 32}, {"v_or_b32", k_or, 32}, {"v_lshlrev_b32", k_lshl, 32},
+    {"v_lshrrev_b32", k_lshr, 32}, {"v_sub_u32", k_sub, 32}, {"v_mov_b32", k_mov, 32}, {"v_xad_u32", k_xad, 32},
+    {"v_add_lshl_u32", k_addlshl, 32}, {"v_lshl_or_b32", k_lshlor, 32},
     {"v_add_co_u32", k_addco, 32}, {"v_addc_co_u32", k_addc, 32},
     {"v_mul_lo_u32", k_mullo, 32}, {"v_mul_hi_u32", k_mulhi, 32},
     {"v_mul_u32_u24", k_mulu24, 32}, {"v_mul_hi_u32_u24", k_mulhiu24, 32},
