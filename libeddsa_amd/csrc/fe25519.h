@@ -30,6 +30,7 @@ namespace ed { void bound_violation(const char* file, int line, const char* what
 #define ED_CHECK(cond) do { if (!(cond)) ::ed::bound_violation(__FILE__, __LINE__, #cond); } while (0)
 #define ED_CONSTANT_MEM static const
 #define ED_ASSUME(cond) ((void)0)
+namespace ed { static const uint64_t ed_opaque_zero = 0; }
 #else
 #include <hip/hip_runtime.h>
 #define ED_DEV __device__ __forceinline__
@@ -44,6 +45,13 @@ namespace ed { void bound_violation(const char* file, int line, const char* what
 
 namespace ed {
 
+#ifndef ED_HOST_CHECK
+// Always 0 (nothing ever stores to it), but externally visible, so the compiler cannot fold it.
+// mad() below states its no-wrap fact through it: a plain `r >= c` is PROVABLE from the known
+// bits of masked limbs, InstCombine then deletes the assumption and the protection is gone.
+inline __device__ uint64_t ed_opaque_zero;
+#endif
+
 struct fe { uint32_t v[10]; };
 
 constexpr uint32_t M26 = (1u << 26) - 1;
@@ -53,14 +61,14 @@ ED_DEV constexpr int limb_bits(int i) { return (i & 1) ? 25 : 26; }
 ED_DEV constexpr uint32_t limb_mask(int i) { return (i & 1) ? M25 : M26; }
 
 // One multiply-accumulate of a product column: v_mad_u64_u32.  The assumption (true: the limb
-// bounds keep every column below 2^64, so the sum never wraps) gives each partial sum a second
-// use in the IR, which stops LLVM's reassociation from moving the carry-in to the END of the
+// bounds keep every column below 2^64, so the sum never wraps; ed_opaque_zero is 0) gives each
+// partial sum a second use in the IR, which stops LLVM's reassociation from moving the carry-in to the END of the
 // chain -- there it costs a v_mul plus a 64-bit add per column instead of being the free initial
 // addend.  It emits no code and, unlike an asm barrier, does not pin the instruction order.
 ED_DEV uint64_t mad(uint32_t a, uint32_t b, uint64_t c) {
   const uint64_t r = (uint64_t)a * b + c;
   ED_CHECK(r >= c);                              // the column sum did not wrap
-  ED_ASSUME(r >= c);
+  ED_ASSUME((r ^ ed_opaque_zero) >= (c ^ ed_opaque_zero));
   return r;
 }
 
