@@ -54,10 +54,10 @@ EDDSA_AMD_DECL int eddsa_amd_init(int device);
 EDDSA_AMD_DECL void eddsa_amd_shutdown(void);
 /* human-readable text for a negative return value */
 EDDSA_AMD_DECL const char *eddsa_amd_strerror(int err);
-/* copy the device's generated tables out for inspection: base8 = 129 entries k*B, comb = 256
+/* copy the device's generated tables out for inspection: base16 = 32769 entries k*B, comb = 256
  * entries (k+1)*256^i*B in the order of the reference's ed_lookup[i][k]; each entry 32 words:
  * 10 radix-2^25.5 limbs of y-x, y+x, 2dxy, then 2 words of padding. */
-EDDSA_AMD_DECL int eddsa_amd_dump_tables(uint32_t *base8_words, uint32_t *comb_words);
+EDDSA_AMD_DECL int eddsa_amd_dump_tables(uint32_t *base16_words, uint32_t *comb_words);
 
 /* measurement aid: when on, HIP events are recorded on the launch stream around the three kernels
  * of every verify pass (up to 256 passes); eddsa_amd_verify_phase_ms() waits for them and returns

@@ -25,7 +25,7 @@
 struct engine {
     int ready;
     int device;
-    uint32_t *base8, *comb;           /* generated base-point tables (HBM) */
+    uint32_t *base16, *comb;           /* generated base-point tables (HBM) */
     edk_verify_ws ws;                 /* verify workspace, grown on demand up to CHUNK_MAX items */
     hipEvent_t ws_free;               /* recorded after the last kernel that touches ws */
     int profiling;                    /* record marks around the three verify kernels */
@@ -81,18 +81,18 @@ int eddsa_amd_init(int device)
     if (g_eng.ready && g_eng.device == device) goto out;
     if (g_eng.ready) {                /* re-bind to another device */
         ws_release(&g_eng);
-        (void)hipFree(g_eng.base8); (void)hipFree(g_eng.comb); (void)hipEventDestroy(g_eng.ws_free);
+        (void)hipFree(g_eng.base16); (void)hipFree(g_eng.comb); (void)hipEventDestroy(g_eng.ws_free);
         memset(&g_eng, 0, sizeof(g_eng));
     }
     TRY(hipSetDevice(device));
     TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { rc = -100000; goto out; }
-    TRY(hipMalloc((void **)&g_eng.base8, TABLE_BASE8_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&g_eng.base16, (size_t)TABLE_BASE16_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&g_eng.comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t)));
     TRY(hipEventCreateWithFlags(&g_eng.ws_free, hipEventDisableTiming));
     for (int s = 0; s < MARK_SLOTS; s++)
         for (int i = 0; i < 4; i++) TRY(hipEventCreate(&g_eng.marks[s][i]));
-    TRY(edk_init_tables(g_eng.base8, g_eng.comb, NULL));
+    TRY(edk_init_tables(g_eng.base16, g_eng.comb, NULL));
     TRY(hipEventRecord(g_eng.ws_free, NULL));
     TRY(hipDeviceSynchronize());
     g_eng.device = device;
@@ -108,7 +108,7 @@ void eddsa_amd_shutdown(void)
     if (g_eng.ready) {
         (void)hipDeviceSynchronize();
         ws_release(&g_eng);
-        (void)hipFree(g_eng.base8); (void)hipFree(g_eng.comb); (void)hipEventDestroy(g_eng.ws_free);
+        (void)hipFree(g_eng.base16); (void)hipFree(g_eng.comb); (void)hipEventDestroy(g_eng.ws_free);
         memset(&g_eng, 0, sizeof(g_eng));
     }
     pthread_mutex_unlock(&g_lock);
@@ -123,11 +123,11 @@ static int ensure_init(void)
     return eddsa_amd_init(dev);
 }
 
-int eddsa_amd_dump_tables(uint32_t *base8_words, uint32_t *comb_words)
+int eddsa_amd_dump_tables(uint32_t *base16_words, uint32_t *comb_words)
 {
     int rc = ensure_init();
     if (rc) return rc;
-    TRY(hipMemcpy(base8_words, g_eng.base8, TABLE_BASE8_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    TRY(hipMemcpy(base16_words, g_eng.base16, (size_t)TABLE_BASE16_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
     TRY(hipMemcpy(comb_words, g_eng.comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
 out:
     return rc;
@@ -183,7 +183,7 @@ int ed25519_verify_batch_dev(uint8_t *ok, const uint8_t *sigs, const uint8_t *pu
         if (msg_off) op = msg_off + done; else mp = msgs + done * msg_len;
         hipEvent_t *marks = NULL;
         if (g_eng.profiling && g_eng.marks_used < MARK_SLOTS) marks = g_eng.marks[g_eng.marks_used++];
-        TRY(edk_verify(ok + done, sigs + 64 * done, pubs + 32 * done, mp, op, msg_len, m, g_eng.base8,
+        TRY(edk_verify(ok + done, sigs + 64 * done, pubs + 32 * done, mp, op, msg_len, m, g_eng.base16,
                        &g_eng.ws, marks, st));
     }
     TRY(hipEventRecord(g_eng.ws_free, st));

@@ -5,8 +5,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#ifndef TABLE_BASE8_ENTRIES       /* also defined, identically, by lanes.h for the device side */
-#define TABLE_BASE8_ENTRIES 129   /* k*B, k = 0..128 */
+#ifndef TABLE_BASE16_ENTRIES      /* also defined, identically, by lanes.h for the device side */
+#define TABLE_BASE16_ENTRIES 32769 /* k*B, k = 0..32768 */
 #define TABLE_COMB_ENTRIES 256    /* (k+1)*256^i*B, i < 32, k < 8: ed.c:41-43 ed_lookup */
 #define TABLE_ENTRY_WORDS 32      /* 3 x 10 limbs + 2 padding words */
 #define VERIFY_TABLE_ENTRIES 9    /* 0..8 times -A, cached form */
@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-hipError_t edk_init_tables(uint32_t* base8, uint32_t* comb, hipStream_t stream);
+hipError_t edk_init_tables(uint32_t* base16, uint32_t* comb, hipStream_t stream);
 hipError_t edk_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* points, size_t n,
                       hipStream_t stream);
 /* verify workspace for up to `capacity` items (a multiple of VERIFY_TILE), all in HBM */
@@ -32,7 +32,7 @@ typedef struct edk_verify_ws {
 } edk_verify_ws;
 
 hipError_t edk_verify(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs,
-                      const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* base8,
+                      const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* base16,
                       const edk_verify_ws* ws, hipEvent_t* marks /* 4 events or NULL */,
                       hipStream_t stream);
 

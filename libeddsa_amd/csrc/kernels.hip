@@ -64,7 +64,7 @@ ED_DEV void stage_table(uint32_t* lds, const uint32_t* src, int words) {
 
 // ---------------------------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(BLOCK, 2)
+__global__ void __launch_bounds__(BLOCK, 4)
 k_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* points, size_t n) {
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
@@ -75,13 +75,13 @@ k_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* points, size_t n) 
   store32(out, i, 32, r);
 }
 
-__global__ void __launch_bounds__(64) k_init_tables(uint32_t* base8, uint32_t* comb) {
+__global__ void __launch_bounds__(64) k_init_tables(uint32_t* base16, uint32_t* comb) {
   const int id = blockIdx.x * 64 + threadIdx.x;
-  if (id >= TABLE_BASE8_ENTRIES + TABLE_COMB_ENTRIES) return;
-  if (id < TABLE_BASE8_ENTRIES) {
-    table_entry_lane(base8 + TABLE_ENTRY_WORDS * id, (uint32_t)id, 0);
+  if (id >= TABLE_BASE16_ENTRIES + TABLE_COMB_ENTRIES) return;
+  if (id < TABLE_BASE16_ENTRIES) {
+    table_entry_lane(base16 + (size_t)TABLE_ENTRY_WORDS * id, (uint32_t)id, 0);
   } else {
-    const int c = id - TABLE_BASE8_ENTRIES;       // comb[i][k], c = 8 i + k
+    const int c = id - TABLE_BASE16_ENTRIES;      // comb[i][k], c = 8 i + k
     table_entry_lane(comb + TABLE_ENTRY_WORDS * c, (uint32_t)(c & 7) + 1, 8u * (uint32_t)(c >> 3));
   }
 }
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(64) k_init_tables(uint32_t* base8, uint32_t* c
 // Ed25519 verify.  Three kernels per chunk, so that each stays inside its register budget and its
 // own I-cache footprint (one fused kernel spilled 4.5 KB/lane):
 //   k_verify_prepare  hash, scalars -> digit words, decompress -A, table of 0..8 * -A
-//   k_verify_main     the 252 doublings + 96 additions            (~85 % of the time)
+//   k_verify_main     the 252 doublings + 80 additions            (~85 % of the time)
 //   k_verify_finish   invert Z (shared by 8 items per lane), encode, compare with R
 // Workspace (HBM; tile = 256 items):
 //   digits [item][16]                  t + 0x88.., S + 0x80.. as little-endian words
@@ -119,11 +119,8 @@ k_verify_prepare(const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs,
   flags[i] = (uint8_t)oncurve;
 }
 
-__global__ void __launch_bounds__(BLOCK, 2)
-k_verify_main(const uint32_t* digits, const uint32_t* table, const uint32_t* base8, uint32_t* accout) {
-  __shared__ uint32_t lds_base[TABLE_BASE8_ENTRIES * TABLE_ENTRY_WORDS];
-  stage_table(lds_base, base8, TABLE_BASE8_ENTRIES * TABLE_ENTRY_WORDS);
-
+__global__ void __launch_bounds__(BLOCK, 4)
+k_verify_main(const uint32_t* digits, const uint32_t* table, const uint32_t* base16, uint32_t* accout) {
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;   // < workspace capacity
   uint32_t tw[8], sw[8];
   {
@@ -133,7 +130,7 @@ k_verify_main(const uint32_t* digits, const uint32_t* table, const uint32_t* bas
     sw[0] = c.x; sw[1] = c.y; sw[2] = c.z; sw[3] = c.w; sw[4] = e.x; sw[5] = e.y; sw[6] = e.z; sw[7] = e.w;
   }
   ge acc;
-  verify_main_lane(acc, tw, sw, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), lds_base);
+  verify_main_lane(acc, tw, sw, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16);
   uint32_t* o = accout + (size_t)blockIdx.x * (30 * BLOCK) + threadIdx.x;
 #pragma unroll
   for (int j = 0; j < 10; j++) {
@@ -214,7 +211,7 @@ k_verify_finish(uint8_t* ok, const uint8_t* sigs, const uint32_t* accin, const u
 
 __global__ void __launch_bounds__(BLOCK, 2)
 k_genpub(uint8_t* pubs, const uint8_t* secs, size_t n, const uint32_t* comb) {
-  __shared__ uint32_t lds_comb[TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS];
+  __shared__ alignas(16) uint32_t lds_comb[TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS];
   stage_table(lds_comb, comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS);
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const size_t item = i < n ? i : n - 1;
@@ -227,7 +224,7 @@ k_genpub(uint8_t* pubs, const uint8_t* secs, size_t n, const uint32_t* comb) {
 __global__ void __launch_bounds__(BLOCK, 2)
 k_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, const uint8_t* msgs,
        const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* comb) {
-  __shared__ uint32_t lds_comb[TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS];
+  __shared__ alignas(16) uint32_t lds_comb[TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS];
   stage_table(lds_comb, comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS);
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const size_t item = i < n ? i : n - 1;
@@ -242,7 +239,7 @@ k_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, const uint8_t* m
 
 __global__ void __launch_bounds__(BLOCK, 2)
 k_x25519_base(uint8_t* out, const uint8_t* scalars, size_t n, const uint32_t* comb) {
-  __shared__ uint32_t lds_comb[TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS];
+  __shared__ alignas(16) uint32_t lds_comb[TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS];
   stage_table(lds_comb, comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS);
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const size_t item = i < n ? i : n - 1;
@@ -282,9 +279,9 @@ using namespace ed;
 
 extern "C" {
 
-hipError_t edk_init_tables(uint32_t* base8, uint32_t* comb, hipStream_t stream) {
-  const int total = TABLE_BASE8_ENTRIES + TABLE_COMB_ENTRIES;
-  hipLaunchKernelGGL(k_init_tables, dim3((total + 63) / 64), dim3(64), 0, stream, base8, comb);
+hipError_t edk_init_tables(uint32_t* base16, uint32_t* comb, hipStream_t stream) {
+  const int total = TABLE_BASE16_ENTRIES + TABLE_COMB_ENTRIES;
+  hipLaunchKernelGGL(k_init_tables, dim3((total + 63) / 64), dim3(64), 0, stream, base16, comb);
   return hipGetLastError();
 }
 
@@ -297,7 +294,7 @@ hipError_t edk_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* point
 }
 
 hipError_t edk_verify(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs,
-                      const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* base8,
+                      const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* base16,
                       const edk_verify_ws* ws, hipEvent_t* marks, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   const unsigned blocks = (unsigned)((n + BLOCK - 1) / BLOCK);
@@ -305,7 +302,7 @@ hipError_t edk_verify(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, con
   hipLaunchKernelGGL(k_verify_prepare, dim3(blocks), dim3(BLOCK), 0, stream, sigs, pubs, msgs, msg_off,
                      msg_len, n, ws->digits, ws->table, ws->flags);
   if (marks) (void)hipEventRecord(marks[1], stream);
-  hipLaunchKernelGGL(k_verify_main, dim3(blocks), dim3(BLOCK), 0, stream, ws->digits, ws->table, base8,
+  hipLaunchKernelGGL(k_verify_main, dim3(blocks), dim3(BLOCK), 0, stream, ws->digits, ws->table, base16,
                      ws->acc);
   if (marks) (void)hipEventRecord(marks[2], stream);
   hipLaunchKernelGGL(k_verify_finish, dim3((blocks + FINISH_K - 1) / FINISH_K), dim3(BLOCK), 0, stream, ok, sigs,

@@ -18,7 +18,7 @@
 #include "sc25519.h"
 #include "sha512.h"
 
-#define TABLE_BASE8_ENTRIES 129   /* k*B, k = 0..128 */
+#define TABLE_BASE16_ENTRIES 32769 /* k*B, k = 0..32768: 16-bit signed windows of S (4 MiB, L2/MALL) */
 #define TABLE_COMB_ENTRIES 256    /* (k+1)*256^i*B, i < 32, k < 8: ed.c:41-43 ed_lookup */
 #define TABLE_ENTRY_WORDS 32      /* 3 x 10 limbs + 2 padding words */
 #define VERIFY_TABLE_ENTRIES 9    /* 0..8 times -A, cached form */
@@ -28,7 +28,7 @@ namespace ed {
 
 struct alignas(16) word4 { uint32_t x, y, z, w; };   // one 16-byte load / store
 
-// 256-bit little-endian value << s (s = 1, 4 or 8): the scalar is consumed from the top
+// 256-bit little-endian value << s (s = 1, 4 or 16): the scalar is consumed from the top
 template <int S>
 ED_DEV void shl256(uint32_t w[8]) {
 #pragma unroll
@@ -94,7 +94,7 @@ ED_DEV void x25519_lane(uint32_t out[8], uint32_t s[8], const uint32_t pt[8]) {
 // base-point tables (what the reference ships as generated data, lib/ed_lookup64.h)
 // ---------------------------------------------------------------------------------------------
 // Entry = 32 words: y-x | y+x | 2dxy (10 canonical limbs each) + 2 words of padding.
-//   base8[k],  k = 0..128 : k * B                  (8-bit signed windows of S in verify)
+//   base16[k], k = 0..32768 : k * B                (16-bit signed windows of S in verify)
 //   comb[i][k], i < 32, k < 8 : (k+1) * 256^i * B  (ed.c:41-43 ed_lookup, sign/genpub/x25519_base)
 
 ED_DEV void niels_store(uint32_t* dst, const ge_niels& n) {
@@ -103,9 +103,17 @@ ED_DEV void niels_store(uint32_t* dst, const ge_niels& n) {
   dst[30] = 0; dst[31] = 0;
 }
 
+// entries are 128 bytes, 128-byte aligned: eight 16-byte loads (one cache line)
 ED_DEV void niels_load(ge_niels& n, const uint32_t* src) {
+  const word4* p = reinterpret_cast<const word4*>(src);
+  uint32_t w[32];
 #pragma unroll
-  for (int j = 0; j < 10; j++) { n.ymx.v[j] = src[j]; n.ypx.v[j] = src[10 + j]; n.t2d.v[j] = src[20 + j]; }
+  for (int q = 0; q < 8; q++) {
+    const word4 v = p[q];
+    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+  }
+#pragma unroll
+  for (int j = 0; j < 10; j++) { n.ymx.v[j] = w[j]; n.ypx.v[j] = w[10 + j]; n.t2d.v[j] = w[20 + j]; }
 }
 
 // dst = affine niels form of mult * 2^shift * B
@@ -115,7 +123,7 @@ ED_DEV void table_entry_lane(uint32_t* dst, uint32_t mult, uint32_t shift) {
   ge_base(b);
   ge_to_cached(bc, b);
   ge_neutral(acc);
-  for (int bit = 7; bit >= 0; bit--) {           // acc = mult * B, mult < 256
+  for (int bit = 15; bit >= 0; bit--) {          // acc = mult * B, mult < 65536
     ge_dbl(acc, acc, true);
     if ((mult >> bit) & 1) ge_add_cached(acc, acc, bc, true);
   }
@@ -129,9 +137,10 @@ ED_DEV void table_entry_lane(uint32_t* dst, uint32_t mult, uint32_t shift) {
 // Ed25519 verify: ed25519-sha512.c:148-181
 // ---------------------------------------------------------------------------------------------
 // C = S*B + t*(-A) is evaluated as ONE left-to-right pass over 64 four-bit windows:
-//     acc = 16*acc + d_i*(-A)  [+ e_j*B when i = 2j]
+//     acc = 16*acc + d_i*(-A)  [+ e_j*B when i = 4j]
 // with d_i in [-8,7] (ed.c:407-409's x + 0x88..8 recoding) looked up in a per-item table of
-// 0..8 times -A, and e_j in [-128,127] looked up in a 129-entry table of multiples of B.
+// 0..8 times -A, and e_j in [-32768,32767] (one every four windows, i = 4j) looked up in a
+// 32769-entry table of multiples of B (4 MiB, shared by all lanes, L2 / Infinity-Cache resident).
 // Control flow is uniform; the reference's 9-way data-dependent branch (ed.c:480-501) would
 // serialise all 64 lanes of a wave.  Equality of the result with the reference's:
 // DESIGN.md "Why the windowed evaluation is bit-exact".
@@ -179,7 +188,7 @@ ED_DEV bool verify_prepare_lane(uint32_t tw[8], uint32_t sw[8], uint32_t* tab, c
     sc_to_words(tw, t);
     sc_to_words(sw, s);
     words_add_pattern(tw, 0x88888888u);          // nibble - 8 is the signed digit
-    words_add_pattern(sw, 0x80808080u);          // byte - 128 is the signed digit
+    words_add_pattern(sw, 0x80008000u);          // halfword - 32768 is the signed digit
   }
   // -A and its multiples 0..8, cached form
   bool oncurve;
@@ -206,9 +215,9 @@ ED_DEV bool verify_prepare_lane(uint32_t tw[8], uint32_t sw[8], uint32_t* tab, c
   return oncurve;
 }
 
-// tw, sw: digit words (consumed); tab: this item's table; base8: the k*B table (LDS on the device)
+// tw, sw: digit words (consumed); tab: this item's table; base16: the k*B table
 ED_DEV void verify_main_lane(ge& acc, uint32_t tw[8], uint32_t sw[8], const uint32_t* tab,
-                             const uint32_t* base8) {
+                             const uint32_t* base16) {
   ge_neutral(acc);
 #pragma unroll 1
   for (int w = 63; w >= 0; w--) {
@@ -223,14 +232,14 @@ ED_DEV void verify_main_lane(ge& acc, uint32_t tw[8], uint32_t sw[8], const uint
       ge_cached c;
       cached_load(c, tab, mag);
       ge_cached_cneg(c, dig < 0);
-      ge_add_cached(acc, acc, c, (w & 1) == 0);
+      ge_add_cached(acc, acc, c, (w & 3) == 0);
     }
-    if ((w & 1) == 0) {
-      const int dig = (int)(sw[7] >> 24) - 128;
-      shl256<8>(sw);
+    if ((w & 3) == 0) {
+      const int dig = (int)(sw[7] >> 16) - 32768;
+      shl256<16>(sw);
       const uint32_t mag = (uint32_t)(dig < 0 ? -dig : dig);
       ge_niels nb;
-      niels_load(nb, base8 + TABLE_ENTRY_WORDS * mag);
+      niels_load(nb, base16 + TABLE_ENTRY_WORDS * mag);
       ge_niels_cneg(nb, dig < 0);
       ge_add_niels(acc, acc, nb, false);
     }

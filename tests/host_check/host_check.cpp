@@ -30,14 +30,16 @@ static void rd(uint32_t w[8], const uint8_t* p) { memcpy(w, p, 32); }      // li
 static void wr(uint8_t* p, const uint32_t w[8]) { memcpy(p, w, 32); }
 
 struct Tables {
-  std::vector<uint32_t> base8, comb;
-  Tables() : base8(TABLE_BASE8_ENTRIES * TABLE_ENTRY_WORDS), comb(TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS) {
-    for (int k = 0; k < TABLE_BASE8_ENTRIES; k++) table_entry_lane(&base8[TABLE_ENTRY_WORDS * k], (uint32_t)k, 0);
+  // 16-byte aligned view of the base table (entries are read with 16-byte loads)
+  uint32_t* b16() { return reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(base16.data()) + 15) & ~(uintptr_t)15); }
+  std::vector<uint32_t> base16, comb;
+  Tables() : base16((size_t)TABLE_BASE16_ENTRIES * TABLE_ENTRY_WORDS + 32), comb(TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS) {
+    for (int k = 0; k < TABLE_BASE16_ENTRIES; k++) table_entry_lane(b16() + (size_t)TABLE_ENTRY_WORDS * k, (uint32_t)k, 0);
     for (int c = 0; c < TABLE_COMB_ENTRIES; c++)
       table_entry_lane(&comb[TABLE_ENTRY_WORDS * c], (uint32_t)(c & 7) + 1, 8u * (uint32_t)(c >> 3));
   }
 };
-static const Tables& tables() { static Tables t; return t; }
+static Tables& tables() { static Tables t; return t; }
 
 extern "C" {
 
@@ -45,8 +47,8 @@ long hc_violations(void) { return g_violations.load(); }
 const char* hc_first_violation(void) { return g_first; }
 void hc_reset(void) { g_violations = 0; g_first[0] = 0; }
 
-void hc_tables(uint32_t* base8, uint32_t* comb) {
-  memcpy(base8, tables().base8.data(), tables().base8.size() * 4);
+void hc_tables(uint32_t* base16, uint32_t* comb) {
+  memcpy(base16, tables().b16(), (size_t)TABLE_BASE16_ENTRIES * TABLE_ENTRY_WORDS * 4);
   memcpy(comb, tables().comb.data(), tables().comb.size() * 4);
 }
 
@@ -65,7 +67,7 @@ int hc_verify(const uint8_t sig[64], const uint8_t pub[32], const uint8_t* msg, 
   rd(rw, sig); rd(sw, sig + 32); rd(aw, pub);
   const bool oncurve = verify_prepare_lane(tw, sw, tab, rw, aw, msg, len);
   ge acc;
-  verify_main_lane(acc, tw, sw, tab, tables().base8.data());
+  verify_main_lane(acc, tw, sw, tab, tables().b16());
   if (!oncurve || fe_iszero(acc.Z)) return 0;
   fe zinv;
   fe_inv(zinv, acc.Z);

@@ -131,9 +131,9 @@ def test_random_against_oracle(hostcheck, oracle):
     no_violations(hostcheck)
 
 
-def test_tables_match_the_reference_points(hostcheck, golden):
-    base8 = np.zeros((129, 32), np.uint32); comb = np.zeros((256, 32), np.uint32)
-    hostcheck.hc_tables(base8.ctypes.data_as(ctypes.c_void_p), comb.ctypes.data_as(ctypes.c_void_p))
+def test_tables_match_the_reference_points(hostcheck, oracle, golden):
+    base16 = np.zeros((32769, 32), np.uint32); comb = np.zeros((256, 32), np.uint32)
+    hostcheck.hc_tables(base16.ctypes.data_as(ctypes.c_void_p), comb.ctypes.data_as(ctypes.c_void_p))
     pos = [0, 26, 51, 77, 102, 128, 153, 179, 204, 230]
     val = lambda limbs: sum(int(v) << s for v, s in zip(limbs, pos))  # noqa: E731
     inv2 = pow(2, P - 2, P)
@@ -142,6 +142,12 @@ def test_tables_match_the_reference_points(hostcheck, golden):
         ymx, ypx = val(comb[e][0:10]), val(comb[e][10:20])
         y, x = (ypx + ymx) * inv2 % P, (ypx - ymx) * inv2 % P
         assert (y | (x & 1) << 255).to_bytes(32, "little") == pts[32 * e:32 * e + 32], e
+    out = ctypes.create_string_buffer(32)
+    for k in list(range(1, 32769, 331)) + [32767, 32768]:
+        ymx, ypx = val(base16[k][0:10]), val(base16[k][10:20])
+        y, x = (ypx + ymx) * inv2 % P, (ypx - ymx) * inv2 % P
+        oracle.lib.orc_ed_scale_base(out, int(k).to_bytes(32, "little"))
+        assert (y | (x & 1) << 255).to_bytes(32, "little") == out.raw, k
     no_violations(hostcheck)
 
 

@@ -87,11 +87,11 @@ def test_layer_kats_through_the_abi(engine, golden):
     assert engine.x25519_base(H(a)) == H(r)
 
 
-def test_device_tables_equal_the_reference_table(engine, golden):
+def test_device_tables_equal_the_reference_table(engine, oracle, golden):
     """the comb table generated on the device == the points of the reference's lib/ed_lookup64.h"""
     import ctypes
-    base8 = np.zeros((129, 32), np.uint32); comb = np.zeros((256, 32), np.uint32)
-    rc = engine.library().eddsa_amd_dump_tables(base8.ctypes.data_as(ctypes.c_void_p), comb.ctypes.data_as(ctypes.c_void_p))
+    base16 = np.zeros((32769, 32), np.uint32); comb = np.zeros((256, 32), np.uint32)
+    rc = engine.library().eddsa_amd_dump_tables(base16.ctypes.data_as(ctypes.c_void_p), comb.ctypes.data_as(ctypes.c_void_p))
     assert rc == 0
     pos = [0, 26, 51, 77, 102, 128, 153, 179, 204, 230]
 
@@ -109,9 +109,13 @@ def test_device_tables_equal_the_reference_table(engine, golden):
     pts = golden("comb_points.bin")
     for e in range(256):
         assert enc(comb[e]) == pts[32 * e:32 * e + 32], e
-    for k in range(1, 9):                                  # base8[k] = k*B = comb row 0
-        assert enc(base8[k]) == pts[32 * (k - 1):32 * k]
-    assert val(base8[0][0:10]) == 1 and val(base8[0][10:20]) == 1 and val(base8[0][20:30]) == 0
+    for k in range(1, 9):                                  # base16[k] = k*B = comb row 0
+        assert enc(base16[k]) == pts[32 * (k - 1):32 * k]
+    assert val(base16[0][0:10]) == 1 and val(base16[0][10:20]) == 1 and val(base16[0][20:30]) == 0
+    out = ctypes.create_string_buffer(32)                  # every 97th entry and the last against the oracle's k*B
+    for k in list(range(9, 32769, 97)) + [256, 32767, 32768]:
+        oracle.lib.orc_ed_scale_base(out, int(k).to_bytes(32, "little"))
+        assert enc(base16[k]) == out.raw, k
 
 
 # ---------------------------------------------------------------- seeded random batches vs the oracle
