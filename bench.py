@@ -75,9 +75,10 @@ def pmc_traffic(kernel):
     None when no profile has been committed."""
     path = os.path.join(ROOT, "profiles", "pmc_summary.json")
     try:
-        k = json.load(open(path))["ed::" + kernel]
-        return {"bytes": (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0,
-                "fetch_size_kb_raw": k["FETCH_SIZE"], "write_size_kb_raw": k["WRITE_SIZE"],
+        prof = json.load(open(path))
+        ks = [prof["ed::" + name.strip()] for name in kernel.split("+")]
+        fetch, write = sum(k["FETCH_SIZE"] for k in ks), sum(k["WRITE_SIZE"] for k in ks)
+        return {"bytes": (2.0 * fetch + write) * 1024.0, "fetch_size_kb_raw": fetch, "write_size_kb_raw": write,
                 "source": "profiles/pmc_summary.json (rocprofv3 --pmc, separate passes)"}
     except (OSError, KeyError, ValueError):
         return None
@@ -225,7 +226,7 @@ def main():
             kernel, k_ms, k_mul32 = "k_verify_main", phases[1], MUL32_VERIFY_MAIN
         else:
             k_ms = sum(a.elapsed_time(b) for a, b in marks) / len(marks)      # HIP events, launch stream
-            kernel, k_mul32 = {"x25519": "k_x25519", "sign": "k_sign"}[op], mul32
+            kernel, k_mul32 = {"x25519": "k_x25519", "sign": "k_sign_point + k_sign_finish"}[op], mul32
         achieved = n * k_mul32 / (k_ms * 1e-3) / 1e12
         roofline = {
             "bound": "valu", "kernel": kernel, "achieved": achieved, "peak": PEAK_TMUL32,

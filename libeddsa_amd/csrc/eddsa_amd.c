@@ -27,7 +27,8 @@ struct engine {
     int device;
     uint32_t *base16, *comb;           /* generated base-point tables (HBM) */
     edk_verify_ws ws;                 /* verify workspace, grown on demand up to CHUNK_MAX items */
-    hipEvent_t ws_free;               /* recorded after the last kernel that touches ws */
+    edk_fixed_ws fws;                 /* sign / genpub / x25519_base workspace, same policy */
+    hipEvent_t ws_free;               /* recorded after the last kernel that touches ws or fws */
     int profiling;                    /* record marks around the three verify kernels */
     int marks_used;                   /* passes recorded since profiling was switched on */
     hipEvent_t marks[MARK_SLOTS][4];
@@ -54,11 +55,36 @@ static void ws_release(struct engine *e)
     memset(&e->ws, 0, sizeof(e->ws));
 }
 
+static void fws_release(struct engine *e)
+{
+    if (e->fws.acc) (void)hipFree(e->fws.acc);
+    if (e->fws.aux) (void)hipFree(e->fws.aux);
+    memset(&e->fws, 0, sizeof(e->fws));
+}
+
+/* caller holds g_lock */
+static int fws_reserve(struct engine *e, size_t items)
+{
+    int rc = 0;
+    size_t cap = (items + VERIFY_TILE - 1) / VERIFY_TILE * VERIFY_TILE;
+    cap = (cap + 8 * VERIFY_TILE - 1) / (8 * VERIFY_TILE) * (8 * VERIFY_TILE);   /* whole finish blocks */
+    if (cap <= e->fws.capacity) return 0;
+    TRY(hipEventSynchronize(e->ws_free));
+    fws_release(e);
+    TRY(hipMalloc((void **)&e->fws.acc, cap * 30 * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&e->fws.aux, cap * 16 * sizeof(uint32_t)));
+    e->fws.capacity = cap;
+out:
+    if (rc) fws_release(e);
+    return rc;
+}
+
 /* caller holds g_lock */
 static int ws_reserve(struct engine *e, size_t items)
 {
     int rc = 0;
     size_t cap = (items + VERIFY_TILE - 1) / VERIFY_TILE * VERIFY_TILE;
+    cap = (cap + 8 * VERIFY_TILE - 1) / (8 * VERIFY_TILE) * (8 * VERIFY_TILE);   /* whole finish blocks */
     if (cap <= e->ws.capacity) return 0;
     /* the old buffers may still be in use by enqueued kernels */
     TRY(hipEventSynchronize(e->ws_free));
@@ -80,7 +106,7 @@ int eddsa_amd_init(int device)
     pthread_mutex_lock(&g_lock);
     if (g_eng.ready && g_eng.device == device) goto out;
     if (g_eng.ready) {                /* re-bind to another device */
-        ws_release(&g_eng);
+        ws_release(&g_eng); fws_release(&g_eng);
         (void)hipFree(g_eng.base16); (void)hipFree(g_eng.comb); (void)hipEventDestroy(g_eng.ws_free);
         memset(&g_eng, 0, sizeof(g_eng));
     }
@@ -107,7 +133,7 @@ void eddsa_amd_shutdown(void)
     pthread_mutex_lock(&g_lock);
     if (g_eng.ready) {
         (void)hipDeviceSynchronize();
-        ws_release(&g_eng);
+        ws_release(&g_eng); fws_release(&g_eng);
         (void)hipFree(g_eng.base16); (void)hipFree(g_eng.comb); (void)hipEventDestroy(g_eng.ws_free);
         memset(&g_eng, 0, sizeof(g_eng));
     }
@@ -192,23 +218,56 @@ out:
     return rc;
 }
 
+/* the three fixed-base operations share one driver: chunks of at most CHUNK_MAX items through fws */
+typedef hipError_t (*fixed_step)(size_t done, size_t m, const void *ctx, hipStream_t st);
+
+static int run_fixed(size_t n, fixed_step step, const void *ctx, void *stream)
+{
+    int rc = ensure_init();
+    hipStream_t st = (hipStream_t)stream;
+    if (rc || n == 0) return rc;
+    pthread_mutex_lock(&g_lock);
+    rc = fws_reserve(&g_eng, n < CHUNK_MAX ? n : CHUNK_MAX);
+    if (rc) goto out;
+    TRY(hipStreamWaitEvent(st, g_eng.ws_free, 0));
+    for (size_t done = 0; done < n; done += CHUNK_MAX)
+        TRY(step(done, n - done < CHUNK_MAX ? n - done : CHUNK_MAX, ctx, st));
+    TRY(hipEventRecord(g_eng.ws_free, st));
+out:
+    pthread_mutex_unlock(&g_lock);
+    return rc;
+}
+
+struct sign_ctx { uint8_t *sigs; const uint8_t *secs, *pubs, *msgs; const uint64_t *msg_off; size_t msg_len; };
+
+static hipError_t sign_step(size_t done, size_t m, const void *vctx, hipStream_t st)
+{
+    const struct sign_ctx *c = (const struct sign_ctx *)vctx;
+    const uint8_t *mp = c->msg_off ? c->msgs : c->msgs + done * c->msg_len;
+    const uint64_t *op = c->msg_off ? c->msg_off + done : NULL;
+    return edk_sign(c->sigs + 64 * done, c->secs + 32 * done, c->pubs + 32 * done, mp, op, c->msg_len, m,
+                    g_eng.comb, &g_eng.fws, st);
+}
+
 int ed25519_sign_batch_dev(uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs, const uint8_t *msgs,
                            const uint64_t *msg_off, size_t msg_len, size_t n, void *stream)
 {
-    int rc = ensure_init();
-    if (rc) return rc;
-    TRY(edk_sign(sigs, secs, pubs, msgs, msg_off, msg_len, n, g_eng.comb, (hipStream_t)stream));
-out:
-    return rc;
+    struct sign_ctx c = { sigs, secs, pubs, msgs, msg_off, msg_len };
+    return run_fixed(n, sign_step, &c, stream);
+}
+
+struct io_ctx { uint8_t *out; const uint8_t *in; };
+
+static hipError_t genpub_step(size_t done, size_t m, const void *vctx, hipStream_t st)
+{
+    const struct io_ctx *c = (const struct io_ctx *)vctx;
+    return edk_genpub(c->out + 32 * done, c->in + 32 * done, m, g_eng.comb, &g_eng.fws, st);
 }
 
 int ed25519_genpub_batch_dev(uint8_t *pubs, const uint8_t *secs, size_t n, void *stream)
 {
-    int rc = ensure_init();
-    if (rc) return rc;
-    TRY(edk_genpub(pubs, secs, n, g_eng.comb, (hipStream_t)stream));
-out:
-    return rc;
+    struct io_ctx c = { pubs, secs };
+    return run_fixed(n, genpub_step, &c, stream);
 }
 
 int x25519_batch_dev(uint8_t *out, const uint8_t *scalars, const uint8_t *points, size_t n, void *stream)
@@ -220,13 +279,16 @@ out:
     return rc;
 }
 
+static hipError_t xbase_step(size_t done, size_t m, const void *vctx, hipStream_t st)
+{
+    const struct io_ctx *c = (const struct io_ctx *)vctx;
+    return edk_x25519_base(c->out + 32 * done, c->in + 32 * done, m, g_eng.comb, &g_eng.fws, st);
+}
+
 int x25519_base_batch_dev(uint8_t *out, const uint8_t *scalars, size_t n, void *stream)
 {
-    int rc = ensure_init();
-    if (rc) return rc;
-    TRY(edk_x25519_base(out, scalars, n, g_eng.comb, (hipStream_t)stream));
-out:
-    return rc;
+    struct io_ctx c = { out, scalars };
+    return run_fixed(n, xbase_step, &c, stream);
 }
 
 int pk_ed25519_to_x25519_batch_dev(uint8_t *out, const uint8_t *in, size_t n, void *stream)

@@ -36,12 +36,20 @@ hipError_t edk_verify(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, con
                       const edk_verify_ws* ws, hipEvent_t* marks /* 4 events or NULL */,
                       hipStream_t stream);
 
-hipError_t edk_genpub(uint8_t* pubs, const uint8_t* secs, size_t n, const uint32_t* comb, hipStream_t stream);
+/* workspace of the fixed-base operations for up to `capacity` items (a multiple of VERIFY_TILE) */
+typedef struct edk_fixed_ws {
+  size_t capacity;
+  uint32_t* acc;      /* capacity * 30 words: projective result, lane-interleaved per tile */
+  uint32_t* aux;      /* capacity * 16 words: sign's secret scalars a, r between its two kernels (zeroed after use) */
+} edk_fixed_ws;
+
+hipError_t edk_genpub(uint8_t* pubs, const uint8_t* secs, size_t n, const uint32_t* comb,
+                      const edk_fixed_ws* ws, hipStream_t stream);
 hipError_t edk_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, const uint8_t* msgs,
                     const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* comb,
-                    hipStream_t stream);
+                    const edk_fixed_ws* ws, hipStream_t stream);
 hipError_t edk_x25519_base(uint8_t* out, const uint8_t* scalars, size_t n, const uint32_t* comb,
-                           hipStream_t stream);
+                           const edk_fixed_ws* ws, hipStream_t stream);
 hipError_t edk_pk_to_x(uint8_t* out, const uint8_t* in, size_t n, hipStream_t stream);
 hipError_t edk_sk_to_x(uint8_t* out, const uint8_t* in, size_t n, hipStream_t stream);
 

@@ -6,9 +6,9 @@
 //
 //   k_x25519         x25519.c:129-150 do_x25519                      (config 3)
 //   k_verify_*       ed25519-sha512.c:148-181 ed25519_verify        (config 2, 4)
-//   k_sign           ed25519-sha512.c:84-123 sign                    (config 5)
-//   k_genpub         ed25519-sha512.c:53-67 genpub
-//   k_x25519_base    x25519.c:158-197 do_x25519_base
+//   k_sign_*         ed25519-sha512.c:84-123 sign                    (config 5)
+//   k_genpub_point + k_encode_finish          ed25519-sha512.c:53-67 genpub
+//   k_x25519_base_*  x25519.c:158-197 do_x25519_base
 //   k_pk_to_x        ed25519-sha512.c:187-232 pk_ed25519_to_x25519
 //   k_sk_to_x        ed25519-sha512.c:239-256 sk_ed25519_to_x25519
 //   k_init_tables    generates what the reference ships as lib/ed_lookup64.h
@@ -138,115 +138,274 @@ k_verify_main(const uint32_t* digits, const uint32_t* table, const uint32_t* bas
   }
 }
 
-// encode and compare with R as bytes (ed25519-sha512.c:176-180): a non-canonical R can never
-// match.  An off-curve A is rejected outright: DESIGN.md "Off-curve public keys".
-//
-// The inversion of ed_export (ed.c:161, 254 S + 11 M) is shared by FINISH_K items per lane with
-// Montgomery's trick: one inversion of the product of their Z plus 3 multiplications per item.
-// Lane t of block b handles lane t of tiles b*K .. b*K+K-1, so every access stays coalesced.
-// Z = 0 cannot occur for a curve point (the a = -1 law is complete); items whose key is off the
-// curve are rejected anyway, and their Z is replaced by 1 so that it cannot poison the product.
+// ---------------------------------------------------------------------------------------------
+// "finish" kernels: everything that needs an inversion (ed_export ed.c:161, x25519.c:192) shares
+// ONE inversion between FINISH_K items per lane (Montgomery's trick: 254 S + 11 M once, plus three
+// multiplications per item).  Lane t of block b handles lane t of tiles b*K .. b*K+K-1 of the
+// lane-interleaved point workspace acc[tile][30][256], so every access stays coalesced.
+// A policy P supplies  den(k, z, good): the value to invert for item k (1 when there is nothing to
+// invert: item past the end, rejected key, or a zero denominator, which must not poison the shared
+// product) and  item(k, zinv, good): the rest of the work of item k.
+// ---------------------------------------------------------------------------------------------
 constexpr int FINISH_K = 8;
 
-// Z of lane threadIdx.x of tile blockIdx.x*K + k, or 1 when that item does not exist, its key is
-// off the curve, or Z = 0
-ED_DEV void finish_load_z(fe& zsel, bool& good, int k, const uint32_t* accin, const uint8_t* flags,
-                          size_t n) {
-  const size_t tile = (size_t)blockIdx.x * FINISH_K + k;
-  const size_t i = tile * BLOCK + threadIdx.x;
-  fe z;
-  fe_set(z, 1);
-  good = false;
-  if (i < n) {
-    const uint32_t* o = accin + tile * (30 * BLOCK) + threadIdx.x;
+struct finish_pos {
+  size_t tile, i;            // tile index and global item index of slot k for this lane
+  const uint32_t* acc;       // this lane's column of the tile: X at [j*BLOCK], Y at [(10+j)*BLOCK], Z at [(20+j)*BLOCK]
+};
+ED_DEV finish_pos finish_at(int k, const uint32_t* accin) {
+  finish_pos p;
+  p.tile = (size_t)blockIdx.x * FINISH_K + k;
+  p.i = p.tile * BLOCK + threadIdx.x;
+  p.acc = accin + p.tile * (30 * BLOCK) + threadIdx.x;
+  return p;
+}
+ED_DEV void acc_load(fe& f, const uint32_t* acc, int coord) {
 #pragma unroll
-    for (int j = 0; j < 10; j++) z.v[j] = o[(20 + j) * BLOCK];
-    good = flags[i] != 0 && !fe_iszero(z);
+  for (int j = 0; j < 10; j++) f.v[j] = acc[(10 * coord + j) * BLOCK];
+}
+ED_DEV void acc_store(uint32_t* accout, const ge& p) {
+  uint32_t* o = accout + (size_t)blockIdx.x * (30 * BLOCK) + threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < 10; j++) {
+    o[j * BLOCK] = p.X.v[j]; o[(10 + j) * BLOCK] = p.Y.v[j]; o[(20 + j) * BLOCK] = p.Z.v[j];
   }
-  fe_set(zsel, 1);
-  fe_cmov(zsel, z, good);
 }
 
-ED_DEV void finish_item(int k, const fe& zinv, bool good, uint8_t* ok, const uint8_t* sigs,
-                        const uint32_t* accin, size_t n) {
-  const size_t tile = (size_t)blockIdx.x * FINISH_K + k;
-  const size_t i = tile * BLOCK + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t* o = accin + tile * (30 * BLOCK) + threadIdx.x;
-  fe x, y;
+// Phase A (straight-line: an fe[8] array indexed in a loop would end up in scratch) multiplies the
+// eight denominators together, inverts once and unwinds; each denominator is written to its Z slot
+// by den() and re-read during the unwinding (keeping all eight in registers next to the seven
+// prefix products and the inversion's temporaries does not fit 256 VGPRs), then replaced by its
+// inverse.  Phase B is an ordinary loop over the items, so the (large) per-item code exists once.
+// slot k's Z in the workspace is overwritten first by the committed denominator, then by its
+// inverse (the same lane writes and later reads it)
+ED_DEV void zinv_store(uint32_t* acc, int k, const fe& zi) {
+  uint32_t* o = acc + ((size_t)blockIdx.x * FINISH_K + k) * (30 * BLOCK) + threadIdx.x;
 #pragma unroll
-  for (int j = 0; j < 10; j++) { x.v[j] = o[j * BLOCK]; y.v[j] = o[(10 + j) * BLOCK]; }
-  uint32_t rw[8];
-  load32(rw, sigs, i, 64);
-  ok[i] = (uint8_t)(verify_encode_lane(x, y, zinv, rw) && good);
+  for (int j = 0; j < 10; j++) o[(20 + j) * BLOCK] = zi.v[j];
+}
+ED_DEV void den_reload(fe& z, const uint32_t* acc, int k) {
+  const uint32_t* o = acc + ((size_t)blockIdx.x * FINISH_K + k) * (30 * BLOCK) + threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < 10; j++) z.v[j] = o[(20 + j) * BLOCK];
 }
 
-__global__ void __launch_bounds__(BLOCK, 2)
-k_verify_finish(uint8_t* ok, const uint8_t* sigs, const uint32_t* accin, const uint8_t* flags, size_t n) {
-  // straight-line on purpose: an fe[8] array indexed in a loop ends up in scratch
-  fe z0, z1, z2, z3, z4, z5, z6, z7, p1, p2, p3, p4, p5, p6, p7, u, zi;
-  bool g0, g1, g2, g3, g4, g5, g6, g7;
-  finish_load_z(z0, g0, 0, accin, flags, n);
-  finish_load_z(z1, g1, 1, accin, flags, n); fe_mul(p1, z0, z1);
-  finish_load_z(z2, g2, 2, accin, flags, n); fe_mul(p2, p1, z2);
-  finish_load_z(z3, g3, 3, accin, flags, n); fe_mul(p3, p2, z3);
-  finish_load_z(z4, g4, 4, accin, flags, n); fe_mul(p4, p3, z4);
-  finish_load_z(z5, g5, 5, accin, flags, n); fe_mul(p5, p4, z5);
-  finish_load_z(z6, g6, 6, accin, flags, n); fe_mul(p6, p5, z6);
-  finish_load_z(z7, g7, 7, accin, flags, n); fe_mul(p7, p6, z7);
+template <class P>
+ED_DEV void finish_batch8(const P& pol, uint32_t* acc) {
+  fe z, p0, p1, p2, p3, p4, p5, p6, p7, u, zi;
+  pol.den(0, p0);
+  pol.den(1, z); fe_mul(p1, p0, z);
+  pol.den(2, z); fe_mul(p2, p1, z);
+  pol.den(3, z); fe_mul(p3, p2, z);
+  pol.den(4, z); fe_mul(p4, p3, z);
+  pol.den(5, z); fe_mul(p5, p4, z);
+  pol.den(6, z); fe_mul(p6, p5, z);
+  pol.den(7, z); fe_mul(p7, p6, z);
   fe_inv(u, p7);                                 // u = 1 / (z0 ... z7)
-  fe_mul(zi, u, p6); finish_item(7, zi, g7, ok, sigs, accin, n); fe_mul(u, u, z7);
-  fe_mul(zi, u, p5); finish_item(6, zi, g6, ok, sigs, accin, n); fe_mul(u, u, z6);
-  fe_mul(zi, u, p4); finish_item(5, zi, g5, ok, sigs, accin, n); fe_mul(u, u, z5);
-  fe_mul(zi, u, p3); finish_item(4, zi, g4, ok, sigs, accin, n); fe_mul(u, u, z4);
-  fe_mul(zi, u, p2); finish_item(3, zi, g3, ok, sigs, accin, n); fe_mul(u, u, z3);
-  fe_mul(zi, u, p1); finish_item(2, zi, g2, ok, sigs, accin, n); fe_mul(u, u, z2);
-  fe_mul(zi, u, z0); finish_item(1, zi, g1, ok, sigs, accin, n); fe_mul(u, u, z1);
-  finish_item(0, u, g0, ok, sigs, accin, n);
+  fe_mul(zi, u, p6); den_reload(z, acc, 7); fe_mul(u, u, z); zinv_store(acc, 7, zi);
+  fe_mul(zi, u, p5); den_reload(z, acc, 6); fe_mul(u, u, z); zinv_store(acc, 6, zi);
+  fe_mul(zi, u, p4); den_reload(z, acc, 5); fe_mul(u, u, z); zinv_store(acc, 5, zi);
+  fe_mul(zi, u, p3); den_reload(z, acc, 4); fe_mul(u, u, z); zinv_store(acc, 4, zi);
+  fe_mul(zi, u, p2); den_reload(z, acc, 3); fe_mul(u, u, z); zinv_store(acc, 3, zi);
+  fe_mul(zi, u, p1); den_reload(z, acc, 2); fe_mul(u, u, z); zinv_store(acc, 2, zi);
+  fe_mul(zi, u, p0); den_reload(z, acc, 1); fe_mul(u, u, z); zinv_store(acc, 1, zi);
+  zinv_store(acc, 0, u);
+#pragma unroll 1
+  for (int k = 0; k < FINISH_K; k++) pol.item(k);
+}
+
+// z := good ? z : 1, committed to slot k's Z so that the unwinding re-reads exactly this value
+ED_DEV void den_commit(fe& z, bool good, uint32_t* acc, int k) {
+  fe one;
+  fe_set(one, 1);
+  fe_cmov(one, z, good);
+  z = one;
+  zinv_store(acc, k, z);
+}
+
+// verify: encode and compare with R as bytes (ed25519-sha512.c:176-180): a non-canonical R can
+// never match.  An off-curve A is rejected outright (DESIGN.md "Off-curve public keys"); Z = 0
+// cannot occur for a curve point (the a = -1 law is complete).
+struct verify_finish_policy {
+  uint8_t* ok; const uint8_t* sigs; uint32_t* acc; uint8_t* flags; size_t n;
+  ED_DEV void den(int k, fe& z) const {
+    const finish_pos p = finish_at(k, acc);
+    fe_set(z, 1);
+    bool good = false;
+    if (p.i < n) {
+      acc_load(z, p.acc, 2);
+      good = flags[p.i] != 0 && !fe_iszero(z);
+      flags[p.i] = (uint8_t)good;                // phase B reads it back
+    }
+    den_commit(z, good, acc, k);
+  }
+  ED_DEV void item(int k) const {
+    const finish_pos p = finish_at(k, acc);
+    if (p.i >= n) return;
+    fe x, y, zinv;
+    acc_load(x, p.acc, 0); acc_load(y, p.acc, 1); acc_load(zinv, p.acc, 2);
+    uint32_t rw[8];
+    load32(rw, sigs, p.i, 64);
+    ok[p.i] = (uint8_t)(verify_encode_lane(x, y, zinv, rw) && flags[p.i] != 0);
+  }
+};
+
+__global__ void __launch_bounds__(BLOCK, 2)
+k_verify_finish(uint8_t* ok, const uint8_t* sigs, uint32_t* acc, uint8_t* flags, size_t n) {
+  finish_batch8(verify_finish_policy{ok, sigs, acc, flags, n}, acc);
 }
 
 // ---------------------------------------------------------------------------------------------
-// fixed-base kernels: the 256-entry comb (32 KiB) is staged in LDS by every block
+// fixed-base kernels: the 256-entry comb (32 KiB) is staged in LDS by every block of a "point"
+// kernel; the matching "finish" kernel encodes (and, for sign, hashes and computes S)
 // ---------------------------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(BLOCK, 2)
-k_genpub(uint8_t* pubs, const uint8_t* secs, size_t n, const uint32_t* comb) {
+k_genpub_point(uint32_t* accout, const uint8_t* secs, size_t n, const uint32_t* comb) {
   __shared__ alignas(16) uint32_t lds_comb[TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS];
   stage_table(lds_comb, comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS);
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  const size_t item = i < n ? i : n - 1;
-  uint32_t sk[8], out[8];
-  load32(sk, secs, item, 32);
-  genpub_lane(out, sk, lds_comb);
-  if (i < n) store32(pubs, i, 32, out);
+  uint32_t sk[8];
+  load32(sk, secs, i < n ? i : n - 1, 32);
+  ge A;
+  genpub_point_lane(A, sk, lds_comb);
+  acc_store(accout, A);
+}
+
+// Z of a comb result is never 0 (B and its multiples are curve points)
+struct encode_finish_policy {
+  uint8_t* out; uint32_t* acc; size_t n;
+  ED_DEV void den(int k, fe& z) const {
+    const finish_pos p = finish_at(k, acc);
+    fe_set(z, 1);
+    if (p.i < n) acc_load(z, p.acc, 2);
+    den_commit(z, true, acc, k);
+  }
+  ED_DEV void item(int k) const {
+    const finish_pos p = finish_at(k, acc);
+    if (p.i >= n) return;
+    fe x, y, zinv;
+    acc_load(x, p.acc, 0); acc_load(y, p.acc, 1); acc_load(zinv, p.acc, 2);
+    uint32_t w[8];
+    encode_lane(w, x, y, zinv);
+    store32(out, p.i, 32, w);
+  }
+};
+
+__global__ void __launch_bounds__(BLOCK, 2)
+k_encode_finish(uint8_t* out, uint32_t* acc, size_t n) {
+  finish_batch8(encode_finish_policy{out, acc, n}, acc);
 }
 
 __global__ void __launch_bounds__(BLOCK, 2)
-k_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, const uint8_t* msgs,
-       const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* comb) {
+k_sign_point(uint32_t* accout, uint32_t* aux, const uint8_t* secs, const uint8_t* msgs,
+             const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* comb) {
   __shared__ alignas(16) uint32_t lds_comb[TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS];
   stage_table(lds_comb, comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS);
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const size_t item = i < n ? i : n - 1;
   const uint8_t* m; size_t mlen;
   msg_span(m, mlen, msgs, msg_off, msg_len, item);
-  uint32_t sk[8], pub[8], Rw[8], Sw[8];
+  uint32_t sk[8], aw[8], rw[8];
   load32(sk, secs, item, 32);
-  load32(pub, pubs, item, 32);
-  sign_lane(Rw, Sw, sk, pub, m, mlen, lds_comb);
-  if (i < n) { store32(sigs, i, 64, Rw); store32(sigs + 32, i, 64, Sw); }
+  ge R;
+  sign_point_lane(R, aw, rw, sk, m, mlen, lds_comb);
+  acc_store(accout, R);
+  uint4* d = reinterpret_cast<uint4*>(aux + 16 * i);     // the secret scalars a and r, for the finish step
+  d[0] = make_uint4(aw[0], aw[1], aw[2], aw[3]); d[1] = make_uint4(aw[4], aw[5], aw[6], aw[7]);
+  d[2] = make_uint4(rw[0], rw[1], rw[2], rw[3]); d[3] = make_uint4(rw[4], rw[5], rw[6], rw[7]);
+}
+
+struct sign_finish_policy {
+  uint8_t* sigs; uint32_t* acc; uint32_t* aux; const uint8_t* pubs; const uint8_t* msgs;
+  const uint64_t* msg_off; size_t msg_len; size_t n;
+  ED_DEV void den(int k, fe& z) const {
+    const finish_pos p = finish_at(k, acc);
+    fe_set(z, 1);
+    if (p.i < n) acc_load(z, p.acc, 2);
+    den_commit(z, true, acc, k);
+  }
+  ED_DEV void item(int k) const {
+    const finish_pos p = finish_at(k, acc);
+    if (p.i >= n) return;
+    fe x, y, zinv;
+    acc_load(x, p.acc, 0); acc_load(y, p.acc, 1); acc_load(zinv, p.acc, 2);
+    uint32_t Rw[8], Sw[8], aw[8], rw[8], pub[8];
+    encode_lane(Rw, x, y, zinv);
+    uint4* d = reinterpret_cast<uint4*>(aux + 16 * p.i);
+    const uint4 a0 = d[0], a1 = d[1], r0 = d[2], r1 = d[3];
+    aw[0] = a0.x; aw[1] = a0.y; aw[2] = a0.z; aw[3] = a0.w; aw[4] = a1.x; aw[5] = a1.y; aw[6] = a1.z; aw[7] = a1.w;
+    rw[0] = r0.x; rw[1] = r0.y; rw[2] = r0.z; rw[3] = r0.w; rw[4] = r1.x; rw[5] = r1.y; rw[6] = r1.z; rw[7] = r1.w;
+    const uint4 zero = make_uint4(0, 0, 0, 0);           // the secrets do not outlive the call in HBM
+    d[0] = zero; d[1] = zero; d[2] = zero; d[3] = zero;
+    load32(pub, pubs, p.i, 32);
+    const uint8_t* m; size_t mlen;
+    msg_span(m, mlen, msgs, msg_off, msg_len, p.i);
+    sign_finish_lane(Sw, Rw, aw, rw, pub, m, mlen);
+    store32(sigs, p.i, 64, Rw);
+    store32(sigs + 32, p.i, 64, Sw);
+  }
+};
+
+__global__ void __launch_bounds__(BLOCK, 2)
+k_sign_finish(uint8_t* sigs, uint32_t* acc, uint32_t* aux, const uint8_t* pubs, const uint8_t* msgs,
+              const uint64_t* msg_off, size_t msg_len, size_t n) {
+  finish_batch8(sign_finish_policy{sigs, acc, aux, pubs, msgs, msg_off, msg_len, n}, acc);
 }
 
 __global__ void __launch_bounds__(BLOCK, 2)
-k_x25519_base(uint8_t* out, const uint8_t* scalars, size_t n, const uint32_t* comb) {
+k_x25519_base_point(uint32_t* accout, const uint8_t* scalars, size_t n, const uint32_t* comb) {
   __shared__ alignas(16) uint32_t lds_comb[TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS];
   stage_table(lds_comb, comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS);
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  const size_t item = i < n ? i : n - 1;
-  uint32_t s[8], o[8];
-  load32(s, scalars, item, 32);
-  x25519_base_lane(o, s, lds_comb);
-  if (i < n) store32(out, i, 32, o);
+  uint32_t s[8];
+  load32(s, scalars, i < n ? i : n - 1, 32);
+  ge R;
+  x25519_base_point_lane(R, s, lds_comb);
+  fe_add(R.X, R.Z, R.Y);                         // the finish step needs z + y, not x
+  fe_carry(R.X);
+  acc_store(accout, R);
+}
+
+// u = (z + y) / (z - y); z = y gives 0 in the reference (fld_inv(0) = 0, x25519.c:192): such an
+// item contributes 1 to the shared product and gets the "inverse" 0 by hand.
+struct x25519_base_finish_policy {
+  uint8_t* out; uint32_t* acc; size_t n;
+  ED_DEV void den(int k, fe& d) const {
+    const finish_pos p = finish_at(k, acc);
+    fe_set(d, 1);
+    bool good = false;
+    if (p.i < n) {
+      fe y, z;
+      acc_load(y, p.acc, 1); acc_load(z, p.acc, 2);
+      fe_sub(d, z, y);                           // 3u
+      good = !fe_iszero(d);
+    }
+    den_commit(d, good, acc, k);
+  }
+  ED_DEV void item(int k) const {
+    const finish_pos p = finish_at(k, acc);
+    if (p.i >= n) return;
+    fe x, y, dinv, z, d;
+    acc_load(y, p.acc, 1); acc_load(dinv, p.acc, 2);     // the Z slot now holds 1/(z - y) (or 1/1)
+    // z itself was overwritten; recover the numerator z + y = (z - y) + 2y from X's slot instead:
+    // the point kernel stores z + y there (x is not needed for x25519_base)
+    acc_load(x, p.acc, 0);                               // = z + y
+    fe_sub(d, x, y); fe_sub(d, d, y);                    // z - y, to detect the zero denominator
+    fe zero;
+    fe_set(zero, 0);
+    fe_cmov(dinv, zero, fe_iszero(d));
+    fe u;
+    fe_mul(u, x, dinv);
+    uint32_t w[8];
+    fe_tobytes(w, u);
+    store32(out, p.i, 32, w);
+  }
+};
+
+__global__ void __launch_bounds__(BLOCK, 2)
+k_x25519_base_finish(uint8_t* out, uint32_t* acc, size_t n) {
+  finish_batch8(x25519_base_finish_policy{out, acc, n}, acc);
 }
 
 __global__ void __launch_bounds__(BLOCK, 2)
@@ -313,24 +472,30 @@ hipError_t edk_verify(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, con
 
 #define EDK_GRID(n) dim3((unsigned)(((n) + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream
 
-hipError_t edk_genpub(uint8_t* pubs, const uint8_t* secs, size_t n, const uint32_t* comb, hipStream_t stream) {
+#define EDK_FINISH_GRID(n) dim3((unsigned)((((n) + BLOCK - 1) / BLOCK + FINISH_K - 1) / FINISH_K)), dim3(BLOCK), 0, stream
+
+hipError_t edk_genpub(uint8_t* pubs, const uint8_t* secs, size_t n, const uint32_t* comb,
+                      const edk_fixed_ws* ws, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_genpub, EDK_GRID(n), pubs, secs, n, comb);
+  hipLaunchKernelGGL(k_genpub_point, EDK_GRID(n), ws->acc, secs, n, comb);
+  hipLaunchKernelGGL(k_encode_finish, EDK_FINISH_GRID(n), pubs, ws->acc, n);
   return hipGetLastError();
 }
 
 hipError_t edk_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, const uint8_t* msgs,
                     const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* comb,
-                    hipStream_t stream) {
+                    const edk_fixed_ws* ws, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_sign, EDK_GRID(n), sigs, secs, pubs, msgs, msg_off, msg_len, n, comb);
+  hipLaunchKernelGGL(k_sign_point, EDK_GRID(n), ws->acc, ws->aux, secs, msgs, msg_off, msg_len, n, comb);
+  hipLaunchKernelGGL(k_sign_finish, EDK_FINISH_GRID(n), sigs, ws->acc, ws->aux, pubs, msgs, msg_off, msg_len, n);
   return hipGetLastError();
 }
 
 hipError_t edk_x25519_base(uint8_t* out, const uint8_t* scalars, size_t n, const uint32_t* comb,
-                           hipStream_t stream) {
+                           const edk_fixed_ws* ws, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_x25519_base, EDK_GRID(n), out, scalars, n, comb);
+  hipLaunchKernelGGL(k_x25519_base_point, EDK_GRID(n), ws->acc, scalars, n, comb);
+  hipLaunchKernelGGL(k_x25519_base_finish, EDK_FINISH_GRID(n), out, ws->acc, n);
   return hipGetLastError();
 }
 

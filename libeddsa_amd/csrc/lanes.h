@@ -9,8 +9,8 @@
 //   verify_main_lane       ed.c:455-507 ed_dual_scale (windowed, uniform control flow)
 //   verify_encode_lane     ed.c:155-169 ed_export + ed25519-sha512.c:176-180 (given 1/Z)
 //   scale_base_lane        ed.c:397-430 ed_scale_base (comb, constant-time select)
-//   genpub_lane, sign_lane ed25519-sha512.c:53-123
-//   x25519_base_lane       x25519.c:158-197
+//   genpub_point_lane, sign_point_lane, sign_finish_lane, encode_lane   ed25519-sha512.c:53-123
+//   x25519_base_point_lane, x25519_base_finish_lane                      x25519.c:158-197
 //   pk_to_x_lane, sk_to_x_lane   ed25519-sha512.c:187-256
 #pragma once
 #include "fe25519.h"
@@ -314,59 +314,76 @@ ED_DEV void key_setup(uint32_t h[16], const uint32_t sk[8]) {
   h[7] = (h[7] & 0x7fffffffu) | 0x40000000u;
 }
 
-// ed25519-sha512.c:53-67 genpub
-ED_DEV void genpub_lane(uint32_t out[8], const uint32_t sk[8], const uint32_t* comb) {
+// The fixed-base operations are split in two, like verify: a "point" step that ends with the
+// projective result, and a "finish" step that needs 1/Z (or 1/(Z-Y)); the kernels run the finish
+// step for eight items per lane on ONE shared inversion (Montgomery's trick, kernels.hip).
+
+// ed_export given zinv = 1/Z (ed.c:155-169)
+ED_DEV void encode_lane(uint32_t out[8], const fe& X, const fe& Y, const fe& zinv) {
+  fe x, y;
+  fe_mul(x, X, zinv);
+  fe_mul(y, Y, zinv);
+  fe_tobytes(out, y);
+  out[7] |= fe_parity(x) << 31;
+}
+
+// ed25519-sha512.c:53-67 genpub, up to the point A = a*B
+ED_DEV void genpub_point_lane(ge& A, const uint32_t sk[8], const uint32_t* comb) {
   uint32_t h[16], aw[8];
   key_setup(h, sk);
   sc a;
   sc_from_words<8>(a, h);
   sc_to_words(aw, a);
-  ge A;
   scale_base_lane(A, aw, comb);
-  ge_tobytes(out, A);
 }
 
-// ed25519-sha512.c:84-123 sign: Rw | Sw is the signature
-ED_DEV void sign_lane(uint32_t Rw[8], uint32_t Sw[8], const uint32_t sk[8], const uint32_t pub[8],
-                      const uint8_t* m, size_t mlen, const uint32_t* comb) {
-  uint32_t h[16], dig[16], rw[8];
+// ed25519-sha512.c:84-110 sign, up to R = r*B; aw, rw = the reduced scalars a and r as words
+ED_DEV void sign_point_lane(ge& R, uint32_t aw[8], uint32_t rw[8], const uint32_t sk[8],
+                            const uint8_t* m, size_t mlen, const uint32_t* comb) {
+  uint32_t h[16], dig[16], rdig[8];
   key_setup(h, sk);
-  sc a, r, t, S;
+  sc a, r;
   sc_from_words<8>(a, h);
+  sc_to_words(aw, a);
   sha512_prefix_msg<8>(dig, h + 8, m, mlen);     // r = H(h[32..64) || M)
   sc_from_words<16>(r, dig);
   sc_to_words(rw, r);
-  {
-    ge R;
-    scale_base_lane(R, rw, comb);
-    ge_tobytes(Rw, R);
-  }
-  {
-    uint32_t pre[16];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { pre[k] = Rw[k]; pre[8 + k] = pub[k]; }
-    sha512_prefix_msg<16>(dig, pre, m, mlen);    // t = H(R || A || M)
-  }
+  for (int k = 0; k < 8; k++) rdig[k] = rw[k];
+  scale_base_lane(R, rdig, comb);
+}
+
+// ed25519-sha512.c:112-122 sign, from the encoded R on: S = r + H(R || A || M) * a
+ED_DEV void sign_finish_lane(uint32_t Sw[8], const uint32_t Rw[8], const uint32_t aw[8],
+                             const uint32_t rw[8], const uint32_t pub[8], const uint8_t* m, size_t mlen) {
+  uint32_t pre[16], dig[16];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { pre[k] = Rw[k]; pre[8 + k] = pub[k]; }
+  sha512_prefix_msg<16>(dig, pre, m, mlen);      // t = H(R || A || M)
+  sc a, r, t, S;
+  sc_from_words<8>(a, aw);
+  sc_from_words<8>(r, rw);
   sc_from_words<16>(t, dig);
   sc_mul(S, t, a);
   sc_add(S, r, S);
   sc_to_words(Sw, S);
 }
 
-// x25519.c:158-197 do_x25519_base
-ED_DEV void x25519_base_lane(uint32_t out[8], uint32_t s[8], const uint32_t* comb) {
+// x25519.c:158-190 do_x25519_base, up to R = x*B
+ED_DEV void x25519_base_point_lane(ge& R, uint32_t s[8], const uint32_t* comb) {
   uint32_t xw[8];
   clamp(s);
   sc x;
   sc_from_words<8>(x, s);
   sc_to_words(xw, x);
-  ge R;
   scale_base_lane(R, xw, comb);
-  fe u, t;
-  fe_sub(t, R.Z, R.Y);                           // 3u
-  fe_inv(t, t);
-  fe_add(u, R.Z, R.Y);                           // 2u
-  fe_mul(u, u, t);
+}
+
+// x25519.c:191-196: u = (z + y) / (z - y), given dinv = 1 / (z - y)  (0 when z = y, as fld_inv)
+ED_DEV void x25519_base_finish_lane(uint32_t out[8], const fe& Y, const fe& Z, const fe& dinv) {
+  fe u;
+  fe_add(u, Z, Y);                               // 2u
+  fe_mul(u, u, dinv);
   fe_tobytes(out, u);
 }
 

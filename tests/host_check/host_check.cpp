@@ -90,24 +90,36 @@ void hc_batch_inverse(uint8_t* out, const uint8_t* zs, int k) {
   fe_tobytes(w, u); wr(out, w);
 }
 
+// point step, inversion, finish step: what the k_*_point / k_*_finish kernel pairs do for one item
 void hc_genpub(uint8_t pub[32], const uint8_t sec[32]) {
   uint32_t sk[8], o[8];
   rd(sk, sec);
-  genpub_lane(o, sk, tables().comb.data());
+  ge A; fe zinv;
+  genpub_point_lane(A, sk, tables().comb.data());
+  fe_inv(zinv, A.Z);
+  encode_lane(o, A.X, A.Y, zinv);
   wr(pub, o);
 }
 
 void hc_sign(uint8_t sig[64], const uint8_t sec[32], const uint8_t pub[32], const uint8_t* msg, size_t len) {
-  uint32_t sk[8], pk[8], R[8], S[8];
+  uint32_t sk[8], pk[8], R[8], S[8], aw[8], rw[8];
   rd(sk, sec); rd(pk, pub);
-  sign_lane(R, S, sk, pk, msg, len, tables().comb.data());
+  ge Rp; fe zinv;
+  sign_point_lane(Rp, aw, rw, sk, msg, len, tables().comb.data());
+  fe_inv(zinv, Rp.Z);
+  encode_lane(R, Rp.X, Rp.Y, zinv);
+  sign_finish_lane(S, R, aw, rw, pk, msg, len);
   wr(sig, R); wr(sig + 32, S);
 }
 
 void hc_x25519_base(uint8_t out[32], const uint8_t scalar[32]) {
   uint32_t s[8], o[8];
   rd(s, scalar);
-  x25519_base_lane(o, s, tables().comb.data());
+  ge R; fe d;
+  x25519_base_point_lane(R, s, tables().comb.data());
+  fe_sub(d, R.Z, R.Y);
+  fe_inv(d, d);                                   // 0 -> 0
+  x25519_base_finish_lane(o, R.Y, R.Z, d);
   wr(out, o);
 }
 
