@@ -35,6 +35,7 @@ struct engine {
 };
 
 static struct engine g_eng;
+static void pipe_release(void);
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 
 #define TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = -(int)e_; goto out; } } while (0)
@@ -133,6 +134,7 @@ void eddsa_amd_shutdown(void)
     pthread_mutex_lock(&g_lock);
     if (g_eng.ready) {
         (void)hipDeviceSynchronize();
+        pipe_release();
         ws_release(&g_eng); fws_release(&g_eng);
         (void)hipFree(g_eng.base16); (void)hipFree(g_eng.comb); (void)hipEventDestroy(g_eng.ws_free);
         memset(&g_eng, 0, sizeof(g_eng));
@@ -310,135 +312,204 @@ out:
 }
 
 /* ------------------------------------------------------------------------------------------
- * host-pointer entry points: stage through HBM, run the device-pointer form, copy back
+ * host-pointer entry points: a streaming pipeline over chunks of PIPE_CHUNK items.
+ *
+ * Three streams: `up` copies chunk k+1 host -> HBM while `exec` runs the kernels of chunk k and
+ * `down` copies the results of chunk k-1 back, on two alternating sets of device input buffers
+ * that persist across calls (grown on demand).  With pageable caller memory the HIP runtime stages
+ * the copies itself and blocks the calling thread for their duration, which is why the download of
+ * chunk k-1 is issued only after the kernels of chunk k were launched; with pinned caller memory
+ * (hipHostMalloc / hipHostRegister) the copies are asynchronous as well.
+ * Ragged messages (msg_off != NULL) go through the same buffers as a single chunk.
  * ---------------------------------------------------------------------------------------- */
 
-#define MAX_BUFS 6
-struct staging { void *dev[MAX_BUFS]; int count; };
+#define PIPE_CHUNK ((size_t)1 << 18)   /* 1024 blocks of 256 lanes: one full residency of the chip */
+#define PIPE_MAX_IN 3
 
-static void staging_free(struct staging *s)
-{
-    for (int i = 0; i < s->count; i++) if (s->dev[i]) (void)hipFree(s->dev[i]);
-    s->count = 0;
-}
+struct hjob {
+    int n_in; const uint8_t *in[PIPE_MAX_IN]; size_t in_w[PIPE_MAX_IN];   /* fixed-width inputs */
+    int has_msgs; const uint8_t *msgs; const uint64_t *msg_off; size_t msg_len;
+    uint8_t *out; size_t out_w;
+    int (*run)(uint8_t *d_out, uint8_t *const d_in[PIPE_MAX_IN], const uint8_t *d_msgs, const uint64_t *d_off,
+               size_t msg_len, size_t m, void *stream);
+};
 
-/* allocate `bytes` (at least 16, so that empty inputs still give a valid pointer) and upload */
-static int staging_in(struct staging *s, void **out, const void *host, size_t bytes)
+struct pipe {
+    int ready;
+    hipStream_t up, exec, down;
+    hipEvent_t in_ready[2], exec_done[2], slot_free[2];
+    void *d_in[2][PIPE_MAX_IN]; size_t in_cap[2][PIPE_MAX_IN];
+    void *d_msgs[2]; size_t msgs_cap[2];
+    void *d_off; size_t off_cap;
+    void *d_out; size_t out_cap;
+};
+static struct pipe g_pipe;
+static pthread_mutex_t g_pipe_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static int pipe_grow(void **buf, size_t *cap, size_t need)
 {
-    void *d = NULL;
-    hipError_t e = hipMalloc(&d, bytes ? bytes : 16);
+    if (need <= *cap) return 0;
+    if (*buf) { (void)hipFree(*buf); *buf = NULL; *cap = 0; }
+    hipError_t e = hipMalloc(buf, need < 256 ? 256 : need);
     if (e != hipSuccess) return -(int)e;
-    s->dev[s->count++] = d;
-    if (host && bytes) {
-        e = hipMemcpy(d, host, bytes, hipMemcpyHostToDevice);
-        if (e != hipSuccess) return -(int)e;
-    }
-    *out = d;
+    *cap = need < 256 ? 256 : need;
     return 0;
 }
 
-#define STAGE(ptr, host, bytes) do { rc = staging_in(&st, (void **)&(ptr), (host), (bytes)); if (rc) goto out; } while (0)
-
-static size_t msgs_total(const uint64_t *msg_off, size_t msg_len, size_t n)
+static int pipe_init(void)
 {
-    return msg_off ? (size_t)msg_off[n] : msg_len * n;
+    int rc = 0;
+    if (g_pipe.ready) return 0;
+    TRY(hipStreamCreateWithFlags(&g_pipe.up, hipStreamNonBlocking));
+    TRY(hipStreamCreateWithFlags(&g_pipe.exec, hipStreamNonBlocking));
+    TRY(hipStreamCreateWithFlags(&g_pipe.down, hipStreamNonBlocking));
+    for (int s = 0; s < 2; s++) {
+        TRY(hipEventCreateWithFlags(&g_pipe.in_ready[s], hipEventDisableTiming));
+        TRY(hipEventCreateWithFlags(&g_pipe.exec_done[s], hipEventDisableTiming));
+        TRY(hipEventCreateWithFlags(&g_pipe.slot_free[s], hipEventDisableTiming));
+    }
+    g_pipe.ready = 1;
+out:
+    return rc;
 }
+
+static void pipe_release(void)
+{
+    if (!g_pipe.ready) return;
+    for (int s = 0; s < 2; s++) {
+        for (int i = 0; i < PIPE_MAX_IN; i++) if (g_pipe.d_in[s][i]) (void)hipFree(g_pipe.d_in[s][i]);
+        if (g_pipe.d_msgs[s]) (void)hipFree(g_pipe.d_msgs[s]);
+        (void)hipEventDestroy(g_pipe.in_ready[s]); (void)hipEventDestroy(g_pipe.exec_done[s]);
+        (void)hipEventDestroy(g_pipe.slot_free[s]);
+    }
+    if (g_pipe.d_off) (void)hipFree(g_pipe.d_off);
+    if (g_pipe.d_out) (void)hipFree(g_pipe.d_out);
+    (void)hipStreamDestroy(g_pipe.up); (void)hipStreamDestroy(g_pipe.exec); (void)hipStreamDestroy(g_pipe.down);
+    memset(&g_pipe, 0, sizeof(g_pipe));
+}
+
+static int pipe_run(const struct hjob *j, size_t n)
+{
+    int rc = ensure_init();
+    if (rc || n == 0) return rc;
+    pthread_mutex_lock(&g_pipe_lock);
+    rc = pipe_init();
+    if (rc) goto out;
+    {
+        const int ragged = j->has_msgs && j->msg_off != NULL;
+        const size_t chunk = ragged ? n : (n < PIPE_CHUNK ? n : PIPE_CHUNK);
+        const size_t nchunks = (n + chunk - 1) / chunk;
+        if ((rc = pipe_grow(&g_pipe.d_out, &g_pipe.out_cap, n * j->out_w))) goto out;
+        if (ragged && (rc = pipe_grow(&g_pipe.d_off, &g_pipe.off_cap, (n + 1) * sizeof(uint64_t)))) goto out;
+        for (int s = 0; s < (nchunks > 1 ? 2 : 1); s++) {
+            for (int i = 0; i < j->n_in; i++)
+                if ((rc = pipe_grow(&g_pipe.d_in[s][i], &g_pipe.in_cap[s][i], chunk * j->in_w[i]))) goto out;
+            if (j->has_msgs) {
+                const size_t need = ragged ? (size_t)j->msg_off[n] : chunk * j->msg_len;
+                if ((rc = pipe_grow(&g_pipe.d_msgs[s], &g_pipe.msgs_cap[s], need))) goto out;
+            }
+        }
+        if (ragged) TRY(hipMemcpyAsync(g_pipe.d_off, j->msg_off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g_pipe.up));
+        for (size_t k = 0; k < nchunks; k++) {
+            const int s = (int)(k & 1);
+            const size_t lo = k * chunk, m = n - lo < chunk ? n - lo : chunk;
+            /* upload chunk k into slot s once the kernels of chunk k-2 have consumed it */
+            if (k >= 2) TRY(hipStreamWaitEvent(g_pipe.up, g_pipe.exec_done[s], 0));
+            for (int i = 0; i < j->n_in; i++)
+                TRY(hipMemcpyAsync(g_pipe.d_in[s][i], j->in[i] + lo * j->in_w[i], m * j->in_w[i], hipMemcpyHostToDevice, g_pipe.up));
+            if (j->has_msgs) {
+                const size_t bytes = ragged ? (size_t)j->msg_off[n] : m * j->msg_len;
+                const uint8_t *src = ragged ? j->msgs : j->msgs + lo * j->msg_len;
+                if (bytes) TRY(hipMemcpyAsync(g_pipe.d_msgs[s], src, bytes, hipMemcpyHostToDevice, g_pipe.up));
+            }
+            TRY(hipEventRecord(g_pipe.in_ready[s], g_pipe.up));
+            /* kernels of chunk k */
+            TRY(hipStreamWaitEvent(g_pipe.exec, g_pipe.in_ready[s], 0));
+            rc = j->run((uint8_t *)g_pipe.d_out + lo * j->out_w, (uint8_t *const *)g_pipe.d_in[s],
+                        (const uint8_t *)g_pipe.d_msgs[s], ragged ? (const uint64_t *)g_pipe.d_off : NULL,
+                        j->msg_len, m, g_pipe.exec);
+            if (rc) goto out;
+            TRY(hipEventRecord(g_pipe.exec_done[s], g_pipe.exec));
+            /* download chunk k-1 (its kernels were launched one iteration ago) */
+            if (k >= 1) {
+                const size_t plo = (k - 1) * chunk;
+                TRY(hipStreamWaitEvent(g_pipe.down, g_pipe.exec_done[s ^ 1], 0));
+                TRY(hipMemcpyAsync(j->out + plo * j->out_w, (uint8_t *)g_pipe.d_out + plo * j->out_w, chunk * j->out_w,
+                                   hipMemcpyDeviceToHost, g_pipe.down));
+            }
+        }
+        {
+            const size_t plo = (nchunks - 1) * chunk;
+            TRY(hipStreamWaitEvent(g_pipe.down, g_pipe.exec_done[(nchunks - 1) & 1], 0));
+            TRY(hipMemcpyAsync(j->out + plo * j->out_w, (uint8_t *)g_pipe.d_out + plo * j->out_w, (n - plo) * j->out_w,
+                               hipMemcpyDeviceToHost, g_pipe.down));
+        }
+        TRY(hipStreamSynchronize(g_pipe.down));
+        TRY(hipStreamSynchronize(g_pipe.exec));
+        TRY(hipStreamSynchronize(g_pipe.up));
+    }
+out:
+    if (rc) { (void)hipStreamSynchronize(g_pipe.up); (void)hipStreamSynchronize(g_pipe.exec); (void)hipStreamSynchronize(g_pipe.down); }
+    pthread_mutex_unlock(&g_pipe_lock);
+    return rc;
+}
+
+static int run_verify(uint8_t *d_out, uint8_t *const d_in[PIPE_MAX_IN], const uint8_t *d_msgs, const uint64_t *d_off,
+                      size_t msg_len, size_t m, void *stream)
+{
+    return ed25519_verify_batch_dev(d_out, d_in[0], d_in[1], d_msgs, d_off, msg_len, m, stream);
+}
+static int run_sign(uint8_t *d_out, uint8_t *const d_in[PIPE_MAX_IN], const uint8_t *d_msgs, const uint64_t *d_off,
+                    size_t msg_len, size_t m, void *stream)
+{
+    return ed25519_sign_batch_dev(d_out, d_in[0], d_in[1], d_msgs, d_off, msg_len, m, stream);
+}
+static int run_x25519(uint8_t *d_out, uint8_t *const d_in[PIPE_MAX_IN], const uint8_t *d_msgs, const uint64_t *d_off,
+                      size_t msg_len, size_t m, void *stream)
+{
+    (void)d_msgs; (void)d_off; (void)msg_len;
+    return x25519_batch_dev(d_out, d_in[0], d_in[1], m, stream);
+}
+#define RUN_1IN(name, devfn) \
+static int name(uint8_t *d_out, uint8_t *const d_in[PIPE_MAX_IN], const uint8_t *d_msgs, const uint64_t *d_off, \
+                size_t msg_len, size_t m, void *stream) \
+{ (void)d_msgs; (void)d_off; (void)msg_len; return devfn(d_out, d_in[0], m, stream); }
+RUN_1IN(run_genpub, ed25519_genpub_batch_dev)
+RUN_1IN(run_xbase, x25519_base_batch_dev)
+RUN_1IN(run_pk_to_x, pk_ed25519_to_x25519_batch_dev)
+RUN_1IN(run_sk_to_x, sk_ed25519_to_x25519_batch_dev)
 
 int ed25519_verify_batch(uint8_t *ok, const uint8_t *sigs, const uint8_t *pubs, const uint8_t *msgs,
                          const uint64_t *msg_off, size_t msg_len, size_t n)
 {
-    struct staging st = { {0}, 0 };
-    uint8_t *d_ok, *d_sig, *d_pub, *d_msg; uint64_t *d_off = NULL;
-    int rc = ensure_init();
-    if (rc || n == 0) return rc;
-    STAGE(d_ok, NULL, n);
-    STAGE(d_sig, sigs, 64 * n);
-    STAGE(d_pub, pubs, 32 * n);
-    STAGE(d_msg, msgs, msgs_total(msg_off, msg_len, n));
-    if (msg_off) STAGE(d_off, msg_off, (n + 1) * sizeof(uint64_t));
-    rc = ed25519_verify_batch_dev(d_ok, d_sig, d_pub, d_msg, d_off, msg_len, n, NULL);
-    if (rc) goto out;
-    TRY(hipMemcpy(ok, d_ok, n, hipMemcpyDeviceToHost));
-out:
-    staging_free(&st);
-    return rc;
+    struct hjob j = { 2, { sigs, pubs, NULL }, { 64, 32, 0 }, 1, msgs, msg_off, msg_len, ok, 1, run_verify };
+    return pipe_run(&j, n);
 }
 
 int ed25519_sign_batch(uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs, const uint8_t *msgs,
                        const uint64_t *msg_off, size_t msg_len, size_t n)
 {
-    struct staging st = { {0}, 0 };
-    uint8_t *d_sig, *d_sec, *d_pub, *d_msg; uint64_t *d_off = NULL;
-    int rc = ensure_init();
-    if (rc || n == 0) return rc;
-    STAGE(d_sig, NULL, 64 * n);
-    STAGE(d_sec, secs, 32 * n);
-    STAGE(d_pub, pubs, 32 * n);
-    STAGE(d_msg, msgs, msgs_total(msg_off, msg_len, n));
-    if (msg_off) STAGE(d_off, msg_off, (n + 1) * sizeof(uint64_t));
-    rc = ed25519_sign_batch_dev(d_sig, d_sec, d_pub, d_msg, d_off, msg_len, n, NULL);
-    if (rc) goto out;
-    TRY(hipMemcpy(sigs, d_sig, 64 * n, hipMemcpyDeviceToHost));
-out:
-    staging_free(&st);
-    return rc;
-}
-
-/* 32 bytes in -> 32 bytes out, one or two inputs */
-typedef int (*dev1_fn)(uint8_t *, const uint8_t *, size_t, void *);
-
-static int run_1in(dev1_fn fn, uint8_t *out, const uint8_t *in, size_t n)
-{
-    struct staging st = { {0}, 0 };
-    uint8_t *d_out, *d_in;
-    int rc = ensure_init();
-    if (rc || n == 0) return rc;
-    STAGE(d_out, NULL, 32 * n);
-    STAGE(d_in, in, 32 * n);
-    rc = fn(d_out, d_in, n, NULL);
-    if (rc) goto out;
-    TRY(hipMemcpy(out, d_out, 32 * n, hipMemcpyDeviceToHost));
-out:
-    staging_free(&st);
-    return rc;
-}
-
-int ed25519_genpub_batch(uint8_t *pubs, const uint8_t *secs, size_t n)
-{
-    return run_1in(ed25519_genpub_batch_dev, pubs, secs, n);
-}
-
-int x25519_base_batch(uint8_t *out, const uint8_t *scalars, size_t n)
-{
-    return run_1in(x25519_base_batch_dev, out, scalars, n);
-}
-
-int pk_ed25519_to_x25519_batch(uint8_t *out, const uint8_t *in, size_t n)
-{
-    return run_1in(pk_ed25519_to_x25519_batch_dev, out, in, n);
-}
-
-int sk_ed25519_to_x25519_batch(uint8_t *out, const uint8_t *in, size_t n)
-{
-    return run_1in(sk_ed25519_to_x25519_batch_dev, out, in, n);
+    struct hjob j = { 2, { secs, pubs, NULL }, { 32, 32, 0 }, 1, msgs, msg_off, msg_len, sigs, 64, run_sign };
+    return pipe_run(&j, n);
 }
 
 int x25519_batch(uint8_t *out, const uint8_t *scalars, const uint8_t *points, size_t n)
 {
-    struct staging st = { {0}, 0 };
-    uint8_t *d_out, *d_s, *d_p;
-    int rc = ensure_init();
-    if (rc || n == 0) return rc;
-    STAGE(d_out, NULL, 32 * n);
-    STAGE(d_s, scalars, 32 * n);
-    STAGE(d_p, points, 32 * n);
-    rc = x25519_batch_dev(d_out, d_s, d_p, n, NULL);
-    if (rc) goto out;
-    TRY(hipMemcpy(out, d_out, 32 * n, hipMemcpyDeviceToHost));
-out:
-    staging_free(&st);
-    return rc;
+    struct hjob j = { 2, { scalars, points, NULL }, { 32, 32, 0 }, 0, NULL, NULL, 0, out, 32, run_x25519 };
+    return pipe_run(&j, n);
 }
+
+static int run_1in(int (*run)(uint8_t *, uint8_t *const *, const uint8_t *, const uint64_t *, size_t, size_t, void *),
+                   uint8_t *out, const uint8_t *in, size_t n)
+{
+    struct hjob j = { 1, { in, NULL, NULL }, { 32, 0, 0 }, 0, NULL, NULL, 0, out, 32, run };
+    return pipe_run(&j, n);
+}
+
+int ed25519_genpub_batch(uint8_t *pubs, const uint8_t *secs, size_t n) { return run_1in(run_genpub, pubs, secs, n); }
+int x25519_base_batch(uint8_t *out, const uint8_t *scalars, size_t n) { return run_1in(run_xbase, out, scalars, n); }
+int pk_ed25519_to_x25519_batch(uint8_t *out, const uint8_t *in, size_t n) { return run_1in(run_pk_to_x, out, in, n); }
+int sk_ed25519_to_x25519_batch(uint8_t *out, const uint8_t *in, size_t n) { return run_1in(run_sk_to_x, out, in, n); }
 
 /* ------------------------------------------------------------------------------------------
  * the eddsa.h surface: batches of one.  No error channel in these signatures, so fail loudly.

@@ -134,7 +134,7 @@ ok = torch.from_numpy((np.arange(lo, hi) % 16 != 5).astype(np.uint8))
 allok = gather_bytes(ok, n)
 assert allok.shape == (n,) and int(allok.sum()) == int((np.arange(n) % 16 != 5).sum())
 dist.destroy_process_group()
-print("rank", rank, "ok")
+open(os.path.join(os.environ["OUT_DIR"], f"rank{rank}.ok"), "w").write("ok")
 '''
 
 
@@ -157,7 +157,7 @@ elapsed, out = bench.timed_region(step, 4, world, lambda: None, torch.device("cp
 assert len(calls) == 4                                   # exactly K steps
 assert 0.39 < elapsed < 1.5, elapsed                     # the MAX over ranks (4 x 0.1 s), on every rank
 dist.destroy_process_group()
-print("rank", rank, "ok")
+open(os.path.join(os.environ["OUT_DIR"], f"rank{rank}.ok"), "w").write("ok")
 '''
 
 
@@ -175,17 +175,17 @@ def test_bench_timing_and_gather_helpers_over_gloo(tmp_path):
     """bench.py's N > 1 plumbing (barrier-bracketed region, max over ranks, result all-gather)"""
     script = tmp_path / "bench_worker.py"
     script.write_text(_BENCH_WORKER)
-    env = dict(os.environ, REPO=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    env = dict(os.environ, REPO=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", OUT_DIR=str(tmp_path))
     r = _torchrun(script, env)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
 
 
 def test_two_rank_shard_and_gather_over_gloo(oracle, tmp_path):
     """N > 1 path: contiguous shards, independent compute, one all-gather of the result bytes."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, REPO=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    env = dict(os.environ, REPO=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", OUT_DIR=str(tmp_path))
     r = _torchrun(script, env)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
