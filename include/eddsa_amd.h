@@ -59,6 +59,13 @@ EDDSA_AMD_DECL const char *eddsa_amd_strerror(int err);
  * 10 radix-2^25.5 limbs of y-x, y+x, 2dxy, then 2 words of padding. */
 EDDSA_AMD_DECL int eddsa_amd_dump_tables(uint32_t *base16_words, uint32_t *comb_words);
 
+/* How ed25519_verify* treats a public key that does not decode to a curve point (the reference's
+ * ed_import never fails, lib/ed.c:100-149).  exact != 0 (default): such items are evaluated in the
+ * reference's own order of operations -- the only way to reproduce its bytes for them.  exact == 0:
+ * they are rejected outright, which differs from the reference only on a SHA-512 fixed point and
+ * saves about 1 ms per pass that contains such keys. */
+EDDSA_AMD_DECL void eddsa_amd_set_offcurve_mode(int exact);
+
 /* measurement aid: when on, HIP events are recorded on the launch stream around the three kernels
  * of every verify pass (up to 256 passes); eddsa_amd_verify_phase_ms() waits for them and returns
  * the average duration of each kernel (prepare, main, finish) in milliseconds. */

@@ -27,6 +27,7 @@ from .api import (  # noqa: F401
     pk_ed25519_to_x25519,
     pk_ed25519_to_x25519_batch,
     sk_ed25519_to_x25519,
+    set_offcurve_mode,
     set_profiling,
     sk_ed25519_to_x25519_batch,
     verify_phase_ms,

@@ -69,6 +69,12 @@ def verify_phase_ms():
     return tuple(out)
 
 
+def set_offcurve_mode(exact=True):
+    """exact=True (default): off-curve public keys are verified in the reference's own operation
+    order; False: they are rejected outright (differs only on a SHA-512 fixed point)."""
+    library().eddsa_amd_set_offcurve_mode(int(bool(exact)))
+
+
 def set_profiling(on):
     library().eddsa_amd_set_profiling(int(bool(on)))
 

@@ -53,7 +53,12 @@ static void ws_release(struct engine *e)
     if (e->ws.table) (void)hipFree(e->ws.table);
     if (e->ws.acc) (void)hipFree(e->ws.acc);
     if (e->ws.flags) (void)hipFree(e->ws.flags);
-    memset(&e->ws, 0, sizeof(e->ws));
+    if (e->ws.offlist) (void)hipFree(e->ws.offlist);
+    if (e->ws.offcount) (void)hipFree(e->ws.offcount);
+    if (e->ws.exact_pad) (void)hipFree(e->ws.exact_pad);
+    e->ws.capacity = 0;
+    e->ws.digits = e->ws.table = e->ws.acc = e->ws.offlist = e->ws.offcount = e->ws.exact_pad = NULL;
+    e->ws.flags = NULL;
 }
 
 static void fws_release(struct engine *e)
@@ -94,6 +99,9 @@ static int ws_reserve(struct engine *e, size_t items)
     TRY(hipMalloc((void **)&e->ws.table, cap / VERIFY_TILE * (size_t)VERIFY_TABLE_WORDS_PER_TILE * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&e->ws.acc, cap * 30 * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&e->ws.flags, cap));
+    TRY(hipMalloc((void **)&e->ws.offlist, cap * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&e->ws.offcount, 256));
+    TRY(hipMalloc((void **)&e->ws.exact_pad, EDK_EXACT_PAD_BYTES));
     e->ws.capacity = cap;
 out:
     if (rc) ws_release(e);
@@ -109,6 +117,7 @@ int eddsa_amd_init(int device)
     if (g_eng.ready) {                /* re-bind to another device */
         ws_release(&g_eng); fws_release(&g_eng);
         (void)hipFree(g_eng.base16); (void)hipFree(g_eng.comb); (void)hipEventDestroy(g_eng.ws_free);
+        (void)hipStreamDestroy(g_eng.ws.side); (void)hipEventDestroy(g_eng.ws.ev_prepared); (void)hipEventDestroy(g_eng.ws.ev_exact);
         memset(&g_eng, 0, sizeof(g_eng));
     }
     TRY(hipSetDevice(device));
@@ -117,6 +126,15 @@ int eddsa_amd_init(int device)
     TRY(hipMalloc((void **)&g_eng.base16, (size_t)TABLE_BASE16_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&g_eng.comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t)));
     TRY(hipEventCreateWithFlags(&g_eng.ws_free, hipEventDisableTiming));
+    {   /* highest queue priority: its few workgroups must be dispatched while k_verify_main still
+         * has thousands waiting, not after them */
+        int lo = 0, hi = 0;
+        TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        TRY(hipStreamCreateWithPriority(&g_eng.ws.side, hipStreamNonBlocking, hi));
+    }
+    TRY(hipEventCreateWithFlags(&g_eng.ws.ev_prepared, hipEventDisableTiming));
+    TRY(hipEventCreateWithFlags(&g_eng.ws.ev_exact, hipEventDisableTiming));
+    g_eng.ws.exact_offcurve = 1;
     for (int s = 0; s < MARK_SLOTS; s++)
         for (int i = 0; i < 4; i++) TRY(hipEventCreate(&g_eng.marks[s][i]));
     TRY(edk_init_tables(g_eng.base16, g_eng.comb, NULL));
@@ -137,6 +155,7 @@ void eddsa_amd_shutdown(void)
         pipe_release();
         ws_release(&g_eng); fws_release(&g_eng);
         (void)hipFree(g_eng.base16); (void)hipFree(g_eng.comb); (void)hipEventDestroy(g_eng.ws_free);
+        (void)hipStreamDestroy(g_eng.ws.side); (void)hipEventDestroy(g_eng.ws.ev_prepared); (void)hipEventDestroy(g_eng.ws.ev_exact);
         memset(&g_eng, 0, sizeof(g_eng));
     }
     pthread_mutex_unlock(&g_lock);
@@ -159,6 +178,19 @@ int eddsa_amd_dump_tables(uint32_t *base16_words, uint32_t *comb_words)
     TRY(hipMemcpy(comb_words, g_eng.comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
 out:
     return rc;
+}
+
+/* How verify treats a public key that does not decode to a curve point (ed_import never fails,
+ * reference lib/ed.c:100-149).  EXACT (default): such items are evaluated in the reference's own
+ * order of operations, which is the only way to reproduce its bytes there.  REJECT: they are
+ * rejected outright; this differs from the reference only if encode(C) == R for a C that depends on
+ * SHA-512(R || A || M), i.e. on a fixed point of a random function, and saves the ~1 ms the exact
+ * pass costs whenever a batch contains such keys. */
+void eddsa_amd_set_offcurve_mode(int exact)
+{
+    pthread_mutex_lock(&g_lock);
+    g_eng.ws.exact_offcurve = exact != 0;
+    pthread_mutex_unlock(&g_lock);
 }
 
 /* per-kernel timing of the verify pass, for bench.py's roofline line: HIP events recorded on the

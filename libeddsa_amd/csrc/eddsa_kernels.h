@@ -22,6 +22,8 @@ extern "C" {
 hipError_t edk_init_tables(uint32_t* base16, uint32_t* comb, hipStream_t stream);
 hipError_t edk_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* points, size_t n,
                       hipStream_t stream);
+#define EDK_EXACT_PAD_BYTES ((size_t)1024 * 64 * (160 + 2 * ((261 + 3) / 4)) * 4)
+
 /* verify workspace for up to `capacity` items (a multiple of VERIFY_TILE), all in HBM */
 typedef struct edk_verify_ws {
   size_t capacity;
@@ -29,6 +31,12 @@ typedef struct edk_verify_ws {
   uint32_t* table;    /* capacity / 256 tiles * VERIFY_TABLE_WORDS_PER_TILE words */
   uint32_t* acc;      /* capacity * 30 words */
   uint8_t* flags;     /* capacity bytes */
+  uint32_t* offlist;  /* capacity words: items whose key is off the curve */
+  uint32_t* offcount; /* 1 word */
+  uint32_t* exact_pad;/* EDK_EXACT_PAD_BYTES: per-lane scratchpad of k_verify_exact */
+  hipStream_t side;   /* the exact path runs here, beside the main kernel */
+  hipEvent_t ev_prepared, ev_exact;
+  int exact_offcurve; /* 1: replay the reference's chain for off-curve keys (default); 0: reject them */
 } edk_verify_ws;
 
 hipError_t edk_verify(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs,

@@ -92,17 +92,20 @@ __global__ void __launch_bounds__(64) k_init_tables(uint32_t* base16, uint32_t* 
 //   k_verify_prepare  hash, scalars -> digit words, decompress -A, table of 0..8 * -A
 //   k_verify_main     the 252 doublings + 80 additions            (~85 % of the time)
 //   k_verify_finish   invert Z (shared by 8 items per lane), encode, compare with R
+//   k_verify_exact    (side stream, beside main) the reference's own chain for the items whose key
+//                     is not a curve point; owns their verdict bytes
 // Workspace (HBM; tile = 256 items):
 //   digits [item][16]                  t + 0x88.., S + 0x80.. as little-endian words
 //   table  [item][entry 9][word 40]    1440 contiguous bytes per item
 //   acc    [tile][word 30][lane 256]   X, Y, Z of the result
-//   flags  [item]                      1 = A decoded to a curve point
+//   flags  [item]                      bit 0: A decoded to a curve point; bit 1: Z usable (set by finish)
+//   offlist[..], offcount              items whose A is off the curve, for k_verify_exact
 // ---------------------------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(BLOCK, 2)
 k_verify_prepare(const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs,
                  const uint64_t* msg_off, size_t msg_len, size_t n, uint32_t* digits,
-                 uint32_t* table, uint8_t* flags) {
+                 uint32_t* table, uint8_t* flags, uint32_t* offlist, uint32_t* offcount) {
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const size_t item = i < n ? i : n - 1;         // idle lanes redo the last item into their own slot
   uint32_t rw[8], aw[8], sw[8], tw[8];
@@ -117,21 +120,52 @@ k_verify_prepare(const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs,
   d[0] = make_uint4(tw[0], tw[1], tw[2], tw[3]); d[1] = make_uint4(tw[4], tw[5], tw[6], tw[7]);
   d[2] = make_uint4(sw[0], sw[1], sw[2], sw[3]); d[3] = make_uint4(sw[4], sw[5], sw[6], sw[7]);
   flags[i] = (uint8_t)oncurve;
+  // keys that are not curve points go to the exact (reference-order) kernel: append to its work list
+  if (!oncurve && i < n) offlist[atomicAdd(offcount, 1u)] = (uint32_t)i;
+}
+
+// ed25519-sha512.c:148-181 replayed in the reference's own order (lanes.h verify_exact_lane) for
+// the items listed by k_verify_prepare.  Each item is one long serial chain (261 add + double
+// steps), so the kernel is latency-bound: about 1.3 ms for any number of items up to the chip's
+// width.  It runs on a high-priority side stream beside k_verify_main, as single-wave blocks capped
+// at 128 VGPRs (loop invariants and digit strings in a small HBM/L2 scratchpad, the rest spills)
+// so that its waves fit the slots k_verify_main's waves free, with a small grid striding over the
+// work list.  Measured alternatives (256-VGPR blocks, LDS-resident invariants, setup/chain split,
+// chain blocks inside k_verify_main's grid, plain serial execution) were all slower for the pass as
+// a whole: DESIGN.md "Off-curve public keys".
+constexpr int EXACT_BLOCK = 64;
+constexpr int EXACT_MAX_BLOCKS = 1024;
+constexpr int EXACT_PAD_WORDS = 160 + 2 * ((REF_JSF_LEN + 3) / 4);   /* per lane: 4 addends + 2 digit strings */
+
+__global__ void __launch_bounds__(EXACT_BLOCK, 4)
+k_verify_exact(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs,
+               const uint64_t* msg_off, size_t msg_len, const uint32_t* offlist, const uint32_t* offcount,
+               const uint32_t* base16, uint32_t* pad) {
+  const size_t count = *offcount;
+  // this wave's scratchpad, lane-interleaved (element k of lane t at [k * 64 + t]: coalesced)
+  uint32_t* base = pad + (size_t)blockIdx.x * (EXACT_PAD_WORDS * EXACT_BLOCK);
+  uint32_t* pts = base + threadIdx.x;
+  int8_t* ux = reinterpret_cast<int8_t*>(base + 160 * EXACT_BLOCK) + threadIdx.x;
+  int8_t* uy = ux + REF_JSF_LEN * EXACT_BLOCK;
+  for (size_t g = (size_t)blockIdx.x * EXACT_BLOCK + threadIdx.x; g < count; g += (size_t)gridDim.x * EXACT_BLOCK) {
+    const size_t i = offlist[g];
+    uint32_t rw[8], sw[8], aw[8];
+    load32(rw, sigs, i, 64);
+    load32(sw, sigs + 32, i, 64);
+    load32(aw, pubs, i, 32);
+    const uint8_t* m; size_t mlen;
+    msg_span(m, mlen, msgs, msg_off, msg_len, i);
+    ok[i] = (uint8_t)verify_exact_lane(rw, sw, aw, m, mlen, base16 + TABLE_ENTRY_WORDS, ux, uy, pts, EXACT_BLOCK);
+  }
 }
 
 __global__ void __launch_bounds__(BLOCK, 4)
 k_verify_main(const uint32_t* digits, const uint32_t* table, const uint32_t* base16, uint32_t* accout) {
-  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;   // < workspace capacity
-  uint32_t tw[8], sw[8];
-  {
-    const uint4* d = reinterpret_cast<const uint4*>(digits + 16 * i);
-    const uint4 a = d[0], b = d[1], c = d[2], e = d[3];
-    tw[0] = a.x; tw[1] = a.y; tw[2] = a.z; tw[3] = a.w; tw[4] = b.x; tw[5] = b.y; tw[6] = b.z; tw[7] = b.w;
-    sw[0] = c.x; sw[1] = c.y; sw[2] = c.z; sw[3] = c.w; sw[4] = e.x; sw[5] = e.y; sw[6] = e.z; sw[7] = e.w;
-  }
+  const size_t tile = blockIdx.x;
+  const size_t i = tile * BLOCK + threadIdx.x;   // < workspace capacity
   ge acc;
-  verify_main_lane(acc, tw, sw, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16);
-  uint32_t* o = accout + (size_t)blockIdx.x * (30 * BLOCK) + threadIdx.x;
+  verify_main_lane(acc, digits + 16 * i, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16);
+  uint32_t* o = accout + tile * (30 * BLOCK) + threadIdx.x;
 #pragma unroll
   for (int j = 0; j < 10; j++) {
     o[j * BLOCK] = acc.X.v[j]; o[(10 + j) * BLOCK] = acc.Y.v[j]; o[(20 + j) * BLOCK] = acc.Z.v[j];
@@ -224,18 +258,20 @@ ED_DEV void den_commit(fe& z, bool good, uint32_t* acc, int k) {
 }
 
 // verify: encode and compare with R as bytes (ed25519-sha512.c:176-180): a non-canonical R can
-// never match.  An off-curve A is rejected outright (DESIGN.md "Off-curve public keys"); Z = 0
-// cannot occur for a curve point (the a = -1 law is complete).
+// never match.  Items whose A is off the curve are skipped here (k_verify_exact writes their
+// verdict; DESIGN.md "Off-curve public keys"); Z = 0 cannot occur for a curve point (the a = -1 law
+// is complete) and is rejected defensively.
 struct verify_finish_policy {
-  uint8_t* ok; const uint8_t* sigs; uint32_t* acc; uint8_t* flags; size_t n;
+  uint8_t* ok; const uint8_t* sigs; uint32_t* acc; uint8_t* flags; size_t n; int exact_offcurve;
   ED_DEV void den(int k, fe& z) const {
     const finish_pos p = finish_at(k, acc);
     fe_set(z, 1);
     bool good = false;
     if (p.i < n) {
       acc_load(z, p.acc, 2);
-      good = flags[p.i] != 0 && !fe_iszero(z);
-      flags[p.i] = (uint8_t)good;                // phase B reads it back
+      const uint8_t fl = flags[p.i];
+      good = (fl & 1) != 0 && !fe_iszero(z);
+      flags[p.i] = (uint8_t)((fl & 1) | (good ? 2 : 0));   // phase B reads it back
     }
     den_commit(z, good, acc, k);
   }
@@ -246,13 +282,18 @@ struct verify_finish_policy {
     acc_load(x, p.acc, 0); acc_load(y, p.acc, 1); acc_load(zinv, p.acc, 2);
     uint32_t rw[8];
     load32(rw, sigs, p.i, 64);
-    ok[p.i] = (uint8_t)(verify_encode_lane(x, y, zinv, rw) && flags[p.i] != 0);
+    const uint8_t fl = flags[p.i];
+    if ((fl & 1) == 0) {                         // off-curve key
+      if (!exact_offcurve) ok[p.i] = 0;          // reject mode; otherwise k_verify_exact owns ok[i]
+      return;
+    }
+    ok[p.i] = (uint8_t)(verify_encode_lane(x, y, zinv, rw) && (fl & 2) != 0);
   }
 };
 
 __global__ void __launch_bounds__(BLOCK, 2)
-k_verify_finish(uint8_t* ok, const uint8_t* sigs, uint32_t* acc, uint8_t* flags, size_t n) {
-  finish_batch8(verify_finish_policy{ok, sigs, acc, flags, n}, acc);
+k_verify_finish(uint8_t* ok, const uint8_t* sigs, uint32_t* acc, uint8_t* flags, size_t n, int exact_offcurve) {
+  finish_batch8(verify_finish_policy{ok, sigs, acc, flags, n, exact_offcurve}, acc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -457,16 +498,27 @@ hipError_t edk_verify(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, con
                       const edk_verify_ws* ws, hipEvent_t* marks, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   const unsigned blocks = (unsigned)((n + BLOCK - 1) / BLOCK);
+  (void)hipMemsetAsync(ws->offcount, 0, sizeof(uint32_t), stream);
   if (marks) (void)hipEventRecord(marks[0], stream);
   hipLaunchKernelGGL(k_verify_prepare, dim3(blocks), dim3(BLOCK), 0, stream, sigs, pubs, msgs, msg_off,
-                     msg_len, n, ws->digits, ws->table, ws->flags);
+                     msg_len, n, ws->digits, ws->table, ws->flags, ws->offlist, ws->offcount);
   if (marks) (void)hipEventRecord(marks[1], stream);
-  hipLaunchKernelGGL(k_verify_main, dim3(blocks), dim3(BLOCK), 0, stream, ws->digits, ws->table, base16,
-                     ws->acc);
+  // the exact path depends only on prepare: run it beside the main kernel on the side stream
+  if (ws->exact_offcurve) {
+    const unsigned eb = (unsigned)((n + EXACT_BLOCK - 1) / EXACT_BLOCK);
+    (void)hipEventRecord(ws->ev_prepared, stream);
+    (void)hipStreamWaitEvent(ws->side, ws->ev_prepared, 0);
+    hipLaunchKernelGGL(k_verify_exact, dim3(eb < (unsigned)EXACT_MAX_BLOCKS ? eb : (unsigned)EXACT_MAX_BLOCKS),
+                       dim3(EXACT_BLOCK), 0, ws->side, ok, sigs, pubs, msgs, msg_off, msg_len, ws->offlist,
+                       ws->offcount, base16, ws->exact_pad);
+    (void)hipEventRecord(ws->ev_exact, ws->side);
+  }
+  hipLaunchKernelGGL(k_verify_main, dim3(blocks), dim3(BLOCK), 0, stream, ws->digits, ws->table, base16, ws->acc);
   if (marks) (void)hipEventRecord(marks[2], stream);
   hipLaunchKernelGGL(k_verify_finish, dim3((blocks + FINISH_K - 1) / FINISH_K), dim3(BLOCK), 0, stream, ok, sigs,
-                     ws->acc, ws->flags, n);
+                     ws->acc, ws->flags, n, ws->exact_offcurve);
   if (marks) (void)hipEventRecord(marks[3], stream);
+  if (ws->exact_offcurve) (void)hipStreamWaitEvent(stream, ws->ev_exact, 0);   // complete when both paths are
   return hipGetLastError();
 }
 

@@ -8,6 +8,7 @@
 //   verify_prepare_lane    ed25519-sha512.c:148-172 (hash, scalars, import of -A) + table 0..8 * -A
 //   verify_main_lane       ed.c:455-507 ed_dual_scale (windowed, uniform control flow)
 //   verify_encode_lane     ed.c:155-169 ed_export + ed25519-sha512.c:176-180 (given 1/Z)
+//   verify_exact_lane      the reference's own JSF/Shamir chain, for keys that are not on the curve
 //   scale_base_lane        ed.c:397-430 ed_scale_base (comb, constant-time select)
 //   genpub_point_lane, sign_point_lane, sign_finish_lane, encode_lane   ed25519-sha512.c:53-123
 //   x25519_base_point_lane, x25519_base_finish_lane                      x25519.c:158-197
@@ -215,9 +216,10 @@ ED_DEV bool verify_prepare_lane(uint32_t tw[8], uint32_t sw[8], uint32_t* tab, c
   return oncurve;
 }
 
-// tw, sw: digit words (consumed); tab: this item's table; base16: the k*B table
-ED_DEV void verify_main_lane(ge& acc, uint32_t tw[8], uint32_t sw[8], const uint32_t* tab,
-                             const uint32_t* base16) {
+// digits: the 16 digit words of this item (t + 0x88.. in [0,8), S + 0x8000.. in [8,16)), read from
+// memory window by window rather than held in 16 registers (that is what lets the kernel fit 128
+// VGPRs without scratch); tab: this item's table; base16: the k*B table
+ED_DEV void verify_main_lane(ge& acc, const uint32_t* digits, const uint32_t* tab, const uint32_t* base16) {
   ge_neutral(acc);
 #pragma unroll 1
   for (int w = 63; w >= 0; w--) {
@@ -226,8 +228,7 @@ ED_DEV void verify_main_lane(ge& acc, uint32_t tw[8], uint32_t sw[8], const uint
       for (int k = 0; k < 4; k++) ge_dbl(acc, acc, k == 3);
     }
     {
-      const int dig = (int)(tw[7] >> 28) - 8;
-      shl256<4>(tw);
+      const int dig = (int)((digits[w >> 3] >> (4 * (w & 7))) & 15u) - 8;
       const uint32_t mag = (uint32_t)(dig < 0 ? -dig : dig);
       ge_cached c;
       cached_load(c, tab, mag);
@@ -235,8 +236,8 @@ ED_DEV void verify_main_lane(ge& acc, uint32_t tw[8], uint32_t sw[8], const uint
       ge_add_cached(acc, acc, c, (w & 3) == 0);
     }
     if ((w & 3) == 0) {
-      const int dig = (int)(sw[7] >> 16) - 32768;
-      shl256<16>(sw);
+      const int j = w >> 2;                        // digit j of S sits at bit 16 j
+      const int dig = (int)((digits[8 + (j >> 1)] >> (16 * (j & 1))) & 0xffffu) - 32768;
       const uint32_t mag = (uint32_t)(dig < 0 ? -dig : dig);
       ge_niels nb;
       niels_load(nb, base16 + TABLE_ENTRY_WORDS * mag);
@@ -258,6 +259,273 @@ ED_DEV bool verify_encode_lane(const fe& X, const fe& Y, const fe& zinv, const u
 #pragma unroll
   for (int q = 0; q < 8; q++) diff |= cw[q] ^ rw[q];
   return diff == 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact path for public keys that are NOT on the curve (slow, rare, data-dependent control flow)
+// ---------------------------------------------------------------------------------------------
+// ed_import (ed.c:100-149) never fails: when neither candidate root fits it keeps j*beta and the
+// reference then applies its addition formulas to a pair (x,y) that is not a curve point.  The
+// result is no longer independent of the evaluation order, so for those keys -- and only those --
+// the reference's own chain is replayed formula by formula: joint-sparse-form digits produced one
+// 52-bit limb at a time (sc.c:297-324, 64-bit build), Shamir's trick over B, Q+B, Q-B and pc(Q)
+// (ed.c:455-507) with ed_add / ed_sub / ed_double / ed_add_pc / ed_sub_pc exactly as written
+// (ed.c:175-335).  All values are field elements, so the limb representation does not matter.
+
+// ed.c:175-203 ed_add (sub = false) / ed.c:245-273 ed_sub (sub = true)
+ED_DEV void ref_add(ge& o, const ge& p, const ge& q, bool sub) {
+  fe a, b, c, d, e, f, g, h, qm, qp;
+  fe_sub(qm, q.Y, q.X);                          // 3u
+  fe_add(qp, q.Y, q.X);                          // 2u
+  fe_sub(a, p.Y, p.X);
+  fe_mul(a, a, sub ? qp : qm);
+  fe_add(b, p.Y, p.X);
+  fe_mul(b, b, sub ? qm : qp);
+  fe_mul(c, p.T, q.T);
+  fe_mul(c, c, fe_const_2d());                   // ed_sub multiplies by -2d: handled by swapping f and g
+  fe_mul(d, p.Z, q.Z);
+  fe_add(d, d, d);                               // 2u
+  fe_sub(e, b, a);                               // 3u
+  fe_sub(f, d, c);                               // 4u: first operand only
+  fe_add(g, d, c);                               // 3u
+  fe_add(h, b, a);                               // 2u
+  if (sub) { fe t = f; f = g; g = t; fe_carry(f); fe_carry(g); }
+  fe_mul(o.X, f, e);
+  fe_mul(o.Y, h, g);
+  fe_mul(o.T, h, e);
+  fe_mul(o.Z, f, g);
+}
+
+// ed.c:211-237 ed_double: the addition law with P = Q (4 S + 5 M)
+ED_DEV void ref_double(ge& o, const ge& p) {
+  fe a, b, c, d, e, f, g, h;
+  fe_sub(a, p.Y, p.X); fe_sq(a, a);
+  fe_add(b, p.Y, p.X); fe_sq(b, b);
+  fe_sq(c, p.T); fe_mul(c, c, fe_const_2d());
+  fe_sq(d, p.Z); fe_add(d, d, d);                // 2u
+  fe_sub(e, b, a);                               // 3u
+  fe_sub(f, d, c);                               // 4u
+  fe_add(g, d, c);                               // 3u
+  fe_add(h, b, a);                               // 2u
+  fe_mul(o.X, f, e);
+  fe_mul(o.Y, h, g);
+  fe_mul(o.T, h, e);
+  fe_mul(o.Z, f, g);
+}
+
+// ed.c:282-305 ed_add_pc / ed.c:310-335 ed_sub_pc
+ED_DEV void ref_add_pc(ge& o, const ge& p, const ge_niels& q, bool sub) {
+  ge_niels qq = q;
+  ge_niels_cneg(qq, sub);                        // (sum, diff, -prod): the same values ed_sub_pc uses
+  ge_add_niels(o, p, qq, true);
+}
+
+// sc.c:272-281 jsfdigit
+ED_DEV int ref_jsf_digit(uint64_t a, uint64_t b) {
+  const int u = 2 - (int)(a & 3);
+  if (u == 2) return 0;
+  if (((a & 7) == 3 || (a & 7) == 5) && (b & 3) == 2) return -u;
+  return u;
+}
+
+// limb i (52 bits) of a reduced scalar held as eight 32-bit words (sc.h:26 in the 64-bit build)
+ED_DEV uint64_t ref_limb52(const uint32_t w[8], int i) {
+  uint64_t v = 0;
+  for (int b = 0; b < 52; b++) {
+    const int bit = 52 * i + b;
+    if (bit < 256) v |= (uint64_t)((w[bit >> 5] >> (bit & 31)) & 1u) << b;
+  }
+  return v;
+}
+
+constexpr int REF_JSF_LEN = 261;
+
+// sc.c:297-324 sc_jsf, limb boundaries included (the look-ahead of jsfdigit does not cross them)
+ED_DEV int ref_jsf(int8_t* u0, int8_t* u1, const uint32_t aw[8], const uint32_t bw[8]) {
+  int64_t n0 = 0, n1 = 0;
+  int k = 0;
+  for (int i = 0; i < 5; i++) {
+    n0 += (int64_t)ref_limb52(aw, i);
+    n1 += (int64_t)ref_limb52(bw, i);
+    for (int j = 0; j < 52; j++, k++) {
+      u0[k] = (int8_t)ref_jsf_digit((uint64_t)n0, (uint64_t)n1);
+      u1[k] = (int8_t)ref_jsf_digit((uint64_t)n1, (uint64_t)n0);
+      n0 = (n0 - u0[k]) >> 1;
+      n1 = (n1 - u1[k]) >> 1;
+    }
+  }
+  u0[k] = (int8_t)ref_jsf_digit((uint64_t)n0, (uint64_t)n1);
+  u1[k] = (int8_t)ref_jsf_digit((uint64_t)n1, (uint64_t)n0);
+  while (k >= 0 && u0[k] == 0 && u1[k] == 0) k--;
+  return k;
+}
+
+// the same recoder writing digit k at [k * stride]
+ED_DEV int ref_jsf_strided(int8_t* u0, int8_t* u1, int stride, const uint32_t aw[8], const uint32_t bw[8]) {
+  int64_t n0 = 0, n1 = 0;
+  int k = 0;
+  for (int i = 0; i < 5; i++) {
+    n0 += (int64_t)ref_limb52(aw, i);
+    n1 += (int64_t)ref_limb52(bw, i);
+    for (int j = 0; j < 52; j++, k++) {
+      const int d0 = ref_jsf_digit((uint64_t)n0, (uint64_t)n1), d1 = ref_jsf_digit((uint64_t)n1, (uint64_t)n0);
+      u0[k * stride] = (int8_t)d0; u1[k * stride] = (int8_t)d1;
+      n0 = (n0 - d0) >> 1;
+      n1 = (n1 - d1) >> 1;
+    }
+  }
+  const int d0 = ref_jsf_digit((uint64_t)n0, (uint64_t)n1), d1 = ref_jsf_digit((uint64_t)n1, (uint64_t)n0);
+  u0[k * stride] = (int8_t)d0; u1[k * stride] = (int8_t)d1;
+  while (k >= 0 && u0[k * stride] == 0 && u1[k * stride] == 0) k--;
+  return k;
+}
+
+// ed.c:455-507 ed_dual_scale: r = x*B + y*Q for reduced scalars given as words, Q affine (z = 1),
+// pcB = the base point in niels form (ed.c:46-52 pced_B)
+ED_DEV void ref_dual_scale(ge& r, const uint32_t xw[8], const uint32_t yw[8], const ge& q,
+                           const ge_niels& pcB) {
+  int8_t ux[REF_JSF_LEN], uy[REF_JSF_LEN];
+  ge_neutral(r);
+  const int n = ref_jsf(ux, uy, xw, yw);
+  if (n < 0) return;
+  ge qpb, qmb;
+  ge_niels pcq;
+  ref_add_pc(qpb, q, pcB, false);
+  ref_add_pc(qmb, q, pcB, true);
+  fe_sub(pcq.ymx, q.Y, q.X); fe_carry(pcq.ymx);          // ed.c:436-442 ed_precompute
+  fe_add(pcq.ypx, q.Y, q.X); fe_carry(pcq.ypx);
+  fe_mul(pcq.t2d, q.T, fe_const_2d());
+  for (int i = n;; i--) {
+    const int a = ux[i], b = uy[i];
+    if (a == 1) {
+      if (b == 1) ref_add(r, r, qpb, false);
+      else if (b == -1) ref_add(r, r, qmb, true);
+      else ref_add_pc(r, r, pcB, false);
+    } else if (a == -1) {
+      if (b == 1) ref_add(r, r, qmb, false);
+      else if (b == -1) ref_add(r, r, qpb, true);
+      else ref_add_pc(r, r, pcB, true);
+    } else if (b == 1) ref_add_pc(r, r, pcq, false);
+    else if (b == -1) ref_add_pc(r, r, pcq, true);
+    if (i == 0) break;
+    ref_double(r, r);
+  }
+}
+
+// The same chain with uniform control flow, which is what the GPU runs (64 lanes with 64 different
+// digit strings would otherwise serialise the nine cases of every step).  Three facts make it
+// produce the reference's field values:
+//   * ed_sub(P, Q) and ed_add(P, -Q) compute the same field elements (ed.c:245-273 vs :175-203:
+//     the sums are swapped and 2d is negated, which is what negating Q.x and Q.t does);
+//   * ed_add_pc(P, pc(Q)) and ed_add(P, Q) agree when Q.z = 1 (2d*Q.t is merely multiplied in
+//     earlier, and 2*P.z*1 = 2*P.z);
+//   * all formulas are homogeneous in the accumulator, so the doublings of the neutral element
+//     above a lane's top digit rescale (X:Y:Z:T) without changing the affine result, and a step
+//     whose digits are both zero leaves the accumulator untouched (select).
+// Per-lane storage supplied by the caller (LDS on the device, so that the kernel needs neither
+// scratch memory nor more than 128 VGPRs and its waves fit the slots k_verify_main's waves free):
+//   ux, uy : 2 x REF_JSF_LEN digits, element i at [i * stride]
+//   pts    : the four loop-invariant addends Q, B, Q+B, Q-B as 4 x 40 words (X|Y|Z|T),
+//            word j of addend a at [(40 a + j) * stride]
+ED_DEV void ref_pt_store(uint32_t* pts, int stride, int a, const ge& p) {
+#pragma unroll
+  for (int j = 0; j < 10; j++) {
+    pts[(40 * a + j) * stride] = p.X.v[j];      pts[(40 * a + 10 + j) * stride] = p.Y.v[j];
+    pts[(40 * a + 20 + j) * stride] = p.Z.v[j]; pts[(40 * a + 30 + j) * stride] = p.T.v[j];
+  }
+}
+ED_DEV void ref_pt_load(ge& p, const uint32_t* pts, int stride, int a) {
+#pragma unroll
+  for (int j = 0; j < 10; j++) {
+    p.X.v[j] = pts[(40 * a + j) * stride];      p.Y.v[j] = pts[(40 * a + 10 + j) * stride];
+    p.Z.v[j] = pts[(40 * a + 20 + j) * stride]; p.T.v[j] = pts[(40 * a + 30 + j) * stride];
+  }
+}
+
+// step 1: recode the scalars and lay out the four addends (sc.c:297-324, ed.c:473-476)
+ED_DEV void ref_dual_scale_setup(const uint32_t xw[8], const uint32_t yw[8], const ge& q, const ge_niels& pcB,
+                                 int8_t* ux, int8_t* uy, uint32_t* pts, int stride) {
+  const int n = ref_jsf_strided(ux, uy, stride, xw, yw);
+  for (int i = n + 1; i < REF_JSF_LEN; i++) { ux[i * stride] = 0; uy[i * stride] = 0; }
+  ge t;
+  ref_pt_store(pts, stride, 0, q);
+  ge_base(t);                                    // B as an extended point (x, y, 1, xy)
+  ref_pt_store(pts, stride, 1, t);
+  ref_add_pc(t, q, pcB, false);
+  ref_pt_store(pts, stride, 2, t);               // Q + B
+  ref_add_pc(t, q, pcB, true);
+  ref_pt_store(pts, stride, 3, t);               // Q - B
+}
+
+// step 2: the Shamir loop of ed.c:479-506 over all REF_JSF_LEN digit positions
+ED_DEV void ref_dual_scale_chain(ge& r, const int8_t* ux, const int8_t* uy, const uint32_t* pts, int stride) {
+  ge_neutral(r);
+#pragma unroll 1
+  for (int i = REF_JSF_LEN - 1; i >= 0; i--) {
+    const int da = ux[i * stride], db = uy[i * stride];
+    const bool both = (da != 0) && (db != 0);
+    const bool skip = (da == 0) && (db == 0);
+    // which addend: 2 = Q+B (digits equal), 3 = Q-B (digits opposite), 1 = B, 0 = Q
+    const int which = both ? (da == db ? 2 : 3) : (da != 0 ? 1 : 0);
+    const bool neg = which == 2 ? (da < 0) : which == 3 ? (da > 0) : which == 1 ? (da < 0) : (db < 0);
+    ge add, sum;
+    ref_pt_load(add, pts, stride, which);
+    fe nx, nt;
+    fe_neg(nx, add.X); fe_carry(nx);
+    fe_neg(nt, add.T); fe_carry(nt);
+    fe_cmov(add.X, nx, neg); fe_cmov(add.T, nt, neg);
+    ref_add(sum, r, add, false);
+    fe_cmov(r.X, sum.X, !skip); fe_cmov(r.Y, sum.Y, !skip); fe_cmov(r.Z, sum.Z, !skip); fe_cmov(r.T, sum.T, !skip);
+    if (i != 0) ref_double(r, r);
+  }
+}
+
+ED_DEV void ref_dual_scale_uniform(ge& r, const uint32_t xw[8], const uint32_t yw[8], const ge& q,
+                                   const ge_niels& pcB, int8_t* ux, int8_t* uy, uint32_t* pts, int stride) {
+  ref_dual_scale_setup(xw, yw, q, pcB, ux, uy, pts, stride);
+  ref_dual_scale_chain(r, ux, uy, pts, stride);
+}
+
+// ed25519-sha512.c:148-175 in the reference's own order of operations, first half: hash, scalars,
+// import of -A, digits and addends into the scratchpad.  base1 = entry 1 of the k*B table.
+ED_DEV void verify_exact_setup_lane(const uint32_t rw[8], const uint32_t sraw[8], const uint32_t aw[8],
+                                    const uint8_t* m, size_t mlen, const uint32_t* base1, int8_t* ux,
+                                    int8_t* uy, uint32_t* pts, int stride) {
+  uint32_t pre[16], dig[16], tw[8], sw[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { pre[k] = rw[k]; pre[8 + k] = aw[k]; }
+  sha512_prefix_msg<16>(dig, pre, m, mlen);
+  sc t, s;
+  sc_from_words<16>(t, dig);
+  sc_from_words<8>(s, sraw);
+  sc_to_words(tw, t);
+  sc_to_words(sw, s);
+  bool oncurve;
+  ge a;
+  ge_frombytes(a, oncurve, aw, true);            // -A, as ed25519-sha512.c:174-175
+  ge_niels pcB;
+  niels_load(pcB, base1);
+  ref_dual_scale_setup(sw, tw, a, pcB, ux, uy, pts, stride);
+}
+
+// second half (ed25519-sha512.c:176-180): the chain, ed_export, comparison with R
+ED_DEV bool verify_exact_chain_lane(const uint32_t rw[8], const int8_t* ux, const int8_t* uy,
+                                    const uint32_t* pts, int stride) {
+  ge c;
+  ref_dual_scale_chain(c, ux, uy, pts, stride);
+  uint32_t cw[8];
+  ge_tobytes(cw, c);                             // fld_inv(0) = 0 as in the reference
+  uint32_t diff = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) diff |= cw[k] ^ rw[k];
+  return diff == 0;
+}
+
+ED_DEV bool verify_exact_lane(const uint32_t rw[8], const uint32_t sraw[8], const uint32_t aw[8],
+                              const uint8_t* m, size_t mlen, const uint32_t* base1, int8_t* ux, int8_t* uy,
+                              uint32_t* pts, int stride) {
+  verify_exact_setup_lane(rw, sraw, aw, m, mlen, base1, ux, uy, pts, stride);
+  return verify_exact_chain_lane(rw, ux, uy, pts, stride);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -67,11 +67,39 @@ int hc_verify(const uint8_t sig[64], const uint8_t pub[32], const uint8_t* msg, 
   rd(rw, sig); rd(sw, sig + 32); rd(aw, pub);
   const bool oncurve = verify_prepare_lane(tw, sw, tab, rw, aw, msg, len);
   ge acc;
-  verify_main_lane(acc, tw, sw, tab, tables().b16());
+  uint32_t digits[16];
+  memcpy(digits, tw, 32); memcpy(digits + 8, sw, 32);
+  verify_main_lane(acc, digits, tab, tables().b16());
   if (!oncurve || fe_iszero(acc.Z)) return 0;
   fe zinv;
   fe_inv(zinv, acc.Z);
   return verify_encode_lane(acc.X, acc.Y, zinv, rw) ? 1 : 0;
+}
+
+// the exact (reference-order) path, as k_verify_exact runs it for off-curve keys
+int hc_verify_exact(const uint8_t sig[64], const uint8_t pub[32], const uint8_t* msg, size_t len) {
+  uint32_t rw[8], sw[8], aw[8];
+  rd(rw, sig); rd(sw, sig + 32); rd(aw, pub);
+  int8_t ux[REF_JSF_LEN], uy[REF_JSF_LEN];
+  uint32_t pts[160];
+  return verify_exact_lane(rw, sw, aw, msg, len, tables().b16() + TABLE_ENTRY_WORDS, ux, uy, pts, 1) ? 1 : 0;
+}
+
+// ed_dual_scale in the reference's order on an arbitrary 32-byte "point" (cf. orc_ed_dual_scale)
+void hc_dual_scale_exact(uint8_t out[32], const uint8_t s[32], const uint8_t t[32], const uint8_t q[32], int uniform) {
+  uint32_t w[8], sw[8], tw[8], o[8];
+  sc x, y;
+  rd(w, s); sc_from_words<8>(x, w); sc_to_words(sw, x);
+  rd(w, t); sc_from_words<8>(y, w); sc_to_words(tw, y);
+  rd(w, q);
+  ge Q, R; bool oc;
+  ge_frombytes(Q, oc, w, false);
+  ge_niels pcB;
+  niels_load(pcB, tables().b16() + TABLE_ENTRY_WORDS);
+  int8_t ux[REF_JSF_LEN], uy[REF_JSF_LEN];
+  uint32_t pts[160];
+  if (uniform) ref_dual_scale_uniform(R, sw, tw, Q, pcB, ux, uy, pts, 1); else ref_dual_scale(R, sw, tw, Q, pcB);
+  ge_tobytes(o, R); wr(out, o);
 }
 
 // Montgomery's trick exactly as k_verify_finish applies it, on k <= 8 values: out[j] = 1/z[j]

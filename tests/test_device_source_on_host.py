@@ -131,6 +131,31 @@ def test_random_against_oracle(hostcheck, oracle):
     no_violations(hostcheck)
 
 
+def test_exact_chain_for_off_curve_points(hostcheck, oracle, golden):
+    """ed_dual_scale replayed in the reference's order (divergent form and the uniform form the GPU
+    runs): the encoded result equals the reference's even when the 'point' is not on the curve"""
+    k = golden("layer_kats.json")
+    rng = np.random.default_rng(31)
+    rb = lambda n: bytes(rng.integers(0, 256, n, dtype=np.uint8))  # noqa: E731
+    off = 0
+    for uniform in (0, 1):
+        for s, t, q, r in k["ed_dual_scale"]:
+            assert call(hostcheck, "hc_dual_scale_exact", 32, H(s), H(t), H(q), uniform).hex() == r
+        for i in range(120):
+            s, t, q = rb(32), rb(32), rb(32)
+            if i % 9 == 0: s = bytes(32)
+            if i % 13 == 0: t = bytes(32)
+            want = ctypes.create_string_buffer(32)
+            oracle.lib.orc_ed_dual_scale(want, s, t, q)
+            assert call(hostcheck, "hc_dual_scale_exact", 32, s, t, q, uniform) == want.raw
+            off += call(hostcheck, "hc_ed_import_export", 32, q) is not None and hostcheck.hc_ed_import_export(ctypes.create_string_buffer(32), q) == 0
+    assert off > 60                                   # plenty of genuinely off-curve inputs were exercised
+    for c in golden("verify_edges.json"):
+        msg = H(c["msg"])
+        assert hostcheck.hc_verify_exact(H(c["sig"]), H(c["pub"]), msg, SZ(len(msg))) == int(c["accept"]), c["name"]
+    no_violations(hostcheck)
+
+
 def test_tables_match_the_reference_points(hostcheck, oracle, golden):
     base16 = np.zeros((32769, 32), np.uint32); comb = np.zeros((256, 32), np.uint32)
     hostcheck.hc_tables(base16.ctypes.data_as(ctypes.c_void_p), comb.ctypes.data_as(ctypes.c_void_p))

@@ -163,6 +163,26 @@ def test_sign_verify_random_fixed_length(engine, oracle, mlen):
     assert 0 < want.sum() < n
 
 
+def test_off_curve_keys_take_the_exact_path(engine, oracle):
+    """public keys that do not decode to curve points (about half of random 32-byte strings) are
+    evaluated by k_verify_exact in the reference's own operation order; verdicts equal the oracle's,
+    which reproduces the reference's chain byte for byte on such inputs"""
+    n = 6000
+    rng = np.random.default_rng(4242)
+    sk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    msg = rng.integers(0, 256, (n, 40), dtype=np.uint8)
+    pk = oracle.genpub_batch(sk)
+    sig = oracle.sign_batch(sk, pk, msg, 40)
+    pk[::2] = rng.integers(0, 256, (n // 2, 32), dtype=np.uint8)        # garbage keys under genuine signatures
+    sig[1::4, :32] = 0                                                   # R = 32 zero bytes ...
+    sig[1::4, 32:] = rng.integers(0, 256, (len(sig[1::4]), 32), dtype=np.uint8)
+    pk[1::4] = rng.integers(0, 256, (len(pk[1::4]), 32), dtype=np.uint8)  # ... under garbage keys (the Z = 0 corner)
+    want = oracle.verify_batch(sig, pk, msg, 40)
+    assert np.array_equal(engine.ed25519_verify_batch(sig, pk, msg, msg_len=40), want)
+    assert np.array_equal(engine.ed25519_verify_batch(dev(sig), dev(pk), dev(msg), msg_len=40).cpu().numpy(), want)
+    assert want[3::4].all() and not want[::2].any()
+
+
 def test_unaligned_device_buffers(engine, oracle):
     """device pointers that are not 16-byte aligned take the byte-wise load/store path"""
     import torch
