@@ -181,6 +181,12 @@ def test_off_curve_keys_take_the_exact_path(engine, oracle):
     assert np.array_equal(engine.ed25519_verify_batch(sig, pk, msg, msg_len=40), want)
     assert np.array_equal(engine.ed25519_verify_batch(dev(sig), dev(pk), dev(msg), msg_len=40).cpu().numpy(), want)
     assert want[3::4].all() and not want[::2].any()
+    # reject mode: the same verdicts (the two modes can differ only on a SHA-512 fixed point)
+    engine.set_offcurve_mode(False)
+    try:
+        assert np.array_equal(engine.ed25519_verify_batch(sig, pk, msg, msg_len=40), want)
+    finally:
+        engine.set_offcurve_mode(True)
 
 
 def test_unaligned_device_buffers(engine, oracle):
