@@ -248,7 +248,7 @@ def main():
             "value": value, "unit": {"verify": "verifies/s", "x25519": "ops/s", "sign": "signs/s"}[op],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 limbs (radix 2^25.5), u64 accumulators", "data": "synthetic",
+            "dtype": "u32 (radix-2^25.5 limbs, u64 accumulators)", "data": "synthetic",
             "config": {"workload": f"batch=2^{args.log2n} per GPU, ed25519 {op}" if op != "x25519" else
                        f"batch=2^{args.log2n} per GPU, x25519 variable-base", "msg_len": 32 if op != "x25519" else None,
                        "items_per_gpu": n, "parallelism": f"shard{world}+allgather" if world > 1 else "single"},
