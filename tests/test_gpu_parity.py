@@ -239,3 +239,22 @@ def test_small_batch_digests(engine, golden):
     pk = engine.ed25519_genpub_batch(sk)
     assert hashlib.sha512(pk.tobytes()).hexdigest() == d["genpub_2^14"]
     assert hashlib.sha512(engine.ed25519_sign_batch(sk, pk, msg).tobytes()).hexdigest() == d["sign_2^14"]
+
+
+def test_c_program_against_eddsa_h(engine, golden, tmp_path):
+    """a plain C program written against eddsa.h / eddsa_amd.h (tests/c/selftest_dropin.c: the checks
+    of the reference's four selftests on the golden tables) linked against libeddsa_amd.so"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "selftest_dropin"
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c", "selftest_dropin.c"), "-L" + os.path.join(root, "libeddsa_amd"),
+                           "-leddsa_amd", "-Wl,-rpath," + os.path.join(root, "libeddsa_amd"), "-o", str(exe)])
+    msgs = tmp_path / "msgs.bin"
+    msgs.write_bytes(b"".join(golden_msg(i) for i in range(1024)))
+    r = subprocess.run([str(exe), os.path.join(root, "tests", "golden", "x25519_table.bin"),
+                        os.path.join(root, "tests", "golden", "ed25519_table.bin"), str(msgs)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "selftest_dropin: ok" in r.stdout
