@@ -182,3 +182,33 @@ def test_the_assertions_are_live(hostcheck):
     call(hostcheck, "hc_fe_mul_loose", 32, b"\xff" * 32, 7, b"\xff" * 32, 4)      # g = 4u > 3.36u
     assert hostcheck.hc_violations() > 0 and b"fe25519.h" in hostcheck.hc_first_violation()
     hostcheck.hc_reset()
+
+
+def test_fuzz_field_and_scalars_with_hypothesis(hostcheck, oracle):
+    """property-based: products/squares/inverses of arbitrary 256-bit strings and reductions of
+    arbitrary 32/64-byte strings mod l agree with big-integer arithmetic, with no bound violation"""
+    from hypothesis import given, settings, strategies as st
+
+    b32 = st.binary(min_size=32, max_size=32)
+
+    @settings(max_examples=300, deadline=None)
+    @given(b32, b32, st.integers(1, 7), st.integers(1, 3))
+    def mul(a, b, ka, kb):
+        x = int.from_bytes(a, "little") % 2**255 + 19 * (a[31] >> 7)
+        y = int.from_bytes(b, "little") % 2**255 + 19 * (b[31] >> 7)
+        assert call(hostcheck, "hc_fe_mul", 32, a, b) == le(x * y % P)
+        assert call(hostcheck, "hc_fe_mul_loose", 32, a, ka, b, kb) == le(ka * x * kb * y % P)
+        assert call(hostcheck, "hc_fe_sq", 32, a) == le(x * x % P)
+        assert call(hostcheck, "hc_fe_inv", 32, a) == le(pow(x % P, P - 2, P))
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.binary(min_size=64, max_size=64), b32, b32, b32)
+    def scalars(w, a, b, c):
+        assert call(hostcheck, "hc_sc_reduce", 32, w, SZ(64)) == le(int.from_bytes(w, "little") % L)
+        assert call(hostcheck, "hc_sc_reduce", 32, a, SZ(32)) == le(int.from_bytes(a, "little") % L)
+        r = (int.from_bytes(a, "little") * int.from_bytes(b, "little") + int.from_bytes(c, "little")) % L
+        assert call(hostcheck, "hc_sc_muladd", 32, a, b, c) == le(r)
+
+    mul()
+    scalars()
+    no_violations(hostcheck)

@@ -258,3 +258,52 @@ def test_c_program_against_eddsa_h(engine, golden, tmp_path):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "selftest_dropin: ok" in r.stdout
+
+
+def test_concurrent_host_threads(engine, oracle):
+    """several host threads issue batched calls at once (host-pointer pipeline and device-pointer
+    entry points on different torch streams): calls serialise on the engine's workspaces and every
+    result is still bit-exact"""
+    import threading
+    import torch
+    n = 3000
+    rng = np.random.default_rng(99)
+    sk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    msg = rng.integers(0, 256, (n, 24), dtype=np.uint8)
+    pk = oracle.genpub_batch(sk)
+    sig = oracle.sign_batch(sk, pk, msg, 24)
+    bad = sig.copy(); bad[::3, 40] ^= 1
+    want = oracle.verify_batch(bad, pk, msg, 24)
+    sc = rng.integers(0, 256, (n, 32), dtype=np.uint8); pt = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    want_x = oracle.x25519_batch(sc, pt)
+    errors = []
+
+    def host_worker():
+        try:
+            for _ in range(4):
+                assert np.array_equal(engine.ed25519_verify_batch(bad, pk, msg, msg_len=24), want)
+                assert np.array_equal(engine.ed25519_sign_batch(sk, pk, msg, msg_len=24), sig)
+                assert np.array_equal(engine.x25519_batch(sc, pt), want_x)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def dev_worker():
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                d = [dev(a) for a in (bad, pk, msg, sk, sc, pt)]
+                for _ in range(4):
+                    ok = engine.ed25519_verify_batch(d[0], d[1], d[2], msg_len=24)
+                    sg = engine.ed25519_sign_batch(d[3], d[1], d[2], msg_len=24)
+                    xo = engine.x25519_batch(d[4], d[5])
+                    st.synchronize()
+                    assert np.array_equal(ok.cpu().numpy(), want)
+                    assert np.array_equal(sg.cpu().numpy(), sig)
+                    assert np.array_equal(xo.cpu().numpy(), want_x)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=host_worker) for _ in range(2)] + [threading.Thread(target=dev_worker) for _ in range(2)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors, errors
