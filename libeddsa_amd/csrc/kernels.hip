@@ -126,13 +126,10 @@ k_verify_prepare(const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs,
 
 // ed25519-sha512.c:148-181 replayed in the reference's own order (lanes.h verify_exact_lane) for
 // the items listed by k_verify_prepare.  Each item is one long serial chain (261 add + double
-// steps), so the kernel is latency-bound: about 1.3 ms for any number of items up to the chip's
-// width.  It runs on a high-priority side stream beside k_verify_main, as single-wave blocks capped
-// at 128 VGPRs (loop invariants and digit strings in a small HBM/L2 scratchpad, the rest spills)
-// so that its waves fit the slots k_verify_main's waves free, with a small grid striding over the
-// work list.  Measured alternatives (256-VGPR blocks, LDS-resident invariants, setup/chain split,
-// chain blocks inside k_verify_main's grid, plain serial execution) were all slower for the pass as
-// a whole: DESIGN.md "Off-curve public keys".
+// steps), so the work is latency-bound: about 1.3 ms for any number of items up to the chip's
+// width.  Single-wave blocks capped at 128 VGPRs (loop invariants and digit strings in a small
+// HBM/L2 scratchpad) so that the waves fit the slots k_verify_main's waves free.  This one-kernel
+// form (everything per item, spilling) serves work lists beyond the scratchpad's 65536 slots.
 constexpr int EXACT_BLOCK = 64;
 constexpr int EXACT_MAX_BLOCKS = 1024;
 constexpr int EXACT_PAD_WORDS = 160 + 2 * ((REF_JSF_LEN + 3) / 4);   /* per lane: 4 addends + 2 digit strings */
@@ -140,14 +137,14 @@ constexpr int EXACT_PAD_WORDS = 160 + 2 * ((REF_JSF_LEN + 3) / 4);   /* per lane
 __global__ void __launch_bounds__(EXACT_BLOCK, 4)
 k_verify_exact(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs,
                const uint64_t* msg_off, size_t msg_len, const uint32_t* offlist, const uint32_t* offcount,
-               const uint32_t* base16, uint32_t* pad) {
+               const uint32_t* base16, uint32_t* pad, size_t first) {
   const size_t count = *offcount;
   // this wave's scratchpad, lane-interleaved (element k of lane t at [k * 64 + t]: coalesced)
   uint32_t* base = pad + (size_t)blockIdx.x * (EXACT_PAD_WORDS * EXACT_BLOCK);
   uint32_t* pts = base + threadIdx.x;
   int8_t* ux = reinterpret_cast<int8_t*>(base + 160 * EXACT_BLOCK) + threadIdx.x;
   int8_t* uy = ux + REF_JSF_LEN * EXACT_BLOCK;
-  for (size_t g = (size_t)blockIdx.x * EXACT_BLOCK + threadIdx.x; g < count; g += (size_t)gridDim.x * EXACT_BLOCK) {
+  for (size_t g = first + (size_t)blockIdx.x * EXACT_BLOCK + threadIdx.x; g < count; g += (size_t)gridDim.x * EXACT_BLOCK) {
     const size_t i = offlist[g];
     uint32_t rw[8], sw[8], aw[8];
     load32(rw, sigs, i, 64);
@@ -157,6 +154,44 @@ k_verify_exact(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, const uint
     msg_span(m, mlen, msgs, msg_off, msg_len, i);
     ok[i] = (uint8_t)verify_exact_lane(rw, sw, aw, m, mlen, base16 + TABLE_ENTRY_WORDS, ux, uy, pts, EXACT_BLOCK);
   }
+}
+
+// The first EXACT_MAX_BLOCKS * 64 entries of the work list take a faster route.  The register-hungry
+// but short first half (hash, scalars, import, digits, addends: about 0.1 ms whatever the count) is
+// a kernel of its own on the caller's stream right after k_verify_prepare; the long second half, the
+// chain, then needs no more than 128 VGPRs, almost unspilled, and is the ONLY kernel on the side
+// stream, so that it is dispatched together with k_verify_main's first workgroups (a kernel that
+// reaches the side queue later only runs once k_verify_main has drained).
+__global__ void __launch_bounds__(EXACT_BLOCK, 2)
+k_verify_exact_setup(const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs, const uint64_t* msg_off,
+                     size_t msg_len, const uint32_t* offlist, const uint32_t* offcount, const uint32_t* base16,
+                     uint32_t* pad) {
+  const size_t g = (size_t)blockIdx.x * EXACT_BLOCK + threadIdx.x;
+  if (g >= *offcount) return;
+  const size_t i = offlist[g];
+  uint32_t rw[8], sw[8], aw[8];
+  load32(rw, sigs, i, 64);
+  load32(sw, sigs + 32, i, 64);
+  load32(aw, pubs, i, 32);
+  const uint8_t* m; size_t mlen;
+  msg_span(m, mlen, msgs, msg_off, msg_len, i);
+  uint32_t* base = pad + (size_t)blockIdx.x * (EXACT_PAD_WORDS * EXACT_BLOCK);
+  int8_t* ux = reinterpret_cast<int8_t*>(base + 160 * EXACT_BLOCK) + threadIdx.x;
+  verify_exact_setup_lane(rw, sw, aw, m, mlen, base16 + TABLE_ENTRY_WORDS, ux, ux + REF_JSF_LEN * EXACT_BLOCK,
+                          base + threadIdx.x, EXACT_BLOCK);
+}
+
+__global__ void __launch_bounds__(EXACT_BLOCK, 4)
+k_verify_exact_chain(uint8_t* ok, const uint8_t* sigs, const uint32_t* offlist, const uint32_t* offcount,
+                     const uint32_t* pad) {
+  const size_t g = (size_t)blockIdx.x * EXACT_BLOCK + threadIdx.x;
+  if (g >= *offcount) return;
+  const size_t i = offlist[g];
+  uint32_t rw[8];
+  load32(rw, sigs, i, 64);
+  const uint32_t* base = pad + (size_t)blockIdx.x * (EXACT_PAD_WORDS * EXACT_BLOCK);
+  const int8_t* ux = reinterpret_cast<const int8_t*>(base + 160 * EXACT_BLOCK) + threadIdx.x;
+  ok[i] = (uint8_t)verify_exact_chain_lane(rw, ux, ux + REF_JSF_LEN * EXACT_BLOCK, base + threadIdx.x, EXACT_BLOCK);
 }
 
 __global__ void __launch_bounds__(BLOCK, 4)
@@ -504,13 +539,15 @@ hipError_t edk_verify(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, con
                      msg_len, n, ws->digits, ws->table, ws->flags, ws->offlist, ws->offcount);
   if (marks) (void)hipEventRecord(marks[1], stream);
   // the exact path depends only on prepare: run it beside the main kernel on the side stream
+  const unsigned eb = (unsigned)((n + EXACT_BLOCK - 1) / EXACT_BLOCK);
+  const unsigned eb1 = eb < (unsigned)EXACT_MAX_BLOCKS ? eb : (unsigned)EXACT_MAX_BLOCKS;
   if (ws->exact_offcurve) {
-    const unsigned eb = (unsigned)((n + EXACT_BLOCK - 1) / EXACT_BLOCK);
+    hipLaunchKernelGGL(k_verify_exact_setup, dim3(eb1), dim3(EXACT_BLOCK), 0, stream, sigs, pubs, msgs, msg_off,
+                       msg_len, ws->offlist, ws->offcount, base16, ws->exact_pad);
     (void)hipEventRecord(ws->ev_prepared, stream);
     (void)hipStreamWaitEvent(ws->side, ws->ev_prepared, 0);
-    hipLaunchKernelGGL(k_verify_exact, dim3(eb < (unsigned)EXACT_MAX_BLOCKS ? eb : (unsigned)EXACT_MAX_BLOCKS),
-                       dim3(EXACT_BLOCK), 0, ws->side, ok, sigs, pubs, msgs, msg_off, msg_len, ws->offlist,
-                       ws->offcount, base16, ws->exact_pad);
+    hipLaunchKernelGGL(k_verify_exact_chain, dim3(eb1), dim3(EXACT_BLOCK), 0, ws->side, ok, sigs, ws->offlist,
+                       ws->offcount, ws->exact_pad);
     (void)hipEventRecord(ws->ev_exact, ws->side);
   }
   hipLaunchKernelGGL(k_verify_main, dim3(blocks), dim3(BLOCK), 0, stream, ws->digits, ws->table, base16, ws->acc);
@@ -518,7 +555,13 @@ hipError_t edk_verify(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, con
   hipLaunchKernelGGL(k_verify_finish, dim3((blocks + FINISH_K - 1) / FINISH_K), dim3(BLOCK), 0, stream, ok, sigs,
                      ws->acc, ws->flags, n, ws->exact_offcurve);
   if (marks) (void)hipEventRecord(marks[3], stream);
-  if (ws->exact_offcurve) (void)hipStreamWaitEvent(stream, ws->ev_exact, 0);   // complete when both paths are
+  if (ws->exact_offcurve) {
+    (void)hipStreamWaitEvent(stream, ws->ev_exact, 0);   // complete when both paths are
+    if (eb > eb1)   // more than 65536 off-curve keys in the pass: the rest, strided, one (spilling) kernel
+      hipLaunchKernelGGL(k_verify_exact, dim3(EXACT_MAX_BLOCKS), dim3(EXACT_BLOCK), 0, stream, ok, sigs, pubs, msgs,
+                         msg_off, msg_len, ws->offlist, ws->offcount, base16, ws->exact_pad,
+                         (size_t)EXACT_MAX_BLOCKS * EXACT_BLOCK);
+  }
   return hipGetLastError();
 }
 
