@@ -189,3 +189,23 @@ def test_two_rank_shard_and_gather_over_gloo(oracle, tmp_path):
     r = _torchrun(script, env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
+
+
+def test_bench_helpers_without_gpu(tmp_path, monkeypatch):
+    """bench.py's host-side helpers: cgroup-aware core count, PMC traffic lookup (sums the kernels of
+    a multi-kernel pass, applies the gfx950 FETCH_SIZE x2 rule), canonical work figures"""
+    import json
+    import bench
+    assert 1 <= bench.usable_cores() <= (os.cpu_count() or 1)
+    assert bench.MUL32_VERIFY == 2291 * 100 + 1514 * 55 == 312370            # BASELINE.md "Work per item"
+    assert bench.MUL32_X25519 == 1292 * 100 + 1278 * 55 + 256 * 10 == 202050
+    assert bench.MUL32_SIGN == 506 * 100 + 254 * 55 == 64570
+    assert abs(bench.PEAK_TMUL32 - 39.3216) < 1e-9
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "pmc_summary.json").write_text(json.dumps({
+        "ed::k_a": {"FETCH_SIZE": 1000.0, "WRITE_SIZE": 10.0}, "ed::k_b": {"FETCH_SIZE": 24.0, "WRITE_SIZE": 6.0}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    t = bench.pmc_traffic("k_a + k_b")
+    assert t["bytes"] == (2 * 1024.0 + 16.0) * 1024.0 and t["fetch_size_kb_raw"] == 1024.0
+    assert bench.pmc_traffic("k_missing") is None
