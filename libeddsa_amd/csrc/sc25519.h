@@ -141,9 +141,10 @@ ED_DEV void sc_add(sc& out, const sc& a, const sc& b) {
   for (int i = 0; i < 10; i++) out.v[i] = r[i];
 }
 
-// 256-bit little-endian add of a constant pattern byte (0x88 for 4-bit digits, 0x80 for 8-bit):
-// w + pat*0x01010101...; the recoding of ed.c:407-409 (x + con_off, then nibble - 8), done on
-// the exported words.  Needs w < 2^253, so no carry leaves bit 255.
+// 256-bit little-endian add of the same pattern word to each of the eight words (0x88888888 for
+// 4-bit signed digits, 0x80008000 for 16-bit signed digits): the recoding of ed.c:407-409
+// (x + con_off, then nibble - 8), done on the exported words.  Needs w < 2^253, so no carry
+// leaves bit 255.
 ED_DEV void words_add_pattern(uint32_t w[8], uint32_t pat32) {
   uint64_t c = 0;
 #pragma unroll
