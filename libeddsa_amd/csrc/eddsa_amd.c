@@ -26,6 +26,7 @@ struct engine {
     int ready;
     int device;
     uint32_t *base16, *comb;           /* generated base-point tables (HBM) */
+    uint32_t *comb_img;                /* the comb as the point kernels stage it in LDS (lanes.h: comb_select) */
     edk_verify_ws ws;                 /* verify workspace, grown on demand up to CHUNK_MAX items */
     edk_fixed_ws fws;                 /* sign / genpub / x25519_base workspace, same policy */
     hipEvent_t ws_free;               /* recorded after the last kernel that touches ws or fws */
@@ -116,7 +117,7 @@ int eddsa_amd_init(int device)
     if (g_eng.ready && g_eng.device == device) goto out;
     if (g_eng.ready) {                /* re-bind to another device */
         ws_release(&g_eng); fws_release(&g_eng);
-        (void)hipFree(g_eng.base16); (void)hipFree(g_eng.comb); (void)hipEventDestroy(g_eng.ws_free);
+        (void)hipFree(g_eng.base16); (void)hipFree(g_eng.comb); (void)hipFree(g_eng.comb_img); (void)hipEventDestroy(g_eng.ws_free);
         (void)hipStreamDestroy(g_eng.ws.side); (void)hipEventDestroy(g_eng.ws.ev_prepared); (void)hipEventDestroy(g_eng.ws.ev_exact);
         memset(&g_eng, 0, sizeof(g_eng));
     }
@@ -125,6 +126,7 @@ int eddsa_amd_init(int device)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { rc = -100000; goto out; }
     TRY(hipMalloc((void **)&g_eng.base16, (size_t)TABLE_BASE16_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&g_eng.comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&g_eng.comb_img, COMB_IMG_WORDS * sizeof(uint32_t)));
     TRY(hipEventCreateWithFlags(&g_eng.ws_free, hipEventDisableTiming));
     {   /* highest queue priority: its few workgroups must be dispatched while k_verify_main still
          * has thousands waiting, not after them */
@@ -137,7 +139,7 @@ int eddsa_amd_init(int device)
     g_eng.ws.exact_offcurve = 1;
     for (int s = 0; s < MARK_SLOTS; s++)
         for (int i = 0; i < 4; i++) TRY(hipEventCreate(&g_eng.marks[s][i]));
-    TRY(edk_init_tables(g_eng.base16, g_eng.comb, NULL));
+    TRY(edk_init_tables(g_eng.base16, g_eng.comb, g_eng.comb_img, NULL));
     TRY(hipEventRecord(g_eng.ws_free, NULL));
     TRY(hipDeviceSynchronize());
     g_eng.device = device;
@@ -154,7 +156,7 @@ void eddsa_amd_shutdown(void)
         (void)hipDeviceSynchronize();
         pipe_release();
         ws_release(&g_eng); fws_release(&g_eng);
-        (void)hipFree(g_eng.base16); (void)hipFree(g_eng.comb); (void)hipEventDestroy(g_eng.ws_free);
+        (void)hipFree(g_eng.base16); (void)hipFree(g_eng.comb); (void)hipFree(g_eng.comb_img); (void)hipEventDestroy(g_eng.ws_free);
         (void)hipStreamDestroy(g_eng.ws.side); (void)hipEventDestroy(g_eng.ws.ev_prepared); (void)hipEventDestroy(g_eng.ws.ev_exact);
         memset(&g_eng, 0, sizeof(g_eng));
     }
@@ -280,7 +282,7 @@ static hipError_t sign_step(size_t done, size_t m, const void *vctx, hipStream_t
     const uint8_t *mp = c->msg_off ? c->msgs : c->msgs + done * c->msg_len;
     const uint64_t *op = c->msg_off ? c->msg_off + done : NULL;
     return edk_sign(c->sigs + 64 * done, c->secs + 32 * done, c->pubs + 32 * done, mp, op, c->msg_len, m,
-                    g_eng.comb, &g_eng.fws, st);
+                    g_eng.comb_img, &g_eng.fws, st);
 }
 
 int ed25519_sign_batch_dev(uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs, const uint8_t *msgs,
@@ -295,7 +297,7 @@ struct io_ctx { uint8_t *out; const uint8_t *in; };
 static hipError_t genpub_step(size_t done, size_t m, const void *vctx, hipStream_t st)
 {
     const struct io_ctx *c = (const struct io_ctx *)vctx;
-    return edk_genpub(c->out + 32 * done, c->in + 32 * done, m, g_eng.comb, &g_eng.fws, st);
+    return edk_genpub(c->out + 32 * done, c->in + 32 * done, m, g_eng.comb_img, &g_eng.fws, st);
 }
 
 int ed25519_genpub_batch_dev(uint8_t *pubs, const uint8_t *secs, size_t n, void *stream)
@@ -316,7 +318,7 @@ out:
 static hipError_t xbase_step(size_t done, size_t m, const void *vctx, hipStream_t st)
 {
     const struct io_ctx *c = (const struct io_ctx *)vctx;
-    return edk_x25519_base(c->out + 32 * done, c->in + 32 * done, m, g_eng.comb, &g_eng.fws, st);
+    return edk_x25519_base(c->out + 32 * done, c->in + 32 * done, m, g_eng.comb_img, &g_eng.fws, st);
 }
 
 int x25519_base_batch_dev(uint8_t *out, const uint8_t *scalars, size_t n, void *stream)

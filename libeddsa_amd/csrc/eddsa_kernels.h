@@ -11,6 +11,9 @@
 #define TABLE_ENTRY_WORDS 32      /* 3 x 10 limbs + 2 padding words */
 #define VERIFY_TABLE_ENTRIES 9    /* 0..8 times -A, cached form */
 #define VERIFY_ENTRY_WORDS 40     /* ymx | ypx | t2d | z2 */
+#define COMB_IMG_ENTRIES 16       /* LDS image of a comb row: d * 256^i * B for d = -8..7 */
+#define COMB_IMG_ENTRY_WORDS 36
+#define COMB_IMG_WORDS (32 * COMB_IMG_ENTRIES * COMB_IMG_ENTRY_WORDS)
 #endif
 #define VERIFY_TABLE_WORDS_PER_TILE (VERIFY_TABLE_ENTRIES * 40 * 256)
 #define VERIFY_TILE 256            /* items per tile = threads per block */
@@ -19,7 +22,7 @@
 extern "C" {
 #endif
 
-hipError_t edk_init_tables(uint32_t* base16, uint32_t* comb, hipStream_t stream);
+hipError_t edk_init_tables(uint32_t* base16, uint32_t* comb, uint32_t* comb_img, hipStream_t stream);
 hipError_t edk_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* points, size_t n,
                       hipStream_t stream);
 #define EDK_EXACT_PAD_BYTES ((size_t)1024 * 64 * (160 + 2 * ((261 + 3) / 4)) * 4)

@@ -56,9 +56,11 @@ ED_DEV void msg_span(const uint8_t*& m, size_t& mlen, const uint8_t* msgs, const
   else { m = msgs + item * msg_len; mlen = msg_len; }
 }
 
-// copy a table of `words` 32-bit words from HBM into LDS (whole block)
+// copy a table of `words` 32-bit words (a multiple of 4, 16-byte aligned) from HBM into LDS (whole block)
 ED_DEV void stage_table(uint32_t* lds, const uint32_t* src, int words) {
-  for (int j = threadIdx.x; j < words; j += BLOCK) lds[j] = src[j];
+  word4* d = reinterpret_cast<word4*>(lds);
+  const word4* s = reinterpret_cast<const word4*>(src);
+  for (int j = threadIdx.x; j < words / 4; j += BLOCK) d[j] = s[j];
   __syncthreads();
 }
 
@@ -84,6 +86,13 @@ __global__ void __launch_bounds__(64) k_init_tables(uint32_t* base16, uint32_t* 
     const int c = id - TABLE_BASE16_ENTRIES;      // comb[i][k], c = 8 i + k
     table_entry_lane(comb + TABLE_ENTRY_WORDS * c, (uint32_t)(c & 7) + 1, 8u * (uint32_t)(c >> 3));
   }
+}
+
+// the LDS image of the comb (lanes.h: comb_select), one thread per entry
+__global__ void __launch_bounds__(64) k_init_comb_image(uint32_t* img, const uint32_t* comb) {
+  const int id = blockIdx.x * 64 + threadIdx.x;
+  if (id >= 32 * COMB_IMG_ENTRIES) return;
+  comb_image_entry_lane(img + COMB_IMG_ENTRY_WORDS * id, comb, id / COMB_IMG_ENTRIES, id % COMB_IMG_ENTRIES);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -332,14 +341,15 @@ k_verify_finish(uint8_t* ok, const uint8_t* sigs, uint32_t* acc, uint8_t* flags,
 }
 
 // ---------------------------------------------------------------------------------------------
-// fixed-base kernels: the 256-entry comb (32 KiB) is staged in LDS by every block of a "point"
-// kernel; the matching "finish" kernel encodes (and, for sign, hashes and computes S)
+// fixed-base kernels: the image of the comb (32 rows x 16 signed entries, 72 KiB; two blocks per
+// CU) is staged in LDS by every block of a "point" kernel; the matching "finish" kernel encodes
+// (and, for sign, hashes and computes S)
 // ---------------------------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(BLOCK, 2)
 k_genpub_point(uint32_t* accout, const uint8_t* secs, size_t n, const uint32_t* comb) {
-  __shared__ alignas(16) uint32_t lds_comb[TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS];
-  stage_table(lds_comb, comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS);
+  __shared__ alignas(16) uint32_t lds_comb[COMB_IMG_WORDS];
+  stage_table(lds_comb, comb, COMB_IMG_WORDS);
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   uint32_t sk[8];
   load32(sk, secs, i < n ? i : n - 1, 32);
@@ -376,8 +386,8 @@ k_encode_finish(uint8_t* out, uint32_t* acc, size_t n) {
 __global__ void __launch_bounds__(BLOCK, 2)
 k_sign_point(uint32_t* accout, uint32_t* aux, const uint8_t* secs, const uint8_t* msgs,
              const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* comb) {
-  __shared__ alignas(16) uint32_t lds_comb[TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS];
-  stage_table(lds_comb, comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS);
+  __shared__ alignas(16) uint32_t lds_comb[COMB_IMG_WORDS];
+  stage_table(lds_comb, comb, COMB_IMG_WORDS);
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const size_t item = i < n ? i : n - 1;
   const uint8_t* m; size_t mlen;
@@ -431,8 +441,8 @@ k_sign_finish(uint8_t* sigs, uint32_t* acc, uint32_t* aux, const uint8_t* pubs, 
 
 __global__ void __launch_bounds__(BLOCK, 2)
 k_x25519_base_point(uint32_t* accout, const uint8_t* scalars, size_t n, const uint32_t* comb) {
-  __shared__ alignas(16) uint32_t lds_comb[TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS];
-  stage_table(lds_comb, comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS);
+  __shared__ alignas(16) uint32_t lds_comb[COMB_IMG_WORDS];
+  stage_table(lds_comb, comb, COMB_IMG_WORDS);
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   uint32_t s[8];
   load32(s, scalars, i < n ? i : n - 1, 32);
@@ -514,9 +524,10 @@ using namespace ed;
 
 extern "C" {
 
-hipError_t edk_init_tables(uint32_t* base16, uint32_t* comb, hipStream_t stream) {
+hipError_t edk_init_tables(uint32_t* base16, uint32_t* comb, uint32_t* comb_img, hipStream_t stream) {
   const int total = TABLE_BASE16_ENTRIES + TABLE_COMB_ENTRIES;
   hipLaunchKernelGGL(k_init_tables, dim3((total + 63) / 64), dim3(64), 0, stream, base16, comb);
+  hipLaunchKernelGGL(k_init_comb_image, dim3(32 * COMB_IMG_ENTRIES / 64), dim3(64), 0, stream, comb_img, comb);
   return hipGetLastError();
 }
 

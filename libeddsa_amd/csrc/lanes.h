@@ -22,6 +22,9 @@
 #define TABLE_BASE16_ENTRIES 32769 /* k*B, k = 0..32768: 16-bit signed windows of S (4 MiB, L2/MALL) */
 #define TABLE_COMB_ENTRIES 256    /* (k+1)*256^i*B, i < 32, k < 8: ed.c:41-43 ed_lookup */
 #define TABLE_ENTRY_WORDS 32      /* 3 x 10 limbs + 2 padding words */
+#define COMB_IMG_ENTRIES 16       /* LDS image of a comb row: d * 256^i * B for d = -8..7 (entry d + 8) */
+#define COMB_IMG_ENTRY_WORDS 36   /* 30 limbs + 6 padding words: entries start 4 banks apart */
+#define COMB_IMG_WORDS (32 * COMB_IMG_ENTRIES * COMB_IMG_ENTRY_WORDS)
 #define VERIFY_TABLE_ENTRIES 9    /* 0..8 times -A, cached form */
 #define VERIFY_ENTRY_WORDS 40     /* ymx | ypx | t2d | z2 */
 
@@ -532,26 +535,63 @@ ED_DEV bool verify_exact_lane(const uint32_t rw[8], const uint32_t sraw[8], cons
 // fixed-base path: ed.c:346-430 (scale16, ed_scale_base) and its callers
 // ---------------------------------------------------------------------------------------------
 // Same comb as the reference: 64 signed 4-bit digits of (x + 0x88..8); even digits accumulate in
-// R0, odd digits in R1, both from row i of comb[32][8] (staged in LDS); R1 <- 16 R1; R0 + R1.
+// R0, odd digits in R1, both from row i of comb[32][8]; R1 <- 16 R1; R0 + R1.
 // The scalar is secret here, so the lookup keeps the reference's constant-time discipline
-// (ed.c:359-390): every lane reads all eight entries of the row (a wave-uniform LDS address,
-// served as a broadcast) and keeps the one it needs with v_cndmask; no secret-dependent address,
-// no secret-dependent branch.
+// (ed.c:359-390): no memory address and no branch depends on the digit.  On the device the row is
+// staged in LDS as 16 ready-made entries d * 256^i * B, d = -8..7 (sign and the neutral element
+// already applied, `comb_image_entry_lane`); lane L of every wave reads entry L mod 16 -- an
+// address that depends on the lane number only -- and each lane then takes the entry it needs
+// from lane `nibble` of its own wave with ds_bpermute_b32, the cross-lane shuffle of the LDS
+// crossbar (30 of them per lookup, on the LDS pipe, beside the VALU work of the previous
+// addition).  The first version scanned all eight entries with v_cndmask: 240 selects + 40 for
+// the conditional negation per lookup, 15 % of the kernel's instructions.
 
-ED_DEV void comb_select(ge_niels& e, const uint32_t* row, int digit) {
-  const uint32_t mag = (uint32_t)(digit < 0 ? -digit : digit);
+// entry s = d + 8 of the image of comb row `row` (comb = the 256-entry table, global layout)
+ED_DEV void comb_image_entry_lane(uint32_t* dst, const uint32_t* comb, int row, int s) {
+  const int d = s - 8, mag = d < 0 ? -d : d;
+  ge_niels e;
   fe_set(e.ymx, 1); fe_set(e.ypx, 1); fe_set(e.t2d, 0);        // ed.c:73 pced_zero
-#pragma unroll
-  for (uint32_t k = 0; k < 8; k++) {
-    ge_niels c;
-    niels_load(c, row + TABLE_ENTRY_WORDS * k);
-    const bool hit = (mag == k + 1);
-    fe_cmov(e.ymx, c.ymx, hit); fe_cmov(e.ypx, c.ypx, hit); fe_cmov(e.t2d, c.t2d, hit);
+  if (mag != 0) niels_load(e, comb + TABLE_ENTRY_WORDS * (8 * row + mag - 1));
+  if (d < 0) {                                                  // ed.c:383-389: swap diff/sum, negate prod
+    ge_niels_cneg(e, true);
+    fe_carry(e.t2d);
   }
-  ge_niels_cneg(e, digit < 0);
+#pragma unroll
+  for (int j = 0; j < 10; j++) { dst[j] = e.ymx.v[j]; dst[10 + j] = e.ypx.v[j]; dst[20 + j] = e.t2d.v[j]; }
+#pragma unroll
+  for (int j = 30; j < COMB_IMG_ENTRY_WORDS; j++) dst[j] = 0;
 }
 
-// out = x * B for a reduced scalar given as eight little-endian words (consumed)
+#ifdef ED_HOST_CHECK
+// host build: `table` is the 256-entry comb in its global layout; plain indexed lookup
+ED_DEV void comb_select(ge_niels& e, const uint32_t* table, int row, uint32_t nibble) {
+  const int d = (int)nibble - 8, mag = d < 0 ? -d : d;
+  fe_set(e.ymx, 1); fe_set(e.ypx, 1); fe_set(e.t2d, 0);
+  if (mag != 0) niels_load(e, table + TABLE_ENTRY_WORDS * (8 * row + mag - 1));
+  if (d < 0) { ge_niels_cneg(e, true); fe_carry(e.t2d); }
+}
+#else
+// device: `table` is the LDS image [32][COMB_IMG_ENTRIES][COMB_IMG_ENTRY_WORDS]; every lane of
+// the wave must be active (the point kernels give idle lanes a real item for that reason)
+ED_DEV void comb_select(ge_niels& e, const uint32_t* table, int row, uint32_t nibble) {
+  const word4* p = reinterpret_cast<const word4*>(
+      table + COMB_IMG_ENTRY_WORDS * (COMB_IMG_ENTRIES * row + (int)(threadIdx.x & 15u)));
+  uint32_t w[32];
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const word4 v = p[q];
+    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+  }
+  const int src = (int)(nibble << 2);                           // byte address of the source lane's slot
+#pragma unroll
+  for (int j = 0; j < 30; j++) w[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)w[j]);
+#pragma unroll
+  for (int j = 0; j < 10; j++) { e.ymx.v[j] = w[j]; e.ypx.v[j] = w[10 + j]; e.t2d.v[j] = w[20 + j]; }
+}
+#endif
+
+// out = x * B for a reduced scalar given as eight little-endian words (consumed); comb = the LDS
+// image on the device, the 256-entry table in the host build (see comb_select)
 ED_DEV void scale_base_lane(ge& out, uint32_t xw[8], const uint32_t* comb) {
   words_add_pattern(xw, 0x88888888u);            // ed.c:407-409
   ge r0, r1;
@@ -563,9 +603,9 @@ ED_DEV void scale_base_lane(ge& out, uint32_t xw[8], const uint32_t* comb) {
     for (int k = 0; k < 7; k++) xw[k] = (xw[k] >> 8) | (xw[k + 1] << 24);
     xw[7] >>= 8;
     ge_niels e;
-    comb_select(e, comb + TABLE_ENTRY_WORDS * 8 * i, (int)(byte & 15u) - 8);
+    comb_select(e, comb, i, byte & 15u);
     ge_add_niels(r0, r0, e, true);
-    comb_select(e, comb + TABLE_ENTRY_WORDS * 8 * i, (int)(byte >> 4) - 8);
+    comb_select(e, comb, i, byte >> 4);
     ge_add_niels(r1, r1, e, true);
   }
 #pragma unroll 1
