@@ -177,9 +177,7 @@ int eddsa_amd_dump_tables(uint32_t *base16_words, uint32_t *comb_words)
     int rc = ensure_init();
     if (rc) return rc;
     TRY(hipMemcpy(base16_words, g_eng.base16, (size_t)TABLE_BASE16_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    /* the reference's ed_lookup[i][k] = (k+1) * 256^i * B is row 2i of the 64-row comb */
-    TRY(hipMemcpy2D(comb_words, 8 * TABLE_ENTRY_WORDS * sizeof(uint32_t), g_eng.comb, 16 * TABLE_ENTRY_WORDS * sizeof(uint32_t),
-                    8 * TABLE_ENTRY_WORDS * sizeof(uint32_t), 32, hipMemcpyDeviceToHost));
+    TRY(hipMemcpy(comb_words, g_eng.comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
 out:
     return rc;
 }

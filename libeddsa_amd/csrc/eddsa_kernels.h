@@ -7,14 +7,13 @@
 
 #ifndef TABLE_BASE16_ENTRIES      /* also defined, identically, by lanes.h for the device side */
 #define TABLE_BASE16_ENTRIES 32769 /* k*B, k = 0..32768 */
-#define TABLE_COMB_ROWS 64        /* comb[r][k] = (k+1)*16^r*B, k < 8; even rows = ed.c:41-43 ed_lookup */
-#define TABLE_COMB_ENTRIES (8 * TABLE_COMB_ROWS)
+#define TABLE_COMB_ENTRIES 256    /* (k+1)*256^i*B, i < 32, k < 8: ed.c:41-43 ed_lookup */
 #define TABLE_ENTRY_WORDS 32      /* 3 x 10 limbs + 2 padding words */
 #define VERIFY_TABLE_ENTRIES 9    /* 0..8 times -A, cached form */
 #define VERIFY_ENTRY_WORDS 40     /* ymx | ypx | t2d | z2 */
 #define COMB_IMG_ENTRIES 16       /* LDS image of a comb row: d * 256^i * B for d = -8..7 */
 #define COMB_IMG_ENTRY_WORDS 36
-#define COMB_IMG_WORDS (TABLE_COMB_ROWS * COMB_IMG_ENTRIES * COMB_IMG_ENTRY_WORDS)
+#define COMB_IMG_WORDS (32 * COMB_IMG_ENTRIES * COMB_IMG_ENTRY_WORDS)
 #endif
 #define VERIFY_TABLE_WORDS_PER_TILE (VERIFY_TABLE_ENTRIES * 40 * 256)
 #define VERIFY_TILE 256            /* items per tile = threads per block */

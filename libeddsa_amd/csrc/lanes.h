@@ -20,12 +20,11 @@
 #include "sha512.h"
 
 #define TABLE_BASE16_ENTRIES 32769 /* k*B, k = 0..32768: 16-bit signed windows of S (4 MiB, L2/MALL) */
-#define TABLE_COMB_ROWS 64        /* comb[r][k] = (k+1)*16^r*B, k < 8; even rows = ed.c:41-43 ed_lookup */
-#define TABLE_COMB_ENTRIES (8 * TABLE_COMB_ROWS)
+#define TABLE_COMB_ENTRIES 256    /* (k+1)*256^i*B, i < 32, k < 8: ed.c:41-43 ed_lookup */
 #define TABLE_ENTRY_WORDS 32      /* 3 x 10 limbs + 2 padding words */
 #define COMB_IMG_ENTRIES 16       /* LDS image of a comb row: d * 256^i * B for d = -8..7 (entry d + 8) */
 #define COMB_IMG_ENTRY_WORDS 36   /* 30 limbs + 6 padding words: entries start 4 banks apart */
-#define COMB_IMG_WORDS (TABLE_COMB_ROWS * COMB_IMG_ENTRIES * COMB_IMG_ENTRY_WORDS)
+#define COMB_IMG_WORDS (32 * COMB_IMG_ENTRIES * COMB_IMG_ENTRY_WORDS)
 #define VERIFY_TABLE_ENTRIES 9    /* 0..8 times -A, cached form */
 #define VERIFY_ENTRY_WORDS 40     /* ymx | ypx | t2d | z2 */
 
@@ -100,8 +99,7 @@ ED_DEV void x25519_lane(uint32_t out[8], uint32_t s[8], const uint32_t pt[8]) {
 // ---------------------------------------------------------------------------------------------
 // Entry = 32 words: y-x | y+x | 2dxy (10 canonical limbs each) + 2 words of padding.
 //   base16[k], k = 0..32768 : k * B                (16-bit signed windows of S in verify)
-//   comb[r][k], r < 64, k < 8 : (k+1) * 16^r * B   (sign/genpub/x25519_base; rows 2i are the
-//                                                   reference's ed_lookup[i], ed.c:41-43)
+//   comb[i][k], i < 32, k < 8 : (k+1) * 256^i * B  (ed.c:41-43 ed_lookup, sign/genpub/x25519_base)
 
 ED_DEV void niels_store(uint32_t* dst, const ge_niels& n) {
 #pragma unroll
@@ -536,23 +534,17 @@ ED_DEV bool verify_exact_lane(const uint32_t rw[8], const uint32_t sraw[8], cons
 // ---------------------------------------------------------------------------------------------
 // fixed-base path: ed.c:346-430 (scale16, ed_scale_base) and its callers
 // ---------------------------------------------------------------------------------------------
-// The reference's digits, one accumulator: 64 signed 4-bit digits d_j of (x + 0x88..8)
-// (ed.c:407-409), x*B = sum d_j * 16^j * B.  The reference keeps 32 rows (16^(2i) B), adds the even
-// digits into R0 and the odd ones into R1 and finishes with R0 + 16 R1 (ed.c:411-429: four
-// doublings and a full addition); here the table has all 64 rows, so every digit is one mixed
-// addition into a single accumulator.  The sum is the same group element and only its affine
-// encoding leaves the kernels, so the bytes are the reference's (the unified addition law of
-// ed.c:282-305 is complete on this curve: no exceptional cases on the way).
+// Same comb as the reference: 64 signed 4-bit digits of (x + 0x88..8); even digits accumulate in
+// R0, odd digits in R1, both from row i of comb[32][8]; R1 <- 16 R1; R0 + R1.
 // The scalar is secret here, so the lookup keeps the reference's constant-time discipline
-// (ed.c:359-390): no memory address and no branch depends on the digit.  On the device the table
-// is staged in LDS as 16 ready-made entries per row, d * 16^r * B for d = -8..7 (sign and the
-// neutral element already applied, `comb_image_entry_lane`; 144 KiB, one 512-lane block per CU);
-// lane L of every wave reads entry L mod 16 -- an address that depends on the lane number only --
-// and each lane then takes the entry it needs from lane `nibble` of its own wave with
-// ds_bpermute_b32, the cross-lane shuffle of the LDS crossbar (30 per lookup, on the LDS pipe,
-// beside the VALU work of the previous addition).  The first version scanned all eight entries of
-// a row with v_cndmask: 240 selects + 40 for the conditional negation per lookup, 15 % of the
-// kernel's instructions.
+// (ed.c:359-390): no memory address and no branch depends on the digit.  On the device the row is
+// staged in LDS as 16 ready-made entries d * 256^i * B, d = -8..7 (sign and the neutral element
+// already applied, `comb_image_entry_lane`); lane L of every wave reads entry L mod 16 -- an
+// address that depends on the lane number only -- and each lane then takes the entry it needs
+// from lane `nibble` of its own wave with ds_bpermute_b32, the cross-lane shuffle of the LDS
+// crossbar (30 of them per lookup, on the LDS pipe, beside the VALU work of the previous
+// addition).  The first version scanned all eight entries with v_cndmask: 240 selects + 40 for
+// the conditional negation per lookup, 15 % of the kernel's instructions.
 
 // entry s = d + 8 of the image of comb row `row` (comb = the 256-entry table, global layout)
 ED_DEV void comb_image_entry_lane(uint32_t* dst, const uint32_t* comb, int row, int s) {
@@ -571,7 +563,7 @@ ED_DEV void comb_image_entry_lane(uint32_t* dst, const uint32_t* comb, int row, 
 }
 
 #ifdef ED_HOST_CHECK
-// host build: `table` is the comb in its global layout [64][8]; plain indexed lookup
+// host build: `table` is the 256-entry comb in its global layout; plain indexed lookup
 ED_DEV void comb_select(ge_niels& e, const uint32_t* table, int row, uint32_t nibble) {
   const int d = (int)nibble - 8, mag = d < 0 ? -d : d;
   fe_set(e.ymx, 1); fe_set(e.ypx, 1); fe_set(e.t2d, 0);
@@ -579,7 +571,7 @@ ED_DEV void comb_select(ge_niels& e, const uint32_t* table, int row, uint32_t ni
   if (d < 0) { ge_niels_cneg(e, true); fe_carry(e.t2d); }
 }
 #else
-// device: `table` is the LDS image [64][COMB_IMG_ENTRIES][COMB_IMG_ENTRY_WORDS]; every lane of
+// device: `table` is the LDS image [32][COMB_IMG_ENTRIES][COMB_IMG_ENTRY_WORDS]; every lane of
 // the wave must be active (the point kernels give idle lanes a real item for that reason)
 ED_DEV void comb_select(ge_niels& e, const uint32_t* table, int row, uint32_t nibble) {
   const word4* p = reinterpret_cast<const word4*>(
@@ -602,7 +594,8 @@ ED_DEV void comb_select(ge_niels& e, const uint32_t* table, int row, uint32_t ni
 // image on the device, the 256-entry table in the host build (see comb_select)
 ED_DEV void scale_base_lane(ge& out, uint32_t xw[8], const uint32_t* comb) {
   words_add_pattern(xw, 0x88888888u);            // ed.c:407-409
-  ge_neutral(out);
+  ge r0, r1;
+  ge_neutral(r0); ge_neutral(r1);
 #pragma unroll 1
   for (int i = 0; i < 32; i++) {
     const uint32_t byte = xw[0] & 0xffu;
@@ -610,11 +603,16 @@ ED_DEV void scale_base_lane(ge& out, uint32_t xw[8], const uint32_t* comb) {
     for (int k = 0; k < 7; k++) xw[k] = (xw[k] >> 8) | (xw[k + 1] << 24);
     xw[7] >>= 8;
     ge_niels e;
-    comb_select(e, comb, 2 * i, byte & 15u);
-    ge_add_niels(out, out, e, true);
-    comb_select(e, comb, 2 * i + 1, byte >> 4);
-    ge_add_niels(out, out, e, i != 31);
+    comb_select(e, comb, i, byte & 15u);
+    ge_add_niels(r0, r0, e, true);
+    comb_select(e, comb, i, byte >> 4);
+    ge_add_niels(r1, r1, e, true);
   }
+#pragma unroll 1
+  for (int k = 0; k < 4; k++) ge_dbl(r1, r1, k == 3);
+  ge_cached c;
+  ge_to_cached(c, r1);
+  ge_add_cached(out, r0, c, false);
 }
 
 // ed25519-sha512.c:31-47 ed25519_key_setup: h = SHA-512(sk), clamped

@@ -36,7 +36,7 @@ struct Tables {
   Tables() : base16((size_t)TABLE_BASE16_ENTRIES * TABLE_ENTRY_WORDS + 32), comb(TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS) {
     for (int k = 0; k < TABLE_BASE16_ENTRIES; k++) table_entry_lane(b16() + (size_t)TABLE_ENTRY_WORDS * k, (uint32_t)k, 0);
     for (int c = 0; c < TABLE_COMB_ENTRIES; c++)
-      table_entry_lane(&comb[TABLE_ENTRY_WORDS * c], (uint32_t)(c & 7) + 1, 4u * (uint32_t)(c >> 3));
+      table_entry_lane(&comb[TABLE_ENTRY_WORDS * c], (uint32_t)(c & 7) + 1, 8u * (uint32_t)(c >> 3));
   }
 };
 static Tables& tables() { static Tables t; return t; }
@@ -49,8 +49,7 @@ void hc_reset(void) { g_violations = 0; g_first[0] = 0; }
 
 void hc_tables(uint32_t* base16, uint32_t* comb) {
   memcpy(base16, tables().b16(), (size_t)TABLE_BASE16_ENTRIES * TABLE_ENTRY_WORDS * 4);
-  for (int i = 0; i < 32; i++)   // the reference's ed_lookup[i] = row 2i
-    memcpy(comb + 8 * TABLE_ENTRY_WORDS * i, &tables().comb[8 * TABLE_ENTRY_WORDS * 2 * i], 8 * TABLE_ENTRY_WORDS * 4);
+  memcpy(comb, tables().comb.data(), tables().comb.size() * 4);
 }
 
 void hc_x25519(uint8_t out[32], const uint8_t scalar[32], const uint8_t point[32]) {
