@@ -142,6 +142,8 @@ def gather_results(out, world):
     """N > 1: all-gather the result bytes of every rank's shard (the only exchange of the path)."""
     if world == 1:
         return out
+    if dist.get_backend() == "gloo":                    # test hook (see main): stage through the host
+        out = out.cpu()
     full = torch.empty((world * out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
     dist.all_gather_into_tensor(full, out)              # concatenated along dim 0: valid on nccl and gloo
     return full.view((world,) + tuple(out.shape))
@@ -164,7 +166,7 @@ def timed_region(step, steps, world, sync, device):
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed, out
@@ -185,10 +187,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    # Test hooks, so that the N > 1 code path can be exercised on a one-GPU box: EDDSA_BENCH_SHARE_GPU=1
+    # maps every rank onto the visible devices round-robin, EDDSA_BENCH_BACKEND=gloo replaces RCCL
+    # (which refuses two ranks on one device).  Neither is set by the driver's runs.
+    if os.environ.get("EDDSA_BENCH_SHARE_GPU") == "1":
+        local %= torch.cuda.device_count()
+    backend = os.environ.get("EDDSA_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     ed.init(local)
 
     op, n = args.op, 1 << args.log2n
@@ -218,6 +229,10 @@ def main():
     correct = True
     if op == "verify":
         correct = bool(torch.equal(out, w["expect"]))
+    if world > 1:                                       # every rank's shard must be right
+        flag = torch.tensor([int(correct)], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        correct = bool(flag.item())
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * n * args.steps / elapsed
@@ -241,8 +256,9 @@ def main():
         }
         if phases:
             roofline["phase_ms"] = {"k_verify_prepare": phases[0], "k_verify_main": phases[1], "k_verify_finish": phases[2]}
-        base = cpu_baseline(op, w, out, min(args.cpu_sample, n))
-        correct = correct and base["gpu_matches_cpu_on_sample"]
+        # the CPU baseline is timed at N = 1 only (at N > 1 the other ranks' host threads share the cores)
+        base = cpu_baseline(op, w, out, min(args.cpu_sample, n)) if world == 1 else None
+        correct = correct and (base is None or base["gpu_matches_cpu_on_sample"])
         line = {
             "metric": {"verify": "ed25519 verifies/sec", "x25519": "x25519 ops/sec", "sign": "ed25519 signs/sec"}[op],
             "value": value, "unit": {"verify": "verifies/s", "x25519": "ops/s", "sign": "signs/s"}[op],

@@ -1,6 +1,7 @@
 """GPU parity tests: every entry point of the C-ABI (through the ctypes mirror) against the
 committed golden vectors and against the oracle on seeded random batches.  Bit-exact."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -307,3 +308,46 @@ def test_concurrent_host_threads(engine, oracle):
     for t in threads: t.start()
     for t in threads: t.join()
     assert not errors, errors
+
+
+def _bench_line(args, env_extra=None, launcher=None):
+    import json, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **(env_extra or {}))
+    cmd = [sys.executable]
+    if launcher:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(launcher),
+                "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    out = subprocess.run(cmd + [os.path.join(root, "bench.py")] + args, env=env, cwd=root, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout                   # ONE JSON line, from rank 0 only
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("op", ["verify", "x25519", "sign"])
+def test_bench_contract_single_gpu(engine, op):
+    """bench.py's line carries the driver's keys plus roofline and cpu_baseline, and checks its outputs"""
+    d = _bench_line(["--op", op, "--steps", "2", "--warmup", "1", "--log2n", "14", "--cpu-sample", "2048"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["outputs_correct"] is True and d["vs_baseline"] is None
+    assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["gpu_matches_cpu_on_sample"]
+    assert 0 < d["roofline"]["frac"] < 1.5 and "workload" in d["config"]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu(engine):
+    """the N > 1 path of bench.py (shards, gather, max-over-ranks timing) launched exactly as the driver
+    launches it, with the two ranks sharing the box's single GPU and gloo standing in for RCCL"""
+    d = _bench_line(["--gpus", "2", "--steps", "2", "--warmup", "1", "--log2n", "14"],
+                    {"EDDSA_BENCH_SHARE_GPU": "1", "EDDSA_BENCH_BACKEND": "gloo"}, launcher=2)
+    assert d["n_gpus"] == 2 and d["outputs_correct"] is True and d["scaling"] == "weak"
+    assert d["config"]["parallelism"] == "shard2+allgather" and d["cpu_baseline"] is None
+    assert d["value"] > 0
