@@ -63,7 +63,9 @@ EDDSA_AMD_DECL int eddsa_amd_dump_tables(uint32_t *base16_words, uint32_t *comb_
  * ed_import never fails, lib/ed.c:100-149).  exact != 0 (default): such items are evaluated in the
  * reference's own order of operations -- the only way to reproduce its bytes for them.  exact == 0:
  * they are rejected outright, which differs from the reference only on a SHA-512 fixed point and
- * saves about 1 ms per pass that contains such keys. */
+ * saves about 1 ms per pass that contains such keys.  exact == 2: EVERY item is evaluated in the
+ * reference's order of operations (JSF/Shamir chain, lib/ed.c:455-507) and the windowed kernel's
+ * result is ignored -- same verdicts, latency-bound, meant for self-checks. */
 EDDSA_AMD_DECL void eddsa_amd_set_offcurve_mode(int exact);
 
 /* measurement aid: when on, HIP events are recorded on the launch stream around the three kernels

@@ -71,8 +71,9 @@ def verify_phase_ms():
 
 def set_offcurve_mode(exact=True):
     """exact=True (default): off-curve public keys are verified in the reference's own operation
-    order; False: they are rejected outright (differs only on a SHA-512 fixed point)."""
-    library().eddsa_amd_set_offcurve_mode(int(bool(exact)))
+    order; False: they are rejected outright (differs only on a SHA-512 fixed point); 2: every item
+    takes the reference-order path (self-check mode, slow)."""
+    library().eddsa_amd_set_offcurve_mode(2 if exact == 2 else int(bool(exact)))
 
 
 def set_profiling(on):

@@ -187,11 +187,12 @@ out:
  * order of operations, which is the only way to reproduce its bytes there.  REJECT: they are
  * rejected outright; this differs from the reference only if encode(C) == R for a C that depends on
  * SHA-512(R || A || M), i.e. on a fixed point of a random function, and saves the ~1 ms the exact
- * pass costs whenever a batch contains such keys. */
+ * pass costs whenever a batch contains such keys.  ALL (2): every item takes the reference-order
+ * path and the windowed evaluation's result is ignored -- slow (latency-bound), for self-checks. */
 void eddsa_amd_set_offcurve_mode(int exact)
 {
     pthread_mutex_lock(&g_lock);
-    g_eng.ws.exact_offcurve = exact != 0;
+    g_eng.ws.exact_offcurve = exact == 2 ? 2 : exact != 0;
     pthread_mutex_unlock(&g_lock);
 }
 

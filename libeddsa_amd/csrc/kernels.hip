@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(64) k_init_comb_image(uint32_t* img, const uin
 __global__ void __launch_bounds__(BLOCK, 2)
 k_verify_prepare(const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs,
                  const uint64_t* msg_off, size_t msg_len, size_t n, uint32_t* digits,
-                 uint32_t* table, uint8_t* flags, uint32_t* offlist, uint32_t* offcount) {
+                 uint32_t* table, uint8_t* flags, uint32_t* offlist, uint32_t* offcount, int all_exact) {
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const size_t item = i < n ? i : n - 1;         // idle lanes redo the last item into their own slot
   uint32_t rw[8], aw[8], sw[8], tw[8];
@@ -128,9 +128,11 @@ k_verify_prepare(const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs,
   uint4* d = reinterpret_cast<uint4*>(digits + 16 * i);
   d[0] = make_uint4(tw[0], tw[1], tw[2], tw[3]); d[1] = make_uint4(tw[4], tw[5], tw[6], tw[7]);
   d[2] = make_uint4(sw[0], sw[1], sw[2], sw[3]); d[3] = make_uint4(sw[4], sw[5], sw[6], sw[7]);
-  flags[i] = (uint8_t)oncurve;
-  // keys that are not curve points go to the exact (reference-order) kernel: append to its work list
-  if (!oncurve && i < n) offlist[atomicAdd(offcount, 1u)] = (uint32_t)i;
+  // keys that are not curve points go to the exact (reference-order) kernels: append to their work
+  // list (all_exact, a self-check mode: every item does, and the windowed result is not used)
+  const bool windowed = oncurve && !all_exact;
+  flags[i] = (uint8_t)windowed;
+  if (!windowed && i < n) offlist[atomicAdd(offcount, 1u)] = (uint32_t)i;
 }
 
 // ed25519-sha512.c:148-181 replayed in the reference's own order (lanes.h verify_exact_lane) for
@@ -547,7 +549,8 @@ hipError_t edk_verify(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, con
   (void)hipMemsetAsync(ws->offcount, 0, sizeof(uint32_t), stream);
   if (marks) (void)hipEventRecord(marks[0], stream);
   hipLaunchKernelGGL(k_verify_prepare, dim3(blocks), dim3(BLOCK), 0, stream, sigs, pubs, msgs, msg_off,
-                     msg_len, n, ws->digits, ws->table, ws->flags, ws->offlist, ws->offcount);
+                     msg_len, n, ws->digits, ws->table, ws->flags, ws->offlist, ws->offcount,
+                     ws->exact_offcurve == 2);
   if (marks) (void)hipEventRecord(marks[1], stream);
   // the exact path depends only on prepare: run it beside the main kernel on the side stream
   const unsigned eb = (unsigned)((n + EXACT_BLOCK - 1) / EXACT_BLOCK);

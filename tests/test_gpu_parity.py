@@ -190,6 +190,27 @@ def test_off_curve_keys_take_the_exact_path(engine, oracle):
         engine.set_offcurve_mode(True)
 
 
+def test_every_item_through_the_reference_order_kernels(engine):
+    """self-check mode 2: all 70 000 items (more than the 65 536 the setup/chain kernels take, so the
+    strided k_verify_exact runs too) are decided by the replay of the reference's JSF/Shamir chain;
+    genuine and corrupted signatures get the verdicts the windowed kernels give them"""
+    import workload
+    n = 70000
+    sk, msg = workload.sign_inputs(n, seed=11, config=2)
+    pk = engine.ed25519_genpub_batch(dev(sk))
+    sig = engine.ed25519_sign_batch(dev(sk), pk, dev(msg)).cpu().numpy()
+    pk = pk.cpu().numpy()
+    expect = workload.corrupt_for_verify(sig, pk, msg)
+    windowed = engine.ed25519_verify_batch(dev(sig), dev(pk), dev(msg), msg_len=32).cpu().numpy()
+    assert np.array_equal(windowed, expect) and 0 < expect.sum() < n
+    engine.set_offcurve_mode(2)
+    try:
+        replay = engine.ed25519_verify_batch(dev(sig), dev(pk), dev(msg), msg_len=32).cpu().numpy()
+    finally:
+        engine.set_offcurve_mode(True)
+    assert np.array_equal(replay, expect)
+
+
 def test_unaligned_device_buffers(engine, oracle):
     """device pointers that are not 16-byte aligned take the byte-wise load/store path"""
     import torch
