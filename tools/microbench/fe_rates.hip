@@ -27,6 +27,9 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, uint64_t* cyc) {
   if (MODE == 3) { for (int i = 0; i < N / 2; i++) { fe_sq(a, a); fe_sq(c, c); } }
   if (MODE == 4) { for (int i = 0; i < N / 4; i++) { fe_mul(a, a, b); fe_mul(c, c, d); fe_mul(b, b, a); fe_mul(d, d, c); } }
   if (MODE == 5) { for (int i = 0; i < N; i++) { fe t; fe_sub(t, a, b); fe_add(a, t, b); fe_carry(a); } }
+  // partial waves: does a wave64 instruction with only 16 (32) active lanes still take 4 passes?
+  if (MODE == 6) { if ((threadIdx.x & 63) < 16) for (int i = 0; i < N; i++) fe_mul(a, a, b); }
+  if (MODE == 7) { if ((threadIdx.x & 63) < 32) for (int i = 0; i < N; i++) fe_mul(a, a, b); }
   uint64_t t1 = __builtin_amdgcn_s_memtime();
   out[tid] = fold(a) ^ fold(b) ^ fold(c) ^ fold(d);
   if ((threadIdx.x & 63) == 0) cyc[tid >> 6] = t1 - t0;
@@ -39,7 +42,7 @@ int main() {
   struct { const char* name; kern_t f; } es[] = {
     {"fe_mul dependent chain", k<0>}, {"fe_sq dependent chain", k<1>},
     {"fe_mul 2 chains", k<2>}, {"fe_sq 2 chains", k<3>}, {"fe_mul 4-cross", k<4>},
-    {"sub+add+carry", k<5>} };
+    {"sub+add+carry", k<5>}, {"fe_mul chain, 16 lanes", k<6>}, {"fe_mul chain, 32 lanes", k<7>} };
   uint32_t* out; uint64_t* cyc;
   CK(hipMalloc(&out, (size_t)cus * 8 * 256 * 4)); CK(hipMalloc(&cyc, (size_t)cus * 8 * 4 * 8));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
