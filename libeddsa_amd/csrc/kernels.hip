@@ -168,11 +168,18 @@ k_verify_exact(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, const uint
 }
 
 // The first EXACT_MAX_BLOCKS * 64 entries of the work list take a faster route.  The register-hungry
-// but short first half (hash, scalars, import, digits, addends: about 0.1 ms whatever the count) is
+// but short first half (hash, scalars, import, digits, addends: about 0.2 ms whatever the count) is
 // a kernel of its own on the caller's stream right after k_verify_prepare; the long second half, the
-// chain, then needs no more than 128 VGPRs, almost unspilled, and is the ONLY kernel on the side
-// stream, so that it is dispatched together with k_verify_main's first workgroups (a kernel that
-// reaches the side queue later only runs once k_verify_main has drained).
+// chain, is the ONLY kernel on the side stream, so that it is dispatched together with
+// k_verify_main's first workgroups (a kernel that reaches the side queue later only runs once
+// k_verify_main has drained).  Its blocks are four waves -- one per SIMD, the footprint of exactly
+// one k_verify_main block -- with 152 VGPRs, which fit beside three of the main kernel's waves.
+// Measured (tools/exact_path_time.py, rocprofv3 timelines via tools/exact_trace.py): beside the
+// main kernel the chain takes 4.2-4.4 ms (about two of the main kernel's four rounds of 1024
+// resident blocks), so every chain block displaces two main blocks; because 2^20 items are
+// exactly 4 x 1024 blocks there is no slack and ANY displaced block costs a fifth, nearly empty
+// round: +0.6 ms for 1024 listed keys as for 8192, +1.0 ms for 65536 (it was +1.6 ms with
+// single-wave chain blocks, which displaced a main block each).
 __global__ void __launch_bounds__(EXACT_BLOCK, 2)
 k_verify_exact_setup(const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs, const uint64_t* msg_off,
                      size_t msg_len, const uint32_t* offlist, const uint32_t* offcount, const uint32_t* base16,
@@ -192,17 +199,20 @@ k_verify_exact_setup(const uint8_t* sigs, const uint8_t* pubs, const uint8_t* ms
                           base + threadIdx.x, EXACT_BLOCK);
 }
 
-__global__ void __launch_bounds__(EXACT_BLOCK, 4)
+constexpr int CHAIN_WAVES = 4;                   // waves per chain block: one per SIMD, the footprint of ONE k_verify_main block
+__global__ void __launch_bounds__(EXACT_BLOCK * CHAIN_WAVES, 2)
 k_verify_exact_chain(uint8_t* ok, const uint8_t* sigs, const uint32_t* offlist, const uint32_t* offcount,
                      const uint32_t* pad) {
-  const size_t g = (size_t)blockIdx.x * EXACT_BLOCK + threadIdx.x;
+  const size_t wave = (size_t)blockIdx.x * CHAIN_WAVES + (threadIdx.x >> 6);
+  const unsigned lane = threadIdx.x & 63u;
+  const size_t g = wave * EXACT_BLOCK + lane;
   if (g >= *offcount) return;
   const size_t i = offlist[g];
   uint32_t rw[8];
   load32(rw, sigs, i, 64);
-  const uint32_t* base = pad + (size_t)blockIdx.x * (EXACT_PAD_WORDS * EXACT_BLOCK);
-  const int8_t* ux = reinterpret_cast<const int8_t*>(base + 160 * EXACT_BLOCK) + threadIdx.x;
-  ok[i] = (uint8_t)verify_exact_chain_lane(rw, ux, ux + REF_JSF_LEN * EXACT_BLOCK, base + threadIdx.x, EXACT_BLOCK);
+  const uint32_t* base = pad + wave * (EXACT_PAD_WORDS * EXACT_BLOCK);
+  const int8_t* ux = reinterpret_cast<const int8_t*>(base + 160 * EXACT_BLOCK) + lane;
+  ok[i] = (uint8_t)verify_exact_chain_lane(rw, ux, ux + REF_JSF_LEN * EXACT_BLOCK, base + lane, EXACT_BLOCK);
 }
 
 __global__ void __launch_bounds__(BLOCK, 4)
@@ -560,8 +570,8 @@ hipError_t edk_verify(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, con
                        msg_len, ws->offlist, ws->offcount, base16, ws->exact_pad);
     (void)hipEventRecord(ws->ev_prepared, stream);
     (void)hipStreamWaitEvent(ws->side, ws->ev_prepared, 0);
-    hipLaunchKernelGGL(k_verify_exact_chain, dim3(eb1), dim3(EXACT_BLOCK), 0, ws->side, ok, sigs, ws->offlist,
-                       ws->offcount, ws->exact_pad);
+    hipLaunchKernelGGL(k_verify_exact_chain, dim3((eb1 + CHAIN_WAVES - 1) / CHAIN_WAVES), dim3(EXACT_BLOCK * CHAIN_WAVES),
+                       0, ws->side, ok, sigs, ws->offlist, ws->offcount, ws->exact_pad);
     (void)hipEventRecord(ws->ev_exact, ws->side);
   }
   hipLaunchKernelGGL(k_verify_main, dim3(blocks), dim3(BLOCK), 0, stream, ws->digits, ws->table, base16, ws->acc);
