@@ -47,7 +47,7 @@ int main() {
   CK(hipMalloc(&out, (size_t)cus * 8 * 256 * 4)); CK(hipMalloc(&cyc, (size_t)cus * 8 * 4 * 8));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   printf("%-26s %4s %14s %14s %12s\n", "op", "w/S", "cyc/op (wave)", "cyc/op/SIMD", "Gop/s chip");
-  for (auto& e : es) for (int wps : {1, 2, 4}) {
+  for (auto& e : es) for (int wps : {1, 2, 4, 5, 6, 8}) {
     int blocks = cus * wps;
     e.f<<<blocks, 256>>>(out, cyc); CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0)); e.f<<<blocks, 256>>>(out, cyc); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
