@@ -6,6 +6,7 @@
  * reference function returns:
  *
  *   ed25519_verify_batch   loop of ed25519_verify        reference lib/eddsa.h:52
+ *   ed25519_verify_records the same over fixed-size (sig, pub, msg) records
  *   ed25519_sign_batch     loop of ed25519_sign          reference lib/eddsa.h:47
  *   ed25519_genpub_batch   loop of ed25519_genpub        reference lib/eddsa.h:44
  *   x25519_batch           loop of x25519                reference lib/eddsa.h:67
@@ -78,6 +79,15 @@ EDDSA_AMD_DECL int eddsa_amd_verify_phase_ms(float out[3]);
 EDDSA_AMD_DECL int ed25519_verify_batch(uint8_t *ok, const uint8_t *sigs, const uint8_t *pubs,
                                         const uint8_t *msgs, const uint64_t *msg_off, size_t msg_len,
                                         size_t n);
+/* The same loop of ed25519_verify (reference lib/eddsa.h:52) over n fixed-size RECORDS, for callers
+ * that hold (signature, public key, message) together: record i starts at records + i * stride and
+ * has its 64-byte signature at sig_off, its 32-byte key at pub_off and its msg_len-byte message at
+ * msg_off (e.g. stride 128 = sig | pub | 32-byte digest).  Fields may overlap nothing in particular
+ * and need no alignment; every field must lie inside the record, otherwise hipErrorInvalidValue is
+ * returned (negated).  One upload instead of three on the host path. */
+EDDSA_AMD_DECL int ed25519_verify_records(uint8_t *ok, const uint8_t *records, size_t stride,
+                                          size_t sig_off, size_t pub_off, size_t msg_off,
+                                          size_t msg_len, size_t n);
 EDDSA_AMD_DECL int ed25519_sign_batch(uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs,
                                       const uint8_t *msgs, const uint64_t *msg_off, size_t msg_len,
                                       size_t n);
@@ -91,6 +101,9 @@ EDDSA_AMD_DECL int sk_ed25519_to_x25519_batch(uint8_t *out, const uint8_t *in, s
 EDDSA_AMD_DECL int ed25519_verify_batch_dev(uint8_t *ok, const uint8_t *sigs, const uint8_t *pubs,
                                             const uint8_t *msgs, const uint64_t *msg_off,
                                             size_t msg_len, size_t n, void *stream);
+EDDSA_AMD_DECL int ed25519_verify_records_dev(uint8_t *ok, const uint8_t *records, size_t stride,
+                                              size_t sig_off, size_t pub_off, size_t msg_off,
+                                              size_t msg_len, size_t n, void *stream);
 EDDSA_AMD_DECL int ed25519_sign_batch_dev(uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs,
                                           const uint8_t *msgs, const uint64_t *msg_off,
                                           size_t msg_len, size_t n, void *stream);

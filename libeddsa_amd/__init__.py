@@ -16,6 +16,7 @@ from .api import (  # noqa: F401
     ed25519_sign_batch,
     ed25519_verify,
     ed25519_verify_batch,
+    ed25519_verify_records,
     eddsa_genpub,
     eddsa_pk_eddsa_to_dh,
     eddsa_sign,

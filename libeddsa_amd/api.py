@@ -228,6 +228,31 @@ def ed25519_verify_batch(sigs, pubs, msgs, msg_off=None, msg_len=None):
     return ok
 
 
+def ed25519_verify_records(records, sig_off, pub_off, msg_off, msg_len):
+    """loop of ed25519_verify over fixed-size records: `records` is an (n, stride) uint8 array (numpy:
+    host path, one upload; CUDA tensor: device path) holding each item's 64-byte signature at
+    sig_off, 32-byte key at pub_off and msg_len-byte message at msg_off -> (n,) uint8, 1 = accept."""
+    lib = library()
+    if _is_torch(records):
+        import torch
+        if records.dtype != torch.uint8 or records.dim() != 2 or not records.is_cuda or not records.is_contiguous():
+            raise ValueError("records: expected a contiguous (n, stride) uint8 CUDA tensor")
+        n, stride = records.shape
+        ok = torch.empty((n,), dtype=torch.uint8, device=records.device)
+        _check(lib.ed25519_verify_records_dev(_c_ptr(ok.data_ptr()), _c_ptr(records.data_ptr()), _c_size(stride),
+                                              _c_size(sig_off), _c_size(pub_off), _c_size(msg_off), _c_size(msg_len),
+                                              _c_size(n), _stream()), "ed25519_verify_records")
+        return ok
+    records = np.ascontiguousarray(np.asarray(records, dtype=np.uint8))
+    if records.ndim != 2:
+        raise ValueError("records: expected an (n, stride) uint8 array")
+    n, stride = records.shape
+    ok = np.zeros((n,), dtype=np.uint8)
+    _check(lib.ed25519_verify_records(_np_ptr(ok), _np_ptr(records), _c_size(stride), _c_size(sig_off), _c_size(pub_off),
+                                      _c_size(msg_off), _c_size(msg_len), _c_size(n)), "ed25519_verify_records")
+    return ok
+
+
 def ed25519_sign_batch(secs, pubs, msgs, msg_off=None, msg_len=None):
     """loop of ed25519_sign (reference lib/eddsa.h:47) -> (n, 64) uint8"""
     lib = library()

@@ -228,11 +228,10 @@ out:
  * device-pointer entry points
  * ---------------------------------------------------------------------------------------- */
 
-int ed25519_verify_batch_dev(uint8_t *ok, const uint8_t *sigs, const uint8_t *pubs, const uint8_t *msgs,
-                             const uint64_t *msg_off, size_t msg_len, size_t n, void *stream)
+/* both device-pointer verify entry points: chunks of at most CHUNK_MAX items through the workspace */
+static int verify_dev(uint8_t *ok, const edk_verify_src *all, size_t n, hipStream_t st)
 {
     int rc = ensure_init();
-    hipStream_t st = (hipStream_t)stream;
     if (rc || n == 0) return rc;
     pthread_mutex_lock(&g_lock);
     rc = ws_reserve(&g_eng, n < CHUNK_MAX ? n : CHUNK_MAX);
@@ -241,18 +240,41 @@ int ed25519_verify_batch_dev(uint8_t *ok, const uint8_t *sigs, const uint8_t *pu
     TRY(hipStreamWaitEvent(st, g_eng.ws_free, 0));
     for (size_t done = 0; done < n; done += CHUNK_MAX) {
         size_t m = n - done < CHUNK_MAX ? n - done : CHUNK_MAX;
-        const uint8_t *mp = msgs;
-        const uint64_t *op = NULL;
-        if (msg_off) op = msg_off + done; else mp = msgs + done * msg_len;
+        edk_verify_src src = *all;
+        src.sigs += done * all->sig_stride;
+        src.pubs += done * all->pub_stride;
+        if (all->msg_off) src.msg_off += done; else src.msgs += done * all->msg_stride;
         hipEvent_t *marks = NULL;
         if (g_eng.profiling && g_eng.marks_used < MARK_SLOTS) marks = g_eng.marks[g_eng.marks_used++];
-        TRY(edk_verify(ok + done, sigs + 64 * done, pubs + 32 * done, mp, op, msg_len, m, g_eng.base16,
-                       &g_eng.ws, marks, st));
+        TRY(edk_verify(ok + done, &src, m, g_eng.base16, &g_eng.ws, marks, st));
     }
     TRY(hipEventRecord(g_eng.ws_free, st));
 out:
     pthread_mutex_unlock(&g_lock);
     return rc;
+}
+
+int ed25519_verify_batch_dev(uint8_t *ok, const uint8_t *sigs, const uint8_t *pubs, const uint8_t *msgs,
+                             const uint64_t *msg_off, size_t msg_len, size_t n, void *stream)
+{
+    const edk_verify_src src = { sigs, pubs, msgs, msg_off, msg_len, 64, 32, msg_len };
+    return verify_dev(ok, &src, n, (hipStream_t)stream);
+}
+
+/* fixed-size records: see include/eddsa_amd.h */
+static int records_ok(size_t stride, size_t sig_off, size_t pub_off, size_t msg_off, size_t msg_len)
+{
+    return sig_off <= stride && 64 <= stride - sig_off && pub_off <= stride && 32 <= stride - pub_off &&
+           msg_off <= stride && msg_len <= stride - msg_off;
+}
+
+int ed25519_verify_records_dev(uint8_t *ok, const uint8_t *records, size_t stride, size_t sig_off, size_t pub_off,
+                               size_t msg_off, size_t msg_len, size_t n, void *stream)
+{
+    if (!records_ok(stride, sig_off, pub_off, msg_off, msg_len)) return -(int)hipErrorInvalidValue;
+    const edk_verify_src src = { records + sig_off, records + pub_off, records + msg_off, NULL, msg_len,
+                                 stride, stride, stride };
+    return verify_dev(ok, &src, n, (hipStream_t)stream);
 }
 
 /* the three fixed-base operations share one driver: chunks of at most CHUNK_MAX items through fws */
@@ -365,8 +387,9 @@ struct hjob {
     int n_in; const uint8_t *in[PIPE_MAX_IN]; size_t in_w[PIPE_MAX_IN];   /* fixed-width inputs */
     int has_msgs; const uint8_t *msgs; const uint64_t *msg_off; size_t msg_len;
     uint8_t *out; size_t out_w;
-    int (*run)(uint8_t *d_out, uint8_t *const d_in[PIPE_MAX_IN], const uint8_t *d_msgs, const uint64_t *d_off,
-               size_t msg_len, size_t m, void *stream);
+    int (*run)(const struct hjob *j, uint8_t *d_out, uint8_t *const d_in[PIPE_MAX_IN], const uint8_t *d_msgs,
+               const uint64_t *d_off, size_t msg_len, size_t m, void *stream);
+    size_t rec_sig, rec_pub, rec_msg;          /* records: offsets inside in[0]'s items (in_w[0] = stride) */
 };
 
 struct pipe {
@@ -460,7 +483,7 @@ static int pipe_run(const struct hjob *j, size_t n)
             TRY(hipEventRecord(g_pipe.in_ready[s], g_pipe.up));
             /* kernels of chunk k */
             TRY(hipStreamWaitEvent(g_pipe.exec, g_pipe.in_ready[s], 0));
-            rc = j->run((uint8_t *)g_pipe.d_out + lo * j->out_w, (uint8_t *const *)g_pipe.d_in[s],
+            rc = j->run(j, (uint8_t *)g_pipe.d_out + lo * j->out_w, (uint8_t *const *)g_pipe.d_in[s],
                         (const uint8_t *)g_pipe.d_msgs[s], ragged ? (const uint64_t *)g_pipe.d_off : NULL,
                         j->msg_len, m, g_pipe.exec);
             if (rc) goto out;
@@ -489,26 +512,31 @@ out:
     return rc;
 }
 
-static int run_verify(uint8_t *d_out, uint8_t *const d_in[PIPE_MAX_IN], const uint8_t *d_msgs, const uint64_t *d_off,
-                      size_t msg_len, size_t m, void *stream)
+#define RUN_ARGS const struct hjob *j, uint8_t *d_out, uint8_t *const d_in[PIPE_MAX_IN], const uint8_t *d_msgs, \
+                 const uint64_t *d_off, size_t msg_len, size_t m, void *stream
+static int run_verify(RUN_ARGS)
 {
+    (void)j;
     return ed25519_verify_batch_dev(d_out, d_in[0], d_in[1], d_msgs, d_off, msg_len, m, stream);
 }
-static int run_sign(uint8_t *d_out, uint8_t *const d_in[PIPE_MAX_IN], const uint8_t *d_msgs, const uint64_t *d_off,
-                    size_t msg_len, size_t m, void *stream)
+static int run_verify_records(RUN_ARGS)
 {
+    (void)d_msgs; (void)d_off;
+    return ed25519_verify_records_dev(d_out, d_in[0], j->in_w[0], j->rec_sig, j->rec_pub, j->rec_msg, msg_len, m, stream);
+}
+static int run_sign(RUN_ARGS)
+{
+    (void)j;
     return ed25519_sign_batch_dev(d_out, d_in[0], d_in[1], d_msgs, d_off, msg_len, m, stream);
 }
-static int run_x25519(uint8_t *d_out, uint8_t *const d_in[PIPE_MAX_IN], const uint8_t *d_msgs, const uint64_t *d_off,
-                      size_t msg_len, size_t m, void *stream)
+static int run_x25519(RUN_ARGS)
 {
-    (void)d_msgs; (void)d_off; (void)msg_len;
+    (void)j; (void)d_msgs; (void)d_off; (void)msg_len;
     return x25519_batch_dev(d_out, d_in[0], d_in[1], m, stream);
 }
 #define RUN_1IN(name, devfn) \
-static int name(uint8_t *d_out, uint8_t *const d_in[PIPE_MAX_IN], const uint8_t *d_msgs, const uint64_t *d_off, \
-                size_t msg_len, size_t m, void *stream) \
-{ (void)d_msgs; (void)d_off; (void)msg_len; return devfn(d_out, d_in[0], m, stream); }
+static int name(RUN_ARGS) \
+{ (void)j; (void)d_msgs; (void)d_off; (void)msg_len; return devfn(d_out, d_in[0], m, stream); }
 RUN_1IN(run_genpub, ed25519_genpub_batch_dev)
 RUN_1IN(run_xbase, x25519_base_batch_dev)
 RUN_1IN(run_pk_to_x, pk_ed25519_to_x25519_batch_dev)
@@ -517,27 +545,35 @@ RUN_1IN(run_sk_to_x, sk_ed25519_to_x25519_batch_dev)
 int ed25519_verify_batch(uint8_t *ok, const uint8_t *sigs, const uint8_t *pubs, const uint8_t *msgs,
                          const uint64_t *msg_off, size_t msg_len, size_t n)
 {
-    struct hjob j = { 2, { sigs, pubs, NULL }, { 64, 32, 0 }, 1, msgs, msg_off, msg_len, ok, 1, run_verify };
+    struct hjob j = { 2, { sigs, pubs, NULL }, { 64, 32, 0 }, 1, msgs, msg_off, msg_len, ok, 1, run_verify, 0, 0, 0 };
+    return pipe_run(&j, n);
+}
+
+int ed25519_verify_records(uint8_t *ok, const uint8_t *records, size_t stride, size_t sig_off, size_t pub_off,
+                           size_t msg_off, size_t msg_len, size_t n)
+{
+    if (!records_ok(stride, sig_off, pub_off, msg_off, msg_len)) return -(int)hipErrorInvalidValue;
+    struct hjob j = { 1, { records, NULL, NULL }, { stride, 0, 0 }, 0, NULL, NULL, msg_len, ok, 1, run_verify_records,
+                      sig_off, pub_off, msg_off };
     return pipe_run(&j, n);
 }
 
 int ed25519_sign_batch(uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs, const uint8_t *msgs,
                        const uint64_t *msg_off, size_t msg_len, size_t n)
 {
-    struct hjob j = { 2, { secs, pubs, NULL }, { 32, 32, 0 }, 1, msgs, msg_off, msg_len, sigs, 64, run_sign };
+    struct hjob j = { 2, { secs, pubs, NULL }, { 32, 32, 0 }, 1, msgs, msg_off, msg_len, sigs, 64, run_sign, 0, 0, 0 };
     return pipe_run(&j, n);
 }
 
 int x25519_batch(uint8_t *out, const uint8_t *scalars, const uint8_t *points, size_t n)
 {
-    struct hjob j = { 2, { scalars, points, NULL }, { 32, 32, 0 }, 0, NULL, NULL, 0, out, 32, run_x25519 };
+    struct hjob j = { 2, { scalars, points, NULL }, { 32, 32, 0 }, 0, NULL, NULL, 0, out, 32, run_x25519, 0, 0, 0 };
     return pipe_run(&j, n);
 }
 
-static int run_1in(int (*run)(uint8_t *, uint8_t *const *, const uint8_t *, const uint64_t *, size_t, size_t, void *),
-                   uint8_t *out, const uint8_t *in, size_t n)
+static int run_1in(int (*run)(RUN_ARGS), uint8_t *out, const uint8_t *in, size_t n)
 {
-    struct hjob j = { 1, { in, NULL, NULL }, { 32, 0, 0 }, 0, NULL, NULL, 0, out, 32, run };
+    struct hjob j = { 1, { in, NULL, NULL }, { 32, 0, 0 }, 0, NULL, NULL, 0, out, 32, run, 0, 0, 0 };
     return pipe_run(&j, n);
 }
 

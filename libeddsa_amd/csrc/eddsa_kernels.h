@@ -39,11 +39,19 @@ typedef struct edk_verify_ws {
   uint32_t* exact_pad;/* EDK_EXACT_PAD_BYTES: per-lane scratchpad of k_verify_exact */
   hipStream_t side;   /* the exact path runs here, beside the main kernel */
   hipEvent_t ev_prepared, ev_exact;
-  int exact_offcurve; /* 1: replay the reference's chain for off-curve keys (default); 0: reject them */
+  int exact_offcurve; /* 1: replay the reference's chain for off-curve keys (default); 0: reject them; 2: replay for every item */
 } edk_verify_ws;
 
-hipError_t edk_verify(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs,
-                      const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* base16,
+/* where the items of a verify pass live: item i has its signature at sigs + i * sig_stride, its key
+ * at pubs + i * pub_stride and its message at msgs + i * msg_stride (msg_len bytes) or, for ragged
+ * messages, at msgs + msg_off[i].  Packed arrays: strides 64 / 32 / msg_len; records: one stride. */
+typedef struct {
+  const uint8_t *sigs, *pubs, *msgs;
+  const uint64_t* msg_off;
+  size_t msg_len, sig_stride, pub_stride, msg_stride;
+} edk_verify_src;
+
+hipError_t edk_verify(uint8_t* ok, const edk_verify_src* src, size_t n, const uint32_t* base16,
                       const edk_verify_ws* ws, hipEvent_t* marks /* 4 events or NULL */,
                       hipStream_t stream);
 

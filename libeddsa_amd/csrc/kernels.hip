@@ -56,6 +56,16 @@ ED_DEV void msg_span(const uint8_t*& m, size_t& mlen, const uint8_t* msgs, const
   else { m = msgs + item * msg_len; mlen = msg_len; }
 }
 
+// one verify item: R, S, A as words and the message span (packed arrays or fixed-size records)
+ED_DEV void verify_item(uint32_t rw[8], uint32_t sw[8], uint32_t aw[8], const uint8_t*& m, size_t& mlen,
+                        const edk_verify_src& s, size_t item) {
+  load32(rw, s.sigs, item, s.sig_stride);
+  load32(sw, s.sigs + 32, item, s.sig_stride);
+  load32(aw, s.pubs, item, s.pub_stride);
+  if (s.msg_off) { m = s.msgs + s.msg_off[item]; mlen = (size_t)(s.msg_off[item + 1] - s.msg_off[item]); }
+  else { m = s.msgs + item * s.msg_stride; mlen = s.msg_len; }
+}
+
 // copy a table of `words` 32-bit words (a multiple of 4, 16-byte aligned) from HBM into LDS (whole block)
 ED_DEV void stage_table(uint32_t* lds, const uint32_t* src, int words) {
   word4* d = reinterpret_cast<word4*>(lds);
@@ -112,17 +122,13 @@ __global__ void __launch_bounds__(64) k_init_comb_image(uint32_t* img, const uin
 // ---------------------------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(BLOCK, 2)
-k_verify_prepare(const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs,
-                 const uint64_t* msg_off, size_t msg_len, size_t n, uint32_t* digits,
+k_verify_prepare(edk_verify_src src, size_t n, uint32_t* digits,
                  uint32_t* table, uint8_t* flags, uint32_t* offlist, uint32_t* offcount, int all_exact) {
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const size_t item = i < n ? i : n - 1;         // idle lanes redo the last item into their own slot
   uint32_t rw[8], aw[8], sw[8], tw[8];
-  load32(rw, sigs, item, 64);
-  load32(sw, sigs + 32, item, 64);
-  load32(aw, pubs, item, 32);
   const uint8_t* m; size_t mlen;
-  msg_span(m, mlen, msgs, msg_off, msg_len, item);
+  verify_item(rw, sw, aw, m, mlen, src, item);
   const bool oncurve = verify_prepare_lane(tw, sw, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
                                            rw, aw, m, mlen);
   uint4* d = reinterpret_cast<uint4*>(digits + 16 * i);
@@ -146,8 +152,7 @@ constexpr int EXACT_MAX_BLOCKS = 1024;
 constexpr int EXACT_PAD_WORDS = 160 + 2 * ((REF_JSF_LEN + 3) / 4);   /* per lane: 4 addends + 2 digit strings */
 
 __global__ void __launch_bounds__(EXACT_BLOCK, 4)
-k_verify_exact(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs,
-               const uint64_t* msg_off, size_t msg_len, const uint32_t* offlist, const uint32_t* offcount,
+k_verify_exact(uint8_t* ok, edk_verify_src src, const uint32_t* offlist, const uint32_t* offcount,
                const uint32_t* base16, uint32_t* pad, size_t first) {
   const size_t count = *offcount;
   // this wave's scratchpad, lane-interleaved (element k of lane t at [k * 64 + t]: coalesced)
@@ -158,11 +163,8 @@ k_verify_exact(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, const uint
   for (size_t g = first + (size_t)blockIdx.x * EXACT_BLOCK + threadIdx.x; g < count; g += (size_t)gridDim.x * EXACT_BLOCK) {
     const size_t i = offlist[g];
     uint32_t rw[8], sw[8], aw[8];
-    load32(rw, sigs, i, 64);
-    load32(sw, sigs + 32, i, 64);
-    load32(aw, pubs, i, 32);
     const uint8_t* m; size_t mlen;
-    msg_span(m, mlen, msgs, msg_off, msg_len, i);
+    verify_item(rw, sw, aw, m, mlen, src, i);
     ok[i] = (uint8_t)verify_exact_lane(rw, sw, aw, m, mlen, base16 + TABLE_ENTRY_WORDS, ux, uy, pts, EXACT_BLOCK);
   }
 }
@@ -181,18 +183,14 @@ k_verify_exact(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, const uint
 // round: +0.6 ms for 1024 listed keys as for 8192, +1.0 ms for 65536 (it was +1.6 ms with
 // single-wave chain blocks, which displaced a main block each).
 __global__ void __launch_bounds__(EXACT_BLOCK, 2)
-k_verify_exact_setup(const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs, const uint64_t* msg_off,
-                     size_t msg_len, const uint32_t* offlist, const uint32_t* offcount, const uint32_t* base16,
+k_verify_exact_setup(edk_verify_src src, const uint32_t* offlist, const uint32_t* offcount, const uint32_t* base16,
                      uint32_t* pad) {
   const size_t g = (size_t)blockIdx.x * EXACT_BLOCK + threadIdx.x;
   if (g >= *offcount) return;
   const size_t i = offlist[g];
   uint32_t rw[8], sw[8], aw[8];
-  load32(rw, sigs, i, 64);
-  load32(sw, sigs + 32, i, 64);
-  load32(aw, pubs, i, 32);
   const uint8_t* m; size_t mlen;
-  msg_span(m, mlen, msgs, msg_off, msg_len, i);
+  verify_item(rw, sw, aw, m, mlen, src, i);
   uint32_t* base = pad + (size_t)blockIdx.x * (EXACT_PAD_WORDS * EXACT_BLOCK);
   int8_t* ux = reinterpret_cast<int8_t*>(base + 160 * EXACT_BLOCK) + threadIdx.x;
   verify_exact_setup_lane(rw, sw, aw, m, mlen, base16 + TABLE_ENTRY_WORDS, ux, ux + REF_JSF_LEN * EXACT_BLOCK,
@@ -201,15 +199,15 @@ k_verify_exact_setup(const uint8_t* sigs, const uint8_t* pubs, const uint8_t* ms
 
 constexpr int CHAIN_WAVES = 4;                   // waves per chain block: one per SIMD, the footprint of ONE k_verify_main block
 __global__ void __launch_bounds__(EXACT_BLOCK * CHAIN_WAVES, 2)
-k_verify_exact_chain(uint8_t* ok, const uint8_t* sigs, const uint32_t* offlist, const uint32_t* offcount,
-                     const uint32_t* pad) {
+k_verify_exact_chain(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const uint32_t* offlist,
+                     const uint32_t* offcount, const uint32_t* pad) {
   const size_t wave = (size_t)blockIdx.x * CHAIN_WAVES + (threadIdx.x >> 6);
   const unsigned lane = threadIdx.x & 63u;
   const size_t g = wave * EXACT_BLOCK + lane;
   if (g >= *offcount) return;
   const size_t i = offlist[g];
   uint32_t rw[8];
-  load32(rw, sigs, i, 64);
+  load32(rw, sigs, i, sig_stride);
   const uint32_t* base = pad + wave * (EXACT_PAD_WORDS * EXACT_BLOCK);
   const int8_t* ux = reinterpret_cast<const int8_t*>(base + 160 * EXACT_BLOCK) + lane;
   ok[i] = (uint8_t)verify_exact_chain_lane(rw, ux, ux + REF_JSF_LEN * EXACT_BLOCK, base + lane, EXACT_BLOCK);
@@ -318,7 +316,7 @@ ED_DEV void den_commit(fe& z, bool good, uint32_t* acc, int k) {
 // verdict; DESIGN.md "Off-curve public keys"); Z = 0 cannot occur for a curve point (the a = -1 law
 // is complete) and is rejected defensively.
 struct verify_finish_policy {
-  uint8_t* ok; const uint8_t* sigs; uint32_t* acc; uint8_t* flags; size_t n; int exact_offcurve;
+  uint8_t* ok; const uint8_t* sigs; size_t sig_stride; uint32_t* acc; uint8_t* flags; size_t n; int exact_offcurve;
   ED_DEV void den(int k, fe& z) const {
     const finish_pos p = finish_at(k, acc);
     fe_set(z, 1);
@@ -337,7 +335,7 @@ struct verify_finish_policy {
     fe x, y, zinv;
     acc_load(x, p.acc, 0); acc_load(y, p.acc, 1); acc_load(zinv, p.acc, 2);
     uint32_t rw[8];
-    load32(rw, sigs, p.i, 64);
+    load32(rw, sigs, p.i, sig_stride);
     const uint8_t fl = flags[p.i];
     if ((fl & 1) == 0) {                         // off-curve key
       if (!exact_offcurve) ok[p.i] = 0;          // reject mode; otherwise k_verify_exact owns ok[i]
@@ -348,8 +346,9 @@ struct verify_finish_policy {
 };
 
 __global__ void __launch_bounds__(BLOCK, 2)
-k_verify_finish(uint8_t* ok, const uint8_t* sigs, uint32_t* acc, uint8_t* flags, size_t n, int exact_offcurve) {
-  finish_batch8(verify_finish_policy{ok, sigs, acc, flags, n, exact_offcurve}, acc);
+k_verify_finish(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, uint32_t* acc, uint8_t* flags, size_t n,
+                int exact_offcurve) {
+  finish_batch8(verify_finish_policy{ok, sigs, sig_stride, acc, flags, n, exact_offcurve}, acc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -551,39 +550,37 @@ hipError_t edk_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* point
   return hipGetLastError();
 }
 
-hipError_t edk_verify(uint8_t* ok, const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs,
-                      const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* base16,
+hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const uint32_t* base16,
                       const edk_verify_ws* ws, hipEvent_t* marks, hipStream_t stream) {
+  const edk_verify_src src = *srcp;
   if (n == 0) return hipSuccess;
   const unsigned blocks = (unsigned)((n + BLOCK - 1) / BLOCK);
   (void)hipMemsetAsync(ws->offcount, 0, sizeof(uint32_t), stream);
   if (marks) (void)hipEventRecord(marks[0], stream);
-  hipLaunchKernelGGL(k_verify_prepare, dim3(blocks), dim3(BLOCK), 0, stream, sigs, pubs, msgs, msg_off,
-                     msg_len, n, ws->digits, ws->table, ws->flags, ws->offlist, ws->offcount,
+  hipLaunchKernelGGL(k_verify_prepare, dim3(blocks), dim3(BLOCK), 0, stream, src, n, ws->digits, ws->table, ws->flags, ws->offlist, ws->offcount,
                      ws->exact_offcurve == 2);
   if (marks) (void)hipEventRecord(marks[1], stream);
   // the exact path depends only on prepare: run it beside the main kernel on the side stream
   const unsigned eb = (unsigned)((n + EXACT_BLOCK - 1) / EXACT_BLOCK);
   const unsigned eb1 = eb < (unsigned)EXACT_MAX_BLOCKS ? eb : (unsigned)EXACT_MAX_BLOCKS;
   if (ws->exact_offcurve) {
-    hipLaunchKernelGGL(k_verify_exact_setup, dim3(eb1), dim3(EXACT_BLOCK), 0, stream, sigs, pubs, msgs, msg_off,
-                       msg_len, ws->offlist, ws->offcount, base16, ws->exact_pad);
+    hipLaunchKernelGGL(k_verify_exact_setup, dim3(eb1), dim3(EXACT_BLOCK), 0, stream, src, ws->offlist,
+                       ws->offcount, base16, ws->exact_pad);
     (void)hipEventRecord(ws->ev_prepared, stream);
     (void)hipStreamWaitEvent(ws->side, ws->ev_prepared, 0);
     hipLaunchKernelGGL(k_verify_exact_chain, dim3((eb1 + CHAIN_WAVES - 1) / CHAIN_WAVES), dim3(EXACT_BLOCK * CHAIN_WAVES),
-                       0, ws->side, ok, sigs, ws->offlist, ws->offcount, ws->exact_pad);
+                       0, ws->side, ok, src.sigs, src.sig_stride, ws->offlist, ws->offcount, ws->exact_pad);
     (void)hipEventRecord(ws->ev_exact, ws->side);
   }
   hipLaunchKernelGGL(k_verify_main, dim3(blocks), dim3(BLOCK), 0, stream, ws->digits, ws->table, base16, ws->acc);
   if (marks) (void)hipEventRecord(marks[2], stream);
-  hipLaunchKernelGGL(k_verify_finish, dim3((blocks + FINISH_K - 1) / FINISH_K), dim3(BLOCK), 0, stream, ok, sigs,
-                     ws->acc, ws->flags, n, ws->exact_offcurve);
+  hipLaunchKernelGGL(k_verify_finish, dim3((blocks + FINISH_K - 1) / FINISH_K), dim3(BLOCK), 0, stream, ok, src.sigs,
+                     src.sig_stride, ws->acc, ws->flags, n, ws->exact_offcurve);
   if (marks) (void)hipEventRecord(marks[3], stream);
   if (ws->exact_offcurve) {
     (void)hipStreamWaitEvent(stream, ws->ev_exact, 0);   // complete when both paths are
     if (eb > eb1)   // more than 65536 off-curve keys in the pass: the rest, strided, one (spilling) kernel
-      hipLaunchKernelGGL(k_verify_exact, dim3(EXACT_MAX_BLOCKS), dim3(EXACT_BLOCK), 0, stream, ok, sigs, pubs, msgs,
-                         msg_off, msg_len, ws->offlist, ws->offcount, base16, ws->exact_pad,
+      hipLaunchKernelGGL(k_verify_exact, dim3(EXACT_MAX_BLOCKS), dim3(EXACT_BLOCK), 0, stream, ok, src, ws->offlist, ws->offcount, base16, ws->exact_pad,
                          (size_t)EXACT_MAX_BLOCKS * EXACT_BLOCK);
   }
   return hipGetLastError();

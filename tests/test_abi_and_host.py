@@ -81,6 +81,13 @@ def test_argument_validation():
                                 msg_off=[0, 3, 9])
     with pytest.raises(ValueError):
         ed.ed25519_sign(bytes(31), bytes(32), b"")
+    # records: every field must lie inside the record (checked in C, before any device work)
+    with pytest.raises(ed.EddsaAmdError):
+        ed.ed25519_verify_records(np.zeros((2, 100), np.uint8), 40, 0, 0, 32)      # signature sticks out
+    with pytest.raises(ed.EddsaAmdError):
+        ed.ed25519_verify_records(np.zeros((2, 128), np.uint8), 0, 64, 100, 32)    # message sticks out
+    with pytest.raises(ValueError):
+        ed.ed25519_verify_records(np.zeros(128, np.uint8), 0, 64, 96, 32)
 
 
 def test_shard_bounds_partition():

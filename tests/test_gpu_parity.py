@@ -211,6 +211,31 @@ def test_every_item_through_the_reference_order_kernels(engine):
     assert np.array_equal(replay, expect)
 
 
+@pytest.mark.parametrize("stride,sig_off,pub_off,msg_off,mlen", [(128, 0, 64, 96, 32), (137, 41, 5, 105, 32),
+                                                                 (160, 96, 64, 0, 61), (96, 0, 64, 96, 0)])
+def test_verify_records(engine, oracle, stride, sig_off, pub_off, msg_off, mlen):
+    """fixed-size (sig, pub, msg) records: same verdicts as the packed arrays and as the oracle, on the
+    host path and on the device path, aligned and unaligned layouts, empty messages"""
+    import workload
+    n = 3000
+    rng = np.random.default_rng(stride)
+    sk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    msg = rng.integers(0, 256, (n, mlen), dtype=np.uint8)
+    pk = oracle.genpub_batch(sk)
+    sig = oracle.sign_batch(sk, pk, msg, mlen)
+    sig[::7, 3] ^= 1; pk[3::11, 9] ^= 0x40                       # some corrupt signatures and keys (off-curve ones too)
+    if mlen:
+        msg[5::13, 0] ^= 2
+    rec = rng.integers(0, 256, (n, stride), dtype=np.uint8)      # garbage between the fields
+    rec[:, sig_off:sig_off + 64] = sig
+    rec[:, pub_off:pub_off + 32] = pk
+    rec[:, msg_off:msg_off + mlen] = msg
+    want = oracle.verify_batch(sig, pk, msg, mlen)
+    assert 0 < want.sum() < n
+    assert np.array_equal(engine.ed25519_verify_records(rec, sig_off, pub_off, msg_off, mlen), want)
+    assert np.array_equal(engine.ed25519_verify_records(dev(rec), sig_off, pub_off, msg_off, mlen).cpu().numpy(), want)
+
+
 def test_unaligned_device_buffers(engine, oracle):
     """device pointers that are not 16-byte aligned take the byte-wise load/store path"""
     import torch
