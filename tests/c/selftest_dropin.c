@@ -100,6 +100,21 @@ int main(int argc, char **argv)
         CHECK(ed25519_sign_batch(chk, sk, pk, msgs, off, 0, ne) == 0 && memcmp(chk, sig, 64 * ne) == 0, "ed25519_sign_batch");
         CHECK(ed25519_verify_batch(ok, sig, pk, msgs, off, 0, ne) == 0, "ed25519_verify_batch failed");
         for (size_t i = 0; i < ne; i++) CHECK(ok[i] == 1, "ed25519_verify_batch rejected number %zu", i + 1);
+        {   /* record form: the public keys signed as 32-byte messages, one 136-byte record per item
+             * (4 bytes of header, sig, pub, msg, 4 bytes of trailer), every third signature forged */
+            const size_t stride = 136;
+            uint8_t *rec = calloc(ne, stride);
+            CHECK(ed25519_sign_batch(chk, sk, pk, pk, NULL, 32, ne) == 0, "ed25519_sign_batch (fixed length)");
+            for (size_t i = 0; i < ne; i++) {
+                uint8_t *r = rec + stride * i;
+                memcpy(r + 4, chk + 64 * i, 64); memcpy(r + 68, pk + 32 * i, 32); memcpy(r + 100, pk + 32 * i, 32);
+                if (i % 3 == 2) r[4 + 40] ^= 1;
+            }
+            CHECK(ed25519_verify_records(ok, rec, stride, 4, 68, 100, 32, ne) == 0, "ed25519_verify_records failed");
+            for (size_t i = 0; i < ne; i++) CHECK(ok[i] == (i % 3 != 2), "ed25519_verify_records verdict %zu", i + 1);
+            CHECK(ed25519_verify_records(ok, rec, stride, 80, 68, 100, 32, ne) != 0, "a signature outside the record was accepted as a layout");
+            free(rec);
+        }
         free(off); free(sk); free(pk); free(sig); free(chk); free(ok);
     }
     eddsa_amd_shutdown();
