@@ -7,13 +7,17 @@
 
 #ifndef TABLE_BASE16_ENTRIES      /* also defined, identically, by lanes.h for the device side */
 #define TABLE_BASE16_ENTRIES 32769 /* k*B, k = 0..32768 */
-#define TABLE_COMB_ENTRIES 256    /* (k+1)*256^i*B, i < 32, k < 8: ed.c:41-43 ed_lookup */
+#define COMB_W 5                  /* signed window width of the fixed-base comb (the reference's is 4, ed.c:397-430) */
+#define COMB_HALF (1 << (COMB_W - 1))          /* digits d in [-COMB_HALF, COMB_HALF - 1] */
+#define COMB_DIGITS (COMB_W == 4 ? 64 : 52)    /* digits of x + offset: 64 x 4 bits, or 52 x 5 bits (260 bits) */
+#define COMB_ROWS (COMB_DIGITS / 2)            /* even digits and odd digits share a row */
+#define TABLE_COMB_ENTRIES (COMB_ROWS * COMB_HALF) /* comb[i][k] = (k+1) * 2^(2*COMB_W*i) * B, k < COMB_HALF */
 #define TABLE_ENTRY_WORDS 32      /* 3 x 10 limbs + 2 padding words */
 #define VERIFY_TABLE_ENTRIES 9    /* 0..8 times -A, cached form */
 #define VERIFY_ENTRY_WORDS 40     /* ymx | ypx | t2d | z2 */
-#define COMB_IMG_ENTRIES 16       /* LDS image of a comb row: d * 256^i * B for d = -8..7 */
+#define COMB_IMG_ENTRIES (2 * COMB_HALF) /* LDS image of a comb row: entry d + COMB_HALF = d * 2^(2*COMB_W*i) * B */
 #define COMB_IMG_ENTRY_WORDS 36
-#define COMB_IMG_WORDS (32 * COMB_IMG_ENTRIES * COMB_IMG_ENTRY_WORDS)
+#define COMB_IMG_WORDS (COMB_ROWS * COMB_IMG_ENTRIES * COMB_IMG_ENTRY_WORDS)
 #endif
 #define VERIFY_TABLE_WORDS_PER_TILE (VERIFY_TABLE_ENTRIES * 40 * 256)
 #define VERIFY_TILE 256            /* items per tile = threads per block */

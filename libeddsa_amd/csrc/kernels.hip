@@ -70,7 +70,7 @@ ED_DEV void verify_item(uint32_t rw[8], uint32_t sw[8], uint32_t aw[8], const ui
 ED_DEV void stage_table(uint32_t* lds, const uint32_t* src, int words) {
   word4* d = reinterpret_cast<word4*>(lds);
   const word4* s = reinterpret_cast<const word4*>(src);
-  for (int j = threadIdx.x; j < words / 4; j += BLOCK) d[j] = s[j];
+  for (int j = threadIdx.x; j < words / 4; j += (int)blockDim.x) d[j] = s[j];
   __syncthreads();
 }
 
@@ -93,15 +93,15 @@ __global__ void __launch_bounds__(64) k_init_tables(uint32_t* base16, uint32_t* 
   if (id < TABLE_BASE16_ENTRIES) {
     table_entry_lane(base16 + (size_t)TABLE_ENTRY_WORDS * id, (uint32_t)id, 0);
   } else {
-    const int c = id - TABLE_BASE16_ENTRIES;      // comb[i][k], c = 8 i + k
-    table_entry_lane(comb + TABLE_ENTRY_WORDS * c, (uint32_t)(c & 7) + 1, 8u * (uint32_t)(c >> 3));
+    const int c = id - TABLE_BASE16_ENTRIES;      // comb[i][k], c = COMB_HALF i + k
+    table_entry_lane(comb + TABLE_ENTRY_WORDS * c, (uint32_t)(c % COMB_HALF) + 1, 2u * COMB_W * (uint32_t)(c / COMB_HALF));
   }
 }
 
 // the LDS image of the comb (lanes.h: comb_select), one thread per entry
 __global__ void __launch_bounds__(64) k_init_comb_image(uint32_t* img, const uint32_t* comb) {
   const int id = blockIdx.x * 64 + threadIdx.x;
-  if (id >= 32 * COMB_IMG_ENTRIES) return;
+  if (id >= COMB_ROWS * COMB_IMG_ENTRIES) return;
   comb_image_entry_lane(img + COMB_IMG_ENTRY_WORDS * id, comb, id / COMB_IMG_ENTRIES, id % COMB_IMG_ENTRIES);
 }
 
@@ -252,8 +252,9 @@ ED_DEV void acc_load(fe& f, const uint32_t* acc, int coord) {
 #pragma unroll
   for (int j = 0; j < 10; j++) f.v[j] = acc[(10 * coord + j) * BLOCK];
 }
-ED_DEV void acc_store(uint32_t* accout, const ge& p) {
-  uint32_t* o = accout + (size_t)blockIdx.x * (30 * BLOCK) + threadIdx.x;
+// i = the lane's global item slot (tile i / BLOCK, lane i % BLOCK), whatever the block size
+ED_DEV void acc_store(uint32_t* accout, size_t i, const ge& p) {
+  uint32_t* o = accout + (i / BLOCK) * (30 * BLOCK) + (i % BLOCK);
 #pragma unroll
   for (int j = 0; j < 10; j++) {
     o[j * BLOCK] = p.X.v[j]; o[(10 + j) * BLOCK] = p.Y.v[j]; o[(20 + j) * BLOCK] = p.Z.v[j];
@@ -352,21 +353,23 @@ k_verify_finish(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, uint32_t* a
 }
 
 // ---------------------------------------------------------------------------------------------
-// fixed-base kernels: the image of the comb (32 rows x 16 signed entries, 72 KiB; two blocks per
-// CU) is staged in LDS by every block of a "point" kernel; the matching "finish" kernel encodes
-// (and, for sign, hashes and computes S)
+// fixed-base kernels: the image of the comb (26 rows x 32 signed entries, 117 KiB of the CU's
+// 160 KiB LDS; one 512-lane block per CU, two waves per SIMD) is staged by every block of a
+// "point" kernel; the matching "finish" kernel encodes (and, for sign, hashes and computes S)
 // ---------------------------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(BLOCK, 2)
+constexpr int POINT_BLOCK = COMB_IMG_WORDS * 4 > 80 * 1024 ? 512 : 256;   // 8 waves per CU either way
+
+__global__ void __launch_bounds__(POINT_BLOCK, 512 / POINT_BLOCK)
 k_genpub_point(uint32_t* accout, const uint8_t* secs, size_t n, const uint32_t* comb) {
   __shared__ alignas(16) uint32_t lds_comb[COMB_IMG_WORDS];
   stage_table(lds_comb, comb, COMB_IMG_WORDS);
-  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const size_t i = (size_t)blockIdx.x * POINT_BLOCK + threadIdx.x;
   uint32_t sk[8];
   load32(sk, secs, i < n ? i : n - 1, 32);
   ge A;
   genpub_point_lane(A, sk, lds_comb);
-  acc_store(accout, A);
+  acc_store(accout, i, A);
 }
 
 // Z of a comb result is never 0 (B and its multiples are curve points)
@@ -394,12 +397,12 @@ k_encode_finish(uint8_t* out, uint32_t* acc, size_t n) {
   finish_batch8(encode_finish_policy{out, acc, n}, acc);
 }
 
-__global__ void __launch_bounds__(BLOCK, 2)
+__global__ void __launch_bounds__(POINT_BLOCK, 512 / POINT_BLOCK)
 k_sign_point(uint32_t* accout, uint32_t* aux, const uint8_t* secs, const uint8_t* msgs,
              const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* comb) {
   __shared__ alignas(16) uint32_t lds_comb[COMB_IMG_WORDS];
   stage_table(lds_comb, comb, COMB_IMG_WORDS);
-  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const size_t i = (size_t)blockIdx.x * POINT_BLOCK + threadIdx.x;
   const size_t item = i < n ? i : n - 1;
   const uint8_t* m; size_t mlen;
   msg_span(m, mlen, msgs, msg_off, msg_len, item);
@@ -407,7 +410,7 @@ k_sign_point(uint32_t* accout, uint32_t* aux, const uint8_t* secs, const uint8_t
   load32(sk, secs, item, 32);
   ge R;
   sign_point_lane(R, aw, rw, sk, m, mlen, lds_comb);
-  acc_store(accout, R);
+  acc_store(accout, i, R);
   uint4* d = reinterpret_cast<uint4*>(aux + 16 * i);     // the secret scalars a and r, for the finish step
   d[0] = make_uint4(aw[0], aw[1], aw[2], aw[3]); d[1] = make_uint4(aw[4], aw[5], aw[6], aw[7]);
   d[2] = make_uint4(rw[0], rw[1], rw[2], rw[3]); d[3] = make_uint4(rw[4], rw[5], rw[6], rw[7]);
@@ -450,18 +453,18 @@ k_sign_finish(uint8_t* sigs, uint32_t* acc, uint32_t* aux, const uint8_t* pubs, 
   finish_batch8(sign_finish_policy{sigs, acc, aux, pubs, msgs, msg_off, msg_len, n}, acc);
 }
 
-__global__ void __launch_bounds__(BLOCK, 2)
+__global__ void __launch_bounds__(POINT_BLOCK, 512 / POINT_BLOCK)
 k_x25519_base_point(uint32_t* accout, const uint8_t* scalars, size_t n, const uint32_t* comb) {
   __shared__ alignas(16) uint32_t lds_comb[COMB_IMG_WORDS];
   stage_table(lds_comb, comb, COMB_IMG_WORDS);
-  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const size_t i = (size_t)blockIdx.x * POINT_BLOCK + threadIdx.x;
   uint32_t s[8];
   load32(s, scalars, i < n ? i : n - 1, 32);
   ge R;
   x25519_base_point_lane(R, s, lds_comb);
   fe_add(R.X, R.Z, R.Y);                         // the finish step needs z + y, not x
   fe_carry(R.X);
-  acc_store(accout, R);
+  acc_store(accout, i, R);
 }
 
 // u = (z + y) / (z - y); z = y gives 0 in the reference (fld_inv(0) = 0, x25519.c:192): such an
@@ -538,7 +541,7 @@ extern "C" {
 hipError_t edk_init_tables(uint32_t* base16, uint32_t* comb, uint32_t* comb_img, hipStream_t stream) {
   const int total = TABLE_BASE16_ENTRIES + TABLE_COMB_ENTRIES;
   hipLaunchKernelGGL(k_init_tables, dim3((total + 63) / 64), dim3(64), 0, stream, base16, comb);
-  hipLaunchKernelGGL(k_init_comb_image, dim3(32 * COMB_IMG_ENTRIES / 64), dim3(64), 0, stream, comb_img, comb);
+  hipLaunchKernelGGL(k_init_comb_image, dim3((COMB_ROWS * COMB_IMG_ENTRIES + 63) / 64), dim3(64), 0, stream, comb_img, comb);
   return hipGetLastError();
 }
 
@@ -588,12 +591,13 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
 
 #define EDK_GRID(n) dim3((unsigned)(((n) + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream
 
+#define EDK_POINT_GRID(n) dim3((unsigned)(((n) + POINT_BLOCK - 1) / POINT_BLOCK)), dim3(POINT_BLOCK), 0, stream
 #define EDK_FINISH_GRID(n) dim3((unsigned)((((n) + BLOCK - 1) / BLOCK + FINISH_K - 1) / FINISH_K)), dim3(BLOCK), 0, stream
 
 hipError_t edk_genpub(uint8_t* pubs, const uint8_t* secs, size_t n, const uint32_t* comb,
                       const edk_fixed_ws* ws, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_genpub_point, EDK_GRID(n), ws->acc, secs, n, comb);
+  hipLaunchKernelGGL(k_genpub_point, EDK_POINT_GRID(n), ws->acc, secs, n, comb);
   hipLaunchKernelGGL(k_encode_finish, EDK_FINISH_GRID(n), pubs, ws->acc, n);
   return hipGetLastError();
 }
@@ -602,7 +606,7 @@ hipError_t edk_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, con
                     const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* comb,
                     const edk_fixed_ws* ws, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_sign_point, EDK_GRID(n), ws->acc, ws->aux, secs, msgs, msg_off, msg_len, n, comb);
+  hipLaunchKernelGGL(k_sign_point, EDK_POINT_GRID(n), ws->acc, ws->aux, secs, msgs, msg_off, msg_len, n, comb);
   hipLaunchKernelGGL(k_sign_finish, EDK_FINISH_GRID(n), sigs, ws->acc, ws->aux, pubs, msgs, msg_off, msg_len, n);
   return hipGetLastError();
 }
@@ -610,7 +614,7 @@ hipError_t edk_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, con
 hipError_t edk_x25519_base(uint8_t* out, const uint8_t* scalars, size_t n, const uint32_t* comb,
                            const edk_fixed_ws* ws, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_x25519_base_point, EDK_GRID(n), ws->acc, scalars, n, comb);
+  hipLaunchKernelGGL(k_x25519_base_point, EDK_POINT_GRID(n), ws->acc, scalars, n, comb);
   hipLaunchKernelGGL(k_x25519_base_finish, EDK_FINISH_GRID(n), out, ws->acc, n);
   return hipGetLastError();
 }

@@ -20,11 +20,15 @@
 #include "sha512.h"
 
 #define TABLE_BASE16_ENTRIES 32769 /* k*B, k = 0..32768: 16-bit signed windows of S (4 MiB, L2/MALL) */
-#define TABLE_COMB_ENTRIES 256    /* (k+1)*256^i*B, i < 32, k < 8: ed.c:41-43 ed_lookup */
+#define COMB_W 5                  /* signed window width of the fixed-base comb (the reference's is 4, ed.c:397-430) */
+#define COMB_HALF (1 << (COMB_W - 1))          /* digits d in [-COMB_HALF, COMB_HALF - 1] */
+#define COMB_DIGITS (COMB_W == 4 ? 64 : 52)    /* digits of x + offset: 64 x 4 bits, or 52 x 5 bits (260 bits) */
+#define COMB_ROWS (COMB_DIGITS / 2)            /* even digits and odd digits share a row */
+#define TABLE_COMB_ENTRIES (COMB_ROWS * COMB_HALF) /* comb[i][k] = (k+1) * 2^(2*COMB_W*i) * B, k < COMB_HALF */
 #define TABLE_ENTRY_WORDS 32      /* 3 x 10 limbs + 2 padding words */
-#define COMB_IMG_ENTRIES 16       /* LDS image of a comb row: d * 256^i * B for d = -8..7 (entry d + 8) */
+#define COMB_IMG_ENTRIES (2 * COMB_HALF) /* LDS image of a comb row: entry d + COMB_HALF = d * 2^(2*COMB_W*i) * B */
 #define COMB_IMG_ENTRY_WORDS 36   /* 30 limbs + 6 padding words: entries start 4 banks apart */
-#define COMB_IMG_WORDS (32 * COMB_IMG_ENTRIES * COMB_IMG_ENTRY_WORDS)
+#define COMB_IMG_WORDS (COMB_ROWS * COMB_IMG_ENTRIES * COMB_IMG_ENTRY_WORDS)
 #define VERIFY_TABLE_ENTRIES 9    /* 0..8 times -A, cached form */
 #define VERIFY_ENTRY_WORDS 40     /* ymx | ypx | t2d | z2 */
 
@@ -534,24 +538,31 @@ ED_DEV bool verify_exact_lane(const uint32_t rw[8], const uint32_t sraw[8], cons
 // ---------------------------------------------------------------------------------------------
 // fixed-base path: ed.c:346-430 (scale16, ed_scale_base) and its callers
 // ---------------------------------------------------------------------------------------------
-// Same comb as the reference: 64 signed 4-bit digits of (x + 0x88..8); even digits accumulate in
-// R0, odd digits in R1, both from row i of comb[32][8]; R1 <- 16 R1; R0 + R1.
+// The reference's comb (ed.c:397-430) with a wider window: x + offset is cut into COMB_DIGITS
+// signed COMB_W-bit digits d_j in [-COMB_HALF, COMB_HALF - 1] (ed.c:407-409's recoding: add
+// COMB_HALF at every digit position, then subtract it from every digit); even digits accumulate
+// in R0, odd digits in R1, both from row i = j / 2 of the table comb[i][k] = (k+1) * 2^(2 w i) * B;
+// then R1 <- 2^w R1 and out = R0 + R1.  The reference has w = 4 (64 digits, 32 rows of 8); here
+// w = 5: 52 digits, 26 rows of 16, i.e. 52 mixed additions instead of 64 for one more doubling.
+// x * B is the same group element either way and only its affine encoding leaves the kernels (the
+// addition law of ed.c:282-305 is complete on this curve), so the bytes are the reference's.
 // The scalar is secret here, so the lookup keeps the reference's constant-time discipline
-// (ed.c:359-390): no memory address and no branch depends on the digit.  On the device the row is
-// staged in LDS as 16 ready-made entries d * 256^i * B, d = -8..7 (sign and the neutral element
-// already applied, `comb_image_entry_lane`); lane L of every wave reads entry L mod 16 -- an
+// (ed.c:359-390): no memory address and no branch depends on the digit.  On the device the table
+// is staged in LDS as 2 * COMB_HALF ready-made entries per row, d * 2^(2 w i) * B for every digit
+// value d (sign and the neutral element already applied, `comb_image_entry_lane`: 26 x 32 x 144
+// bytes = 117 KiB, one 512-lane block per CU); lane L of every wave reads entry L mod 32 -- an
 // address that depends on the lane number only -- and each lane then takes the entry it needs
-// from lane `nibble` of its own wave with ds_bpermute_b32, the cross-lane shuffle of the LDS
-// crossbar (30 of them per lookup, on the LDS pipe, beside the VALU work of the previous
-// addition).  The first version scanned all eight entries with v_cndmask: 240 selects + 40 for
+// from lane (d + COMB_HALF) of its own wave with ds_bpermute_b32, the cross-lane shuffle of the
+// LDS crossbar (30 per lookup, on the LDS pipe, beside the VALU work of the previous addition).
+// The first version scanned all eight entries of a w = 4 row with v_cndmask: 240 selects + 40 for
 // the conditional negation per lookup, 15 % of the kernel's instructions.
 
-// entry s = d + 8 of the image of comb row `row` (comb = the 256-entry table, global layout)
+// entry s = d + COMB_HALF of the image of comb row `row` (comb = the table in its global layout)
 ED_DEV void comb_image_entry_lane(uint32_t* dst, const uint32_t* comb, int row, int s) {
-  const int d = s - 8, mag = d < 0 ? -d : d;
+  const int d = s - COMB_HALF, mag = d < 0 ? -d : d;
   ge_niels e;
   fe_set(e.ymx, 1); fe_set(e.ypx, 1); fe_set(e.t2d, 0);        // ed.c:73 pced_zero
-  if (mag != 0) niels_load(e, comb + TABLE_ENTRY_WORDS * (8 * row + mag - 1));
+  if (mag != 0) niels_load(e, comb + TABLE_ENTRY_WORDS * (COMB_HALF * row + mag - 1));
   if (d < 0) {                                                  // ed.c:383-389: swap diff/sum, negate prod
     ge_niels_cneg(e, true);
     fe_carry(e.t2d);
@@ -563,26 +574,26 @@ ED_DEV void comb_image_entry_lane(uint32_t* dst, const uint32_t* comb, int row, 
 }
 
 #ifdef ED_HOST_CHECK
-// host build: `table` is the 256-entry comb in its global layout; plain indexed lookup
-ED_DEV void comb_select(ge_niels& e, const uint32_t* table, int row, uint32_t nibble) {
-  const int d = (int)nibble - 8, mag = d < 0 ? -d : d;
+// host build: `table` is the comb in its global layout [COMB_ROWS][COMB_HALF]; plain indexed lookup
+ED_DEV void comb_select(ge_niels& e, const uint32_t* table, int row, uint32_t digit) {
+  const int d = (int)digit - COMB_HALF, mag = d < 0 ? -d : d;
   fe_set(e.ymx, 1); fe_set(e.ypx, 1); fe_set(e.t2d, 0);
-  if (mag != 0) niels_load(e, table + TABLE_ENTRY_WORDS * (8 * row + mag - 1));
+  if (mag != 0) niels_load(e, table + TABLE_ENTRY_WORDS * (COMB_HALF * row + mag - 1));
   if (d < 0) { ge_niels_cneg(e, true); fe_carry(e.t2d); }
 }
 #else
-// device: `table` is the LDS image [32][COMB_IMG_ENTRIES][COMB_IMG_ENTRY_WORDS]; every lane of
-// the wave must be active (the point kernels give idle lanes a real item for that reason)
-ED_DEV void comb_select(ge_niels& e, const uint32_t* table, int row, uint32_t nibble) {
+// device: `table` is the LDS image [COMB_ROWS][COMB_IMG_ENTRIES][COMB_IMG_ENTRY_WORDS]; every lane
+// of the wave must be active (the point kernels give idle lanes a real item for that reason)
+ED_DEV void comb_select(ge_niels& e, const uint32_t* table, int row, uint32_t digit) {
   const word4* p = reinterpret_cast<const word4*>(
-      table + COMB_IMG_ENTRY_WORDS * (COMB_IMG_ENTRIES * row + (int)(threadIdx.x & 15u)));
+      table + COMB_IMG_ENTRY_WORDS * (COMB_IMG_ENTRIES * row + (int)(threadIdx.x & (COMB_IMG_ENTRIES - 1))));
   uint32_t w[32];
 #pragma unroll
   for (int q = 0; q < 8; q++) {
     const word4 v = p[q];
     w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
   }
-  const int src = (int)(nibble << 2);                           // byte address of the source lane's slot
+  const int src = (int)(digit << 2);                            // byte address of the source lane's slot
 #pragma unroll
   for (int j = 0; j < 30; j++) w[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)w[j]);
 #pragma unroll
@@ -590,26 +601,42 @@ ED_DEV void comb_select(ge_niels& e, const uint32_t* table, int row, uint32_t ni
 }
 #endif
 
-// out = x * B for a reduced scalar given as eight little-endian words (consumed); comb = the LDS
-// image on the device, the 256-entry table in the host build (see comb_select)
-ED_DEV void scale_base_lane(ge& out, uint32_t xw[8], const uint32_t* comb) {
-  words_add_pattern(xw, 0x88888888u);            // ed.c:407-409
+// out = x * B for a reduced scalar (x < 2^253) given as eight little-endian words; comb = the LDS
+// image on the device, the table in its global layout in the host build (see comb_select)
+ED_DEV void scale_base_lane(ge& out, const uint32_t xw[8], const uint32_t* comb) {
+  // y = x + sum_j COMB_HALF * 2^(w j): nine words (w = 5: 260 bits)
+  uint32_t y[9];
+  {
+    uint64_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      uint32_t pat = 0;                          // word k of the offset pattern
+#pragma unroll
+      for (int j = 0; j < COMB_DIGITS; j++) {
+        const int bit = COMB_W * j + COMB_W - 1;
+        if ((bit >> 5) == k) pat |= 1u << (bit & 31);
+      }
+      c += (uint64_t)(k < 8 ? xw[k] : 0u) + pat;
+      y[k] = (uint32_t)c;
+      c >>= 32;
+    }
+  }
   ge r0, r1;
   ge_neutral(r0); ge_neutral(r1);
 #pragma unroll 1
-  for (int i = 0; i < 32; i++) {
-    const uint32_t byte = xw[0] & 0xffu;
+  for (int i = 0; i < COMB_ROWS; i++) {
+    const uint32_t two = y[0] & ((1u << (2 * COMB_W)) - 1u);   // digits 2i and 2i+1
 #pragma unroll
-    for (int k = 0; k < 7; k++) xw[k] = (xw[k] >> 8) | (xw[k + 1] << 24);
-    xw[7] >>= 8;
+    for (int k = 0; k < 8; k++) y[k] = (y[k] >> (2 * COMB_W)) | (y[k + 1] << (32 - 2 * COMB_W));
+    y[8] >>= 2 * COMB_W;
     ge_niels e;
-    comb_select(e, comb, i, byte & 15u);
+    comb_select(e, comb, i, two & ((1u << COMB_W) - 1u));
     ge_add_niels(r0, r0, e, true);
-    comb_select(e, comb, i, byte >> 4);
+    comb_select(e, comb, i, two >> COMB_W);
     ge_add_niels(r1, r1, e, true);
   }
 #pragma unroll 1
-  for (int k = 0; k < 4; k++) ge_dbl(r1, r1, k == 3);
+  for (int k = 0; k < COMB_W; k++) ge_dbl(r1, r1, k == COMB_W - 1);
   ge_cached c;
   ge_to_cached(c, r1);
   ge_add_cached(out, r0, c, false);

@@ -36,7 +36,7 @@ struct Tables {
   Tables() : base16((size_t)TABLE_BASE16_ENTRIES * TABLE_ENTRY_WORDS + 32), comb(TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS) {
     for (int k = 0; k < TABLE_BASE16_ENTRIES; k++) table_entry_lane(b16() + (size_t)TABLE_ENTRY_WORDS * k, (uint32_t)k, 0);
     for (int c = 0; c < TABLE_COMB_ENTRIES; c++)
-      table_entry_lane(&comb[TABLE_ENTRY_WORDS * c], (uint32_t)(c & 7) + 1, 8u * (uint32_t)(c >> 3));
+      table_entry_lane(&comb[TABLE_ENTRY_WORDS * c], (uint32_t)(c % COMB_HALF) + 1, 2u * COMB_W * (uint32_t)(c / COMB_HALF));
   }
 };
 static Tables& tables() { static Tables t; return t; }

@@ -157,22 +157,30 @@ def test_exact_chain_for_off_curve_points(hostcheck, oracle, golden):
 
 
 def test_tables_match_the_reference_points(hostcheck, oracle, golden):
-    base16 = np.zeros((32769, 32), np.uint32); comb = np.zeros((256, 32), np.uint32)
+    """comb[i][k] = (k+1) * 1024^i * B (row 0 = the first row of the reference's lib/ed_lookup64.h)
+    and base16[k] = k * B, every comb entry and a sample of base16 against the oracle's k * B"""
+    base16 = np.zeros((32769, 32), np.uint32); comb = np.zeros((416, 32), np.uint32)
     hostcheck.hc_tables(base16.ctypes.data_as(ctypes.c_void_p), comb.ctypes.data_as(ctypes.c_void_p))
     pos = [0, 26, 51, 77, 102, 128, 153, 179, 204, 230]
     val = lambda limbs: sum(int(v) << s for v, s in zip(limbs, pos))  # noqa: E731
     inv2 = pow(2, P - 2, P)
+    ell = 2**252 + 27742317777372353535851937790883648493
+
+    def enc(entry):
+        ymx, ypx = val(entry[0:10]), val(entry[10:20])
+        y, x = (ypx + ymx) * inv2 % P, (ypx - ymx) * inv2 % P
+        return (y | (x & 1) << 255).to_bytes(32, "little")
+
     pts = golden("comb_points.bin")
-    for e in range(256):
-        ymx, ypx = val(comb[e][0:10]), val(comb[e][10:20])
-        y, x = (ypx + ymx) * inv2 % P, (ypx - ymx) * inv2 % P
-        assert (y | (x & 1) << 255).to_bytes(32, "little") == pts[32 * e:32 * e + 32], e
+    for k in range(8):
+        assert enc(comb[k]) == pts[32 * k:32 * k + 32], k
     out = ctypes.create_string_buffer(32)
+    for e in range(416):
+        oracle.lib.orc_ed_scale_base(out, int((e % 16 + 1) * 1024 ** (e // 16) % ell).to_bytes(32, "little"))
+        assert enc(comb[e]) == out.raw, e
     for k in list(range(1, 32769, 331)) + [32767, 32768]:
-        ymx, ypx = val(base16[k][0:10]), val(base16[k][10:20])
-        y, x = (ypx + ymx) * inv2 % P, (ypx - ymx) * inv2 % P
         oracle.lib.orc_ed_scale_base(out, int(k).to_bytes(32, "little"))
-        assert (y | (x & 1) << 255).to_bytes(32, "little") == out.raw, k
+        assert enc(base16[k]) == out.raw, k
     no_violations(hostcheck)
 
 

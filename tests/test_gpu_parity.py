@@ -89,9 +89,10 @@ def test_layer_kats_through_the_abi(engine, golden):
 
 
 def test_device_tables_equal_the_reference_table(engine, oracle, golden):
-    """the comb table generated on the device == the points of the reference's lib/ed_lookup64.h"""
+    """the tables generated on the device: comb[i][k] = (k+1) * 1024^i * B (row 0 = the first row of the
+    reference's lib/ed_lookup64.h, every entry against the oracle's k * B) and base16[k] = k * B"""
     import ctypes
-    base16 = np.zeros((32769, 32), np.uint32); comb = np.zeros((256, 32), np.uint32)
+    base16 = np.zeros((32769, 32), np.uint32); comb = np.zeros((416, 32), np.uint32)
     rc = engine.library().eddsa_amd_dump_tables(base16.ctypes.data_as(ctypes.c_void_p), comb.ctypes.data_as(ctypes.c_void_p))
     assert rc == 0
     pos = [0, 26, 51, 77, 102, 128, 153, 179, 204, 230]
@@ -108,9 +109,13 @@ def test_device_tables_equal_the_reference_table(engine, oracle, golden):
         return (y | (x & 1) << 255).to_bytes(32, "little")
 
     pts = golden("comb_points.bin")
-    for e in range(256):
-        assert enc(comb[e]) == pts[32 * e:32 * e + 32], e
-    for k in range(1, 9):                                  # base16[k] = k*B = comb row 0
+    ell = 2**252 + 27742317777372353535851937790883648493
+    out = ctypes.create_string_buffer(32)
+    for e in range(416):
+        oracle.lib.orc_ed_scale_base(out, int((e % 16 + 1) * 1024 ** (e // 16) % ell).to_bytes(32, "little"))
+        assert enc(comb[e]) == out.raw, e
+    for k in range(1, 9):                                  # base16[k] = k*B = comb row 0 = the reference's row 0
+        assert enc(comb[k - 1]) == pts[32 * (k - 1):32 * k]
         assert enc(base16[k]) == pts[32 * (k - 1):32 * k]
     assert val(base16[0][0:10]) == 1 and val(base16[0][10:20]) == 1 and val(base16[0][20:30]) == 0
     out = ctypes.create_string_buffer(32)                  # every 97th entry and the last against the oracle's k*B
