@@ -30,6 +30,7 @@ from .api import (  # noqa: F401
     sk_ed25519_to_x25519,
     set_offcurve_mode,
     set_profiling,
+    shutdown,
     sk_ed25519_to_x25519_batch,
     verify_phase_ms,
     x25519,

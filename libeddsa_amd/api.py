@@ -61,6 +61,11 @@ def init(device=None):
     _check(library().eddsa_amd_init(int(device)), "eddsa_amd_init")
 
 
+def shutdown():
+    """release every device resource of the engine; the next call initialises it again"""
+    library().eddsa_amd_shutdown()
+
+
 def verify_phase_ms():
     """(prepare, main, finish) kernel durations in ms of the last profiled verify pass, measured
     with HIP events on the launch stream (enable with set_profiling(True))."""

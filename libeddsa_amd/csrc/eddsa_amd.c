@@ -158,6 +158,8 @@ void eddsa_amd_shutdown(void)
         ws_release(&g_eng); fws_release(&g_eng);
         (void)hipFree(g_eng.base16); (void)hipFree(g_eng.comb); (void)hipFree(g_eng.comb_img); (void)hipEventDestroy(g_eng.ws_free);
         (void)hipStreamDestroy(g_eng.ws.side); (void)hipEventDestroy(g_eng.ws.ev_prepared); (void)hipEventDestroy(g_eng.ws.ev_exact);
+        for (int s = 0; s < MARK_SLOTS; s++)
+            for (int i = 0; i < 4; i++) if (g_eng.marks[s][i]) (void)hipEventDestroy(g_eng.marks[s][i]);
         memset(&g_eng, 0, sizeof(g_eng));
     }
     pthread_mutex_unlock(&g_lock);

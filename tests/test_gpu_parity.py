@@ -259,6 +259,20 @@ def test_unaligned_device_buffers(engine, oracle):
     assert engine.ed25519_verify_batch(dev(sig), dev(pk), dev(msg), msg_len=33).all()
 
 
+def test_shutdown_and_implicit_reinit(engine, golden):
+    """eddsa_amd_shutdown releases everything; the next call builds tables and workspaces again"""
+    t = np.frombuffer(golden("x25519_table.bin"), np.uint8).reshape(-1, 96)
+    want = t[:64, 64:]
+    assert np.array_equal(engine.x25519_batch(t[:64, 32:64].copy(), t[:64, :32].copy()), want)
+    engine.shutdown()
+    assert np.array_equal(engine.x25519_batch(t[:64, 32:64].copy(), t[:64, :32].copy()), want)
+    sk = np.arange(32, dtype=np.uint8).reshape(1, 32)
+    pk = engine.ed25519_genpub_batch(sk)
+    engine.shutdown()
+    sig = engine.ed25519_sign_batch(sk, pk, np.zeros((1, 5), np.uint8))
+    assert engine.ed25519_verify_batch(sig, pk, np.zeros((1, 5), np.uint8))[0] == 1
+
+
 def test_empty_batches(engine):
     z32, z64 = np.zeros((0, 32), np.uint8), np.zeros((0, 64), np.uint8)
     assert engine.x25519_batch(z32, z32).shape == (0, 32)
