@@ -241,7 +241,7 @@ def main():
             kernel, k_ms, k_mul32 = "k_verify_main", phases[1], MUL32_VERIFY_MAIN
         else:
             k_ms = sum(a.elapsed_time(b) for a, b in marks) / len(marks)      # HIP events, launch stream
-            kernel, k_mul32 = {"x25519": "k_x25519", "sign": "k_sign_point + k_sign_finish"}[op], mul32
+            kernel, k_mul32 = {"x25519": "k_x25519_ladder + k_x25519_finish", "sign": "k_sign_point + k_sign_finish"}[op], mul32
         achieved = n * k_mul32 / (k_ms * 1e-3) / 1e12
         roofline = {
             "bound": "valu", "kernel": kernel, "achieved": achieved, "peak": PEAK_TMUL32,

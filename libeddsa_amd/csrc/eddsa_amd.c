@@ -331,13 +331,18 @@ int ed25519_genpub_batch_dev(uint8_t *pubs, const uint8_t *secs, size_t n, void 
     return run_fixed(n, genpub_step, &c, stream);
 }
 
+struct io2_ctx { uint8_t *out; const uint8_t *a, *b; };
+
+static hipError_t x25519_step(size_t done, size_t m, const void *vctx, hipStream_t st)
+{
+    const struct io2_ctx *c = (const struct io2_ctx *)vctx;
+    return edk_x25519(c->out + 32 * done, c->a + 32 * done, c->b + 32 * done, m, &g_eng.fws, st);
+}
+
 int x25519_batch_dev(uint8_t *out, const uint8_t *scalars, const uint8_t *points, size_t n, void *stream)
 {
-    int rc = ensure_init();
-    if (rc) return rc;
-    TRY(edk_x25519(out, scalars, points, n, (hipStream_t)stream));
-out:
-    return rc;
+    struct io2_ctx c = { out, scalars, points };
+    return run_fixed(n, x25519_step, &c, stream);
 }
 
 static hipError_t xbase_step(size_t done, size_t m, const void *vctx, hipStream_t st)

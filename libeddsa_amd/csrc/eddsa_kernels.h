@@ -27,8 +27,7 @@ extern "C" {
 #endif
 
 hipError_t edk_init_tables(uint32_t* base16, uint32_t* comb, uint32_t* comb_img, hipStream_t stream);
-hipError_t edk_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* points, size_t n,
-                      hipStream_t stream);
+
 #define EDK_EXACT_PAD_BYTES ((size_t)1024 * 64 * (160 + 2 * ((261 + 3) / 4)) * 4)
 
 /* verify workspace for up to `capacity` items (a multiple of VERIFY_TILE), all in HBM */
@@ -66,6 +65,8 @@ typedef struct edk_fixed_ws {
   uint32_t* aux;      /* capacity * 16 words: sign's secret scalars a, r between its two kernels (zeroed after use) */
 } edk_fixed_ws;
 
+hipError_t edk_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* points, size_t n,
+                      const edk_fixed_ws* ws, hipStream_t stream);
 hipError_t edk_genpub(uint8_t* pubs, const uint8_t* secs, size_t n, const uint32_t* comb,
                       const edk_fixed_ws* ws, hipStream_t stream);
 hipError_t edk_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, const uint8_t* msgs,

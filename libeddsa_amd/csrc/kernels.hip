@@ -4,7 +4,7 @@
 // in lanes.h; this file maps items to lanes, stages the shared tables in LDS and moves the packed,
 // item-major byte arrays of the batch API (include/eddsa_amd.h) in and out.
 //
-//   k_x25519         x25519.c:129-150 do_x25519                      (config 3)
+//   k_x25519_*       x25519.c:129-150 do_x25519                      (config 3)
 //   k_verify_*       ed25519-sha512.c:148-181 ed25519_verify        (config 2, 4)
 //   k_sign_*         ed25519-sha512.c:84-123 sign                    (config 5)
 //   k_genpub_point + k_encode_finish          ed25519-sha512.c:53-67 genpub
@@ -76,15 +76,21 @@ ED_DEV void stage_table(uint32_t* lds, const uint32_t* src, int words) {
 
 // ---------------------------------------------------------------------------------------------
 
+// X25519 in two kernels, like the fixed-base operations: the ladder leaves (x2 : z2) in the point
+// workspace (X and Z slots), the finish kernel inverts z2 once per eight items per lane
+// (finish_batch8 below) -- the per-item inversion was 7 % of the work.
 __global__ void __launch_bounds__(BLOCK, 4)
-k_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* points, size_t n) {
+k_x25519_ladder(uint32_t* accout, const uint8_t* scalars, const uint8_t* points, size_t n) {
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= n) return;
-  uint32_t s[8], pt[8], r[8];
-  load32(s, scalars, i, 32);
-  load32(pt, points, i, 32);
-  x25519_lane(r, s, pt);
-  store32(out, i, 32, r);
+  const size_t item = i < n ? i : n - 1;
+  uint32_t s[8], pt[8];
+  load32(s, scalars, item, 32);
+  load32(pt, points, item, 32);
+  fe x2, z2;
+  x25519_ladder_lane(x2, z2, s, pt);
+  uint32_t* o = accout + (size_t)blockIdx.x * (30 * BLOCK) + threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < 10; j++) { o[j * BLOCK] = x2.v[j]; o[(20 + j) * BLOCK] = z2.v[j]; }
 }
 
 __global__ void __launch_bounds__(64) k_init_tables(uint32_t* base16, uint32_t* comb) {
@@ -352,6 +358,41 @@ k_verify_finish(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, uint32_t* a
   finish_batch8(verify_finish_policy{ok, sigs, sig_stride, acc, flags, n, exact_offcurve}, acc);
 }
 
+// x25519.c:144-149: x2 / z2, and 0 when z2 = 0 (fld_inv(0) = 0): such an item contributes 1 to the
+// shared product and its "inverse" is forced to 0
+struct x25519_finish_policy {
+  uint8_t* out; uint32_t* acc; size_t n;
+  ED_DEV void den(int k, fe& z) const {
+    const finish_pos p = finish_at(k, acc);
+    fe_set(z, 1);
+    bool good = false;
+    if (p.i < n) {
+      acc_load(z, p.acc, 2);
+      good = !fe_iszero(z);
+      if (!good) {                               // remember it: X := 0 makes the product 0 whatever the "inverse"
+        uint32_t* o = acc + p.tile * (30 * BLOCK) + threadIdx.x;
+#pragma unroll
+        for (int j = 0; j < 10; j++) o[j * BLOCK] = 0;
+      }
+    }
+    den_commit(z, good, acc, k);
+  }
+  ED_DEV void item(int k) const {
+    const finish_pos p = finish_at(k, acc);
+    if (p.i >= n) return;
+    fe x, zinv;
+    acc_load(x, p.acc, 0); acc_load(zinv, p.acc, 2);
+    uint32_t w[8];
+    x25519_finish_lane(w, x, zinv);
+    store32(out, p.i, 32, w);
+  }
+};
+
+__global__ void __launch_bounds__(BLOCK, 2)
+k_x25519_finish(uint8_t* out, uint32_t* acc, size_t n) {
+  finish_batch8(x25519_finish_policy{out, acc, n}, acc);
+}
+
 // ---------------------------------------------------------------------------------------------
 // fixed-base kernels: the image of the comb (26 rows x 32 signed entries, 117 KiB of the CU's
 // 160 KiB LDS; one 512-lane block per CU, two waves per SIMD) is staged by every block of a
@@ -546,10 +587,11 @@ hipError_t edk_init_tables(uint32_t* base16, uint32_t* comb, uint32_t* comb_img,
 }
 
 hipError_t edk_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* points, size_t n,
-                      hipStream_t stream) {
+                      const edk_fixed_ws* ws, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  const size_t blocks = (n + BLOCK - 1) / BLOCK;
-  hipLaunchKernelGGL(k_x25519, dim3((unsigned)blocks), dim3(BLOCK), 0, stream, out, scalars, points, n);
+  const unsigned blocks = (unsigned)((n + BLOCK - 1) / BLOCK);
+  hipLaunchKernelGGL(k_x25519_ladder, dim3(blocks), dim3(BLOCK), 0, stream, ws->acc, scalars, points, n);
+  hipLaunchKernelGGL(k_x25519_finish, dim3((blocks + FINISH_K - 1) / FINISH_K), dim3(BLOCK), 0, stream, out, ws->acc, n);
   return hipGetLastError();
 }
 

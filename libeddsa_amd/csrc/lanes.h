@@ -54,8 +54,9 @@ ED_DEV void clamp(uint32_t s[8]) {
 // X25519: x25519.c:60-150 (montgomery, mg_scale, do_x25519)
 // ---------------------------------------------------------------------------------------------
 
-ED_DEV void x25519_lane(uint32_t out[8], uint32_t s[8], const uint32_t pt[8]) {
-  fe x1, x2, z2, x3, z3;
+// the ladder of x25519.c:104-123 (mg_scale): (x2 : z2) = s * (pt : 1), s clamped here, both tight
+ED_DEV void x25519_ladder_lane(fe& x2, fe& z2, uint32_t s[8], const uint32_t pt[8]) {
+  fe x1, x3, z3;
   clamp(s);
   fe_frombytes(x1, pt);                          // bit 255 folded in as +19, not masked (fld.c:153)
   fe_set(x2, 1); fe_set(z2, 0); x3 = x1; fe_set(z3, 1);
@@ -93,9 +94,22 @@ ED_DEV void x25519_lane(uint32_t out[8], uint32_t s[8], const uint32_t pt[8]) {
   }
   fe_cswap(x2, x3, swap != 0);
   fe_cswap(z2, z3, swap != 0);
+}
+
+// x25519.c:144-149: out = x2 / z2 given zinv = 1 / z2 (0 when z2 = 0, as fld_inv)
+ED_DEV void x25519_finish_lane(uint32_t out[8], const fe& x2, const fe& zinv) {
+  fe u;
+  fe_mul(u, x2, zinv);
+  fe_tobytes(out, u);
+}
+
+// the whole of do_x25519 for one item (host check and single-lane use; the kernels split it so that
+// eight items per lane share the inversion)
+ED_DEV void x25519_lane(uint32_t out[8], uint32_t s[8], const uint32_t pt[8]) {
+  fe x2, z2;
+  x25519_ladder_lane(x2, z2, s, pt);
   fe_inv(z2, z2);                                // z = 0 -> 0 (x25519.c:145)
-  fe_mul(x2, x2, z2);
-  fe_tobytes(out, x2);
+  x25519_finish_lane(out, x2, z2);
 }
 
 // ---------------------------------------------------------------------------------------------
