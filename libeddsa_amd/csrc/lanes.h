@@ -65,7 +65,7 @@ ED_DEV void x25519_ladder_lane(fe& x2, fe& z2, uint32_t s[8], const uint32_t pt[
   shl256<1>(s);
   uint32_t swap = 0;
 #pragma unroll 1
-  for (int t = 254; t >= 0; t--) {
+  for (int t = 254; t >= 3; t--) {
     const uint32_t bit = s[7] >> 31;
     shl256<1>(s);
     swap ^= bit;
@@ -94,6 +94,21 @@ ED_DEV void x25519_ladder_lane(fe& x2, fe& z2, uint32_t s[8], const uint32_t pt[
   }
   fe_cswap(x2, x3, swap != 0);
   fe_cswap(z2, z3, swap != 0);
+  // bits 2, 1, 0 of the clamped scalar are 0: their steps never swap, and (x2 : z2) -- all that is
+  // used afterwards -- only goes through the doubling half of x25519.c:60-94 (same field values)
+#pragma unroll 1
+  for (int t = 2; t >= 0; t--) {
+    fe a, aa, b, bb, e, t1;
+    fe_add(a, x2, z2);                           // 2u
+    fe_sq(aa, a);
+    fe_sub(b, x2, z2);                           // 3u
+    fe_sq(bb, b);
+    fe_sub(e, aa, bb);                           // 3u
+    fe_mul(x2, aa, bb);
+    fe_mul121665(t1, e);
+    fe_add(t1, t1, aa);                          // 2u
+    fe_mul(z2, e, t1);
+  }
 }
 
 // x25519.c:144-149: out = x2 / z2 given zinv = 1 / z2 (0 when z2 = 0, as fld_inv)
