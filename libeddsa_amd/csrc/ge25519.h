@@ -20,6 +20,7 @@ struct ge_niels { fe ymx, ypx, t2d; };
 
 // fld.c:23-41 con_d, con_2d, con_j and ed.c:46-52 (base point), radix 2^25.5
 ED_DEV fe fe_const_d() { return fe{{56195235, 13857412, 51736253, 6949390, 114729, 24766616, 60832955, 30306712, 48412415, 21499315}}; }
+ED_DEV fe fe_const_inv_d() { return fe{{30013507, 3972531, 42321084, 12719050, 2979674, 28954470, 51415654, 29910370, 18959708, 16925179}}; }   // 1 / d
 ED_DEV fe fe_const_2d() { return fe{{45281625, 27714825, 36363642, 13898781, 229458, 15978800, 54557047, 27058993, 29715967, 9444199}}; }
 ED_DEV fe fe_const_sqrtm1() { return fe{{34513072, 25610706, 9377949, 3500415, 12389472, 33281959, 41962654, 31548777, 326685, 11406482}}; }
 ED_DEV fe fe_const_bx() { return fe{{52811034, 25909283, 16144682, 17082669, 27570973, 30858332, 40966398, 8378388, 20764389, 8758491}}; }

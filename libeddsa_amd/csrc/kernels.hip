@@ -175,9 +175,10 @@ k_verify_exact(uint8_t* ok, edk_verify_src src, const uint32_t* offlist, const u
   }
 }
 
-// The first EXACT_MAX_BLOCKS * 64 entries of the work list take a faster route.  The register-hungry
-// but short first half (hash, scalars, import, digits, addends: about 0.2 ms whatever the count) is
-// a kernel of its own on the caller's stream right after k_verify_prepare; the long second half, the
+// The first EXACT_MAX_BLOCKS * 64 entries of the work list take a faster route.  The short first
+// half (joint sparse form of the two scalars and the addends Q, B, Q+B, Q-B, all from what
+// k_verify_prepare left in the workspace: lanes.h verify_exact_setup_reuse_lane; about 0.07 ms
+// whatever the count) is a kernel of its own on the caller's stream right after k_verify_prepare; the long second half, the
 // chain, is the ONLY kernel on the side stream, so that it is dispatched together with
 // k_verify_main's first workgroups (a kernel that reaches the side queue later only runs once
 // k_verify_main has drained).  Its blocks are four waves -- one per SIMD, the footprint of exactly
@@ -189,18 +190,16 @@ k_verify_exact(uint8_t* ok, edk_verify_src src, const uint32_t* offlist, const u
 // round: +0.6 ms for 1024 listed keys as for 8192, +1.0 ms for 65536 (it was +1.6 ms with
 // single-wave chain blocks, which displaced a main block each).
 __global__ void __launch_bounds__(EXACT_BLOCK, 2)
-k_verify_exact_setup(edk_verify_src src, const uint32_t* offlist, const uint32_t* offcount, const uint32_t* base16,
-                     uint32_t* pad) {
+k_verify_exact_setup(const uint32_t* digits, const uint32_t* table, const uint32_t* offlist, const uint32_t* offcount,
+                     const uint32_t* base16, uint32_t* pad) {
   const size_t g = (size_t)blockIdx.x * EXACT_BLOCK + threadIdx.x;
   if (g >= *offcount) return;
-  const size_t i = offlist[g];
-  uint32_t rw[8], sw[8], aw[8];
-  const uint8_t* m; size_t mlen;
-  verify_item(rw, sw, aw, m, mlen, src, i);
+  const size_t i = offlist[g];                   // = the item's slot in this pass's workspace
   uint32_t* base = pad + (size_t)blockIdx.x * (EXACT_PAD_WORDS * EXACT_BLOCK);
   int8_t* ux = reinterpret_cast<int8_t*>(base + 160 * EXACT_BLOCK) + threadIdx.x;
-  verify_exact_setup_lane(rw, sw, aw, m, mlen, base16 + TABLE_ENTRY_WORDS, ux, ux + REF_JSF_LEN * EXACT_BLOCK,
-                          base + threadIdx.x, EXACT_BLOCK);
+  verify_exact_setup_reuse_lane(digits + 16 * i, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
+                                base16 + TABLE_ENTRY_WORDS, ux, ux + REF_JSF_LEN * EXACT_BLOCK,
+                                base + threadIdx.x, EXACT_BLOCK);
 }
 
 constexpr int CHAIN_WAVES = 4;                   // waves per chain block: one per SIMD, the footprint of ONE k_verify_main block
@@ -609,8 +608,8 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   const unsigned eb = (unsigned)((n + EXACT_BLOCK - 1) / EXACT_BLOCK);
   const unsigned eb1 = eb < (unsigned)EXACT_MAX_BLOCKS ? eb : (unsigned)EXACT_MAX_BLOCKS;
   if (ws->exact_offcurve) {
-    hipLaunchKernelGGL(k_verify_exact_setup, dim3(eb1), dim3(EXACT_BLOCK), 0, stream, src, ws->offlist,
-                       ws->offcount, base16, ws->exact_pad);
+    hipLaunchKernelGGL(k_verify_exact_setup, dim3(eb1), dim3(EXACT_BLOCK), 0, stream, ws->digits, ws->table,
+                       ws->offlist, ws->offcount, base16, ws->exact_pad);
     (void)hipEventRecord(ws->ev_prepared, stream);
     (void)hipStreamWaitEvent(ws->side, ws->ev_prepared, 0);
     hipLaunchKernelGGL(k_verify_exact_chain, dim3((eb1 + CHAIN_WAVES - 1) / CHAIN_WAVES), dim3(EXACT_BLOCK * CHAIN_WAVES),

@@ -544,6 +544,32 @@ ED_DEV void verify_exact_setup_lane(const uint32_t rw[8], const uint32_t sraw[8]
   ref_dual_scale_setup(sw, tw, a, pcB, ux, uy, pts, stride);
 }
 
+// The same first half from what k_verify_prepare already left in the workspace -- the digit words
+// (t + 0x88..8, S + 0x8000..) and entry 1 of the item's table, -A in cached form (y-x, y+x, 2d*t, 2) --
+// instead of hashing, reducing and decompressing again.  The point is rebuilt with all four
+// coordinates doubled: (2x, 2y, 2, 2t) = (ypx - ymx, ypx + ymx, z2, t2d / d); every formula of the
+// chain is homogeneous in each operand (of degree 2 in the accumulator and in an extended addend),
+// so a common factor of an addend only rescales (X : Y : Z : T) and the affine result, all that is
+// encoded, is the reference's.
+ED_DEV void verify_exact_setup_reuse_lane(const uint32_t* digits, const uint32_t* tab, const uint32_t* base1,
+                                          int8_t* ux, int8_t* uy, uint32_t* pts, int stride) {
+  uint32_t tw[8], sw[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { tw[k] = digits[k]; sw[k] = digits[8 + k]; }
+  words_sub_pattern(tw, 0x88888888u);
+  words_sub_pattern(sw, 0x80008000u);
+  ge_cached c1;
+  cached_load(c1, tab, 1);
+  ge a;
+  fe_sub(a.X, c1.ypx, c1.ymx); fe_carry(a.X);
+  fe_add(a.Y, c1.ypx, c1.ymx); fe_carry(a.Y);
+  a.Z = c1.z2;
+  fe_mul(a.T, c1.t2d, fe_const_inv_d());
+  ge_niels pcB;
+  niels_load(pcB, base1);
+  ref_dual_scale_setup(sw, tw, a, pcB, ux, uy, pts, stride);
+}
+
 // second half (ed25519-sha512.c:176-180): the chain, ed_export, comparison with R
 ED_DEV bool verify_exact_chain_lane(const uint32_t rw[8], const int8_t* ux, const int8_t* uy,
                                     const uint32_t* pts, int stride) {

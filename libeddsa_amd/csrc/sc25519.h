@@ -155,4 +155,15 @@ ED_DEV void words_add_pattern(uint32_t w[8], uint32_t pat32) {
   }
 }
 
+// the inverse of words_add_pattern: w - pat * (1, 1, ..., 1), w >= the pattern value
+ED_DEV void words_sub_pattern(uint32_t w[8], uint32_t pat32) {
+  int64_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    c += (int64_t)w[k] - (int64_t)pat32;
+    w[k] = (uint32_t)c;
+    c >>= 32;                                    // arithmetic: 0 or -1
+  }
+}
+
 }  // namespace ed
