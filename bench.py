@@ -84,6 +84,18 @@ def pmc_traffic(kernel):
         return None
 
 
+def pmc_valu_busy(kernel):
+    """VALU-busy fraction of `kernel` from the same committed PMC passes: SQ_INSTS_VALU wave-instructions
+    x 4 clocks (one VALU instruction per SIMD per 4 clocks, profiles/r01_valu_rates.txt) / (1024 SIMDs x
+    GRBM_GUI_ACTIVE / 8 XCDs).  None when the profile lacks the counters."""
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+        k = prof["ed::" + kernel.split("+")[0].strip()]
+        return 4.0 * k["SQ_INSTS_VALU"] / (1024.0 * k["GRBM_GUI_ACTIVE"] / 8.0)
+    except (OSError, KeyError, ValueError, TypeError, ZeroDivisionError):
+        return None
+
+
 def run_step(op, w):
     if op == "verify":
         return ed.ed25519_verify_batch(w["sigs"], w["pubs"], w["msgs"], msg_len=32)
@@ -246,6 +258,7 @@ def main():
         roofline = {
             "bound": "valu", "kernel": kernel, "achieved": achieved, "peak": PEAK_TMUL32,
             "unit": "Tmul32/s", "frac": achieved / PEAK_TMUL32, "traffic": pmc_traffic(kernel),
+            "valu_busy": pmc_valu_busy(kernel),
             "kernel_ms": k_ms, "canonical_mul32_per_item": k_mul32,
             "note": "integer-VALU multiply-issue roofline (SURVEY 8d): canonical 32x32->64 products of the "
                     "reference's radix-2^25.5 schoolbook per item / v_mad_u64_u32 issue peak; the path is not "

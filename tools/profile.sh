@@ -20,4 +20,6 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_sign -- $CMD --
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_sign -- $CMD --op sign > $OUT/bench_write_s.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT/bench_sq.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES --output-format csv -d $OUT/pmc_misc -- $CMD > $OUT/bench_misc.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq_x25519 -- $CMD --op x25519 > $OUT/bench_sq_x.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq_sign -- $CMD --op sign > $OUT/bench_sq_s.log 2>&1
 python3 $REPO/tools/summarize_profile.py $TAG

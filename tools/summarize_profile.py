@@ -33,7 +33,7 @@ if rows:
 
 out = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc", "pmc_fetch_x25519", "pmc_write_x25519",
-            "pmc_fetch_sign", "pmc_write_sign"):
+            "pmc_fetch_sign", "pmc_write_sign", "pmc_sq_x25519", "pmc_sq_sign"):
     for f in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         meta = {}
