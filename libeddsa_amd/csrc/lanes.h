@@ -63,25 +63,31 @@ ED_DEV void x25519_ladder_lane(fe& x2, fe& z2, uint32_t s[8], const uint32_t pt[
   // bit 255 of the clamped scalar is 0 and the step for it maps (1:0),(x1:1) to itself
   // projectively, so the ladder starts at bit 254.
   shl256<1>(s);
+  // x25519.c:104-123 swaps (x2,z2) <-> (x3,z3) before and after every step.  The differential
+  // addition is symmetric in the two points, so only the doubling has to know which slot holds
+  // the point to double: with `swap` = (slots currently exchanged) ^ (this bit), the doubling's
+  // inputs x+z, x-z are SELECTED (20 v_cndmask) instead of four elements being swapped (40);
+  // afterwards slot 2 holds the double and slot 3 the sum, i.e. the slots are exchanged iff the
+  // bit was 1.  Same field values as the reference's swap-step-swap.
   uint32_t swap = 0;
 #pragma unroll 1
   for (int t = 254; t >= 3; t--) {
     const uint32_t bit = s[7] >> 31;
     shl256<1>(s);
     swap ^= bit;
-    fe_cswap(x2, x3, swap != 0);
-    fe_cswap(z2, z3, swap != 0);
-    swap = bit;
     fe a, aa, b, bb, e, c, d, da, cb, t1;
     fe_add(a, x2, z2);                           // 2u
-    fe_sq(aa, a);
     fe_sub(b, x2, z2);                           // 3u
-    fe_sq(bb, b);
-    fe_sub(e, aa, bb);                           // 3u
     fe_add(c, x3, z3);                           // 2u
     fe_sub(d, x3, z3);                           // 3u
     fe_mul(da, d, a);
     fe_mul(cb, c, b);
+    fe_cmov(a, c, swap != 0);                    // the point to double: slot 3 when exchanged
+    fe_cmov(b, d, swap != 0);
+    swap = bit;
+    fe_sq(aa, a);
+    fe_sq(bb, b);
+    fe_sub(e, aa, bb);                           // 3u
     fe_add(t1, da, cb);                          // 2u
     fe_sq(x3, t1);
     fe_sub(t1, da, cb);                          // 3u
