@@ -388,6 +388,9 @@ out:
  * ---------------------------------------------------------------------------------------- */
 
 #define PIPE_CHUNK ((size_t)1 << 18)   /* 1024 blocks of 256 lanes: one full residency of the chip */
+/* verify: two residencies per chunk, so that the exact path's chain for off-curve keys (4 ms beside
+ * the main kernel, tools/verify_sizes.py) stays hidden behind k_verify_main as it is in one big pass */
+#define PIPE_CHUNK_VERIFY ((size_t)1 << 19)
 #define PIPE_MAX_IN 3
 
 struct hjob {
@@ -397,6 +400,7 @@ struct hjob {
     int (*run)(const struct hjob *j, uint8_t *d_out, uint8_t *const d_in[PIPE_MAX_IN], const uint8_t *d_msgs,
                const uint64_t *d_off, size_t msg_len, size_t m, void *stream);
     size_t rec_sig, rec_pub, rec_msg;          /* records: offsets inside in[0]'s items (in_w[0] = stride) */
+    size_t chunk;                              /* items per pipeline stage (0: PIPE_CHUNK) */
 };
 
 struct pipe {
@@ -462,7 +466,8 @@ static int pipe_run(const struct hjob *j, size_t n)
     if (rc) goto out;
     {
         const int ragged = j->has_msgs && j->msg_off != NULL;
-        const size_t chunk = ragged ? n : (n < PIPE_CHUNK ? n : PIPE_CHUNK);
+        const size_t stage = j->chunk ? j->chunk : PIPE_CHUNK;
+        const size_t chunk = ragged ? n : (n < stage ? n : stage);
         const size_t nchunks = (n + chunk - 1) / chunk;
         if ((rc = pipe_grow(&g_pipe.d_out, &g_pipe.out_cap, n * j->out_w))) goto out;
         if (ragged && (rc = pipe_grow(&g_pipe.d_off, &g_pipe.off_cap, (n + 1) * sizeof(uint64_t)))) goto out;
@@ -552,7 +557,7 @@ RUN_1IN(run_sk_to_x, sk_ed25519_to_x25519_batch_dev)
 int ed25519_verify_batch(uint8_t *ok, const uint8_t *sigs, const uint8_t *pubs, const uint8_t *msgs,
                          const uint64_t *msg_off, size_t msg_len, size_t n)
 {
-    struct hjob j = { 2, { sigs, pubs, NULL }, { 64, 32, 0 }, 1, msgs, msg_off, msg_len, ok, 1, run_verify, 0, 0, 0 };
+    struct hjob j = { 2, { sigs, pubs, NULL }, { 64, 32, 0 }, 1, msgs, msg_off, msg_len, ok, 1, run_verify, 0, 0, 0, PIPE_CHUNK_VERIFY };
     return pipe_run(&j, n);
 }
 
@@ -561,26 +566,26 @@ int ed25519_verify_records(uint8_t *ok, const uint8_t *records, size_t stride, s
 {
     if (!records_ok(stride, sig_off, pub_off, msg_off, msg_len)) return -(int)hipErrorInvalidValue;
     struct hjob j = { 1, { records, NULL, NULL }, { stride, 0, 0 }, 0, NULL, NULL, msg_len, ok, 1, run_verify_records,
-                      sig_off, pub_off, msg_off };
+                      sig_off, pub_off, msg_off, PIPE_CHUNK_VERIFY };
     return pipe_run(&j, n);
 }
 
 int ed25519_sign_batch(uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs, const uint8_t *msgs,
                        const uint64_t *msg_off, size_t msg_len, size_t n)
 {
-    struct hjob j = { 2, { secs, pubs, NULL }, { 32, 32, 0 }, 1, msgs, msg_off, msg_len, sigs, 64, run_sign, 0, 0, 0 };
+    struct hjob j = { 2, { secs, pubs, NULL }, { 32, 32, 0 }, 1, msgs, msg_off, msg_len, sigs, 64, run_sign, 0, 0, 0, 0 };
     return pipe_run(&j, n);
 }
 
 int x25519_batch(uint8_t *out, const uint8_t *scalars, const uint8_t *points, size_t n)
 {
-    struct hjob j = { 2, { scalars, points, NULL }, { 32, 32, 0 }, 0, NULL, NULL, 0, out, 32, run_x25519, 0, 0, 0 };
+    struct hjob j = { 2, { scalars, points, NULL }, { 32, 32, 0 }, 0, NULL, NULL, 0, out, 32, run_x25519, 0, 0, 0, 0 };
     return pipe_run(&j, n);
 }
 
 static int run_1in(int (*run)(RUN_ARGS), uint8_t *out, const uint8_t *in, size_t n)
 {
-    struct hjob j = { 1, { in, NULL, NULL }, { 32, 0, 0 }, 0, NULL, NULL, 0, out, 32, run, 0, 0, 0 };
+    struct hjob j = { 1, { in, NULL, NULL }, { 32, 0, 0 }, 0, NULL, NULL, 0, out, 32, run, 0, 0, 0, 0 };
     return pipe_run(&j, n);
 }
 

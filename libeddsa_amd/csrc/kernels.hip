@@ -14,6 +14,7 @@
 //   k_init_tables    generates what the reference ships as lib/ed_lookup64.h
 #include "eddsa_kernels.h"
 #include "lanes.h"
+#include "quad_exact.h"
 
 namespace ed {
 
@@ -206,6 +207,7 @@ constexpr int CHAIN_WAVES = 4;                   // waves per chain block: one p
 __global__ void __launch_bounds__(EXACT_BLOCK * CHAIN_WAVES, 2)
 k_verify_exact_chain(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const uint32_t* offlist,
                      const uint32_t* offcount, const uint32_t* pad) {
+  __builtin_amdgcn_s_setprio(3);                 // few, long, latency-bound waves: let them issue first
   const size_t wave = (size_t)blockIdx.x * CHAIN_WAVES + (threadIdx.x >> 6);
   const unsigned lane = threadIdx.x & 63u;
   const size_t g = wave * EXACT_BLOCK + lane;
@@ -216,6 +218,37 @@ k_verify_exact_chain(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const 
   const uint32_t* base = pad + wave * (EXACT_PAD_WORDS * EXACT_BLOCK);
   const int8_t* ux = reinterpret_cast<const int8_t*>(base + 160 * EXACT_BLOCK) + lane;
   ok[i] = (uint8_t)verify_exact_chain_lane(rw, ux, ux + REF_JSF_LEN * EXACT_BLOCK, base + lane, EXACT_BLOCK);
+}
+
+// Passes of up to QUAD_ROUTE_MAX_N items wait for the chain (k_verify_main is at most two rounds
+// long there), so they take the low-latency form: four lanes per item (quad_exact.h), for the first
+// QUAD_MAX_ITEMS entries of the work list.
+constexpr size_t QUAD_ROUTE_MAX_N = (size_t)1 << 19;
+constexpr int QUAD_MAX_ITEMS = 32768;
+constexpr int QUAD_BLOCK = 256;
+static_assert((size_t)QUAD_MAX_ITEMS * QUAD_ITEM_WORDS * 4 <= EDK_EXACT_PAD_BYTES, "scratchpad too small");
+
+__global__ void __launch_bounds__(EXACT_BLOCK, 2)
+k_verify_exact_setup_quad(const uint32_t* digits, const uint32_t* table, const uint32_t* offlist,
+                          const uint32_t* offcount, const uint32_t* base16, uint32_t* pad) {
+  const size_t g = (size_t)blockIdx.x * EXACT_BLOCK + threadIdx.x;
+  if (g >= *offcount || g >= (size_t)QUAD_MAX_ITEMS) return;
+  const size_t i = offlist[g];
+  verify_exact_setup_quad_lane(digits + 16 * i, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
+                               base16 + TABLE_ENTRY_WORDS, pad + g * QUAD_ITEM_WORDS);
+}
+
+__global__ void __launch_bounds__(QUAD_BLOCK, 2)
+k_verify_exact_chain_quad(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const uint32_t* offlist,
+                          const uint32_t* offcount, const uint32_t* pad) {
+  __builtin_amdgcn_s_setprio(3);
+  const size_t g = ((size_t)blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;     // quads are all-or-nothing
+  if (g >= *offcount || g >= (size_t)QUAD_MAX_ITEMS) return;
+  const size_t i = offlist[g];
+  uint32_t rw[8];
+  load32(rw, sigs, i, sig_stride);
+  const bool same = verify_exact_chain_quad(rw, pad + g * QUAD_ITEM_WORDS, (int)(threadIdx.x & 3u));
+  if ((threadIdx.x & 3u) == 1u) ok[i] = (uint8_t)same;
 }
 
 __global__ void __launch_bounds__(BLOCK, 4)
@@ -607,7 +640,20 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   // the exact path depends only on prepare: run it beside the main kernel on the side stream
   const unsigned eb = (unsigned)((n + EXACT_BLOCK - 1) / EXACT_BLOCK);
   const unsigned eb1 = eb < (unsigned)EXACT_MAX_BLOCKS ? eb : (unsigned)EXACT_MAX_BLOCKS;
-  if (ws->exact_offcurve) {
+  const bool quad = n <= QUAD_ROUTE_MAX_N;
+  const size_t fast_items = quad ? (size_t)QUAD_MAX_ITEMS : (size_t)EXACT_MAX_BLOCKS * EXACT_BLOCK;
+  if (ws->exact_offcurve && quad) {
+    const size_t qi = n < (size_t)QUAD_MAX_ITEMS ? n : (size_t)QUAD_MAX_ITEMS;
+    hipLaunchKernelGGL(k_verify_exact_setup_quad, dim3((unsigned)((qi + EXACT_BLOCK - 1) / EXACT_BLOCK)),
+                       dim3(EXACT_BLOCK), 0, stream, ws->digits, ws->table, ws->offlist, ws->offcount, base16,
+                       ws->exact_pad);
+    (void)hipEventRecord(ws->ev_prepared, stream);
+    (void)hipStreamWaitEvent(ws->side, ws->ev_prepared, 0);
+    hipLaunchKernelGGL(k_verify_exact_chain_quad, dim3((unsigned)((4 * qi + QUAD_BLOCK - 1) / QUAD_BLOCK)),
+                       dim3(QUAD_BLOCK), 0, ws->side, ok, src.sigs, src.sig_stride, ws->offlist, ws->offcount,
+                       ws->exact_pad);
+    (void)hipEventRecord(ws->ev_exact, ws->side);
+  } else if (ws->exact_offcurve) {
     hipLaunchKernelGGL(k_verify_exact_setup, dim3(eb1), dim3(EXACT_BLOCK), 0, stream, ws->digits, ws->table,
                        ws->offlist, ws->offcount, base16, ws->exact_pad);
     (void)hipEventRecord(ws->ev_prepared, stream);
@@ -623,9 +669,9 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   if (marks) (void)hipEventRecord(marks[3], stream);
   if (ws->exact_offcurve) {
     (void)hipStreamWaitEvent(stream, ws->ev_exact, 0);   // complete when both paths are
-    if (eb > eb1)   // more than 65536 off-curve keys in the pass: the rest, strided, one (spilling) kernel
-      hipLaunchKernelGGL(k_verify_exact, dim3(EXACT_MAX_BLOCKS), dim3(EXACT_BLOCK), 0, stream, ok, src, ws->offlist, ws->offcount, base16, ws->exact_pad,
-                         (size_t)EXACT_MAX_BLOCKS * EXACT_BLOCK);
+    if (n > fast_items)   // possibly more listed keys than the fast route takes: the rest, strided, one kernel
+      hipLaunchKernelGGL(k_verify_exact, dim3(EXACT_MAX_BLOCKS), dim3(EXACT_BLOCK), 0, stream, ok, src, ws->offlist,
+                         ws->offcount, base16, ws->exact_pad, fast_items);
   }
   return hipGetLastError();
 }

@@ -1,0 +1,210 @@
+// quad_exact.h - the exact (reference-order) verify chain with FOUR lanes per item.
+//
+// lanes.h: ref_dual_scale_chain replays the reference's JSF/Shamir chain (ed.c:455-507) for public
+// keys that are not curve points with one lane per item: 261 steps of "uniform addition, then
+// doubling", 18 dependent field multiplications per step -- 1.3 ms on an idle chip however few the
+// items are, 4 ms beside k_verify_main.  That latency is what a pass of up to 2^19 items waits
+// for.  Here the four coordinates of the accumulator live in the four lanes of a quad (lane & 3 =
+// 0: X, 1: Y, 2: T, 3: Z) and the four multiplications of each stage of the addition law run side
+// by side:
+//
+//   ed_add (ed.c:175-203)                            lane 0        lane 1        lane 2        lane 3
+//   stage A   one fe_mul                             a=(Y-X)(y-x)  b=(Y+X)(y+x)  c=T*(2d*t)    d=Z*(2z)
+//   stage B   e=b-a f=d-c g=d+c h=b+a, one fe_mul    X=f*e         Y=h*g         T=h*e         Z=f*g
+//   ed_double (ed.c:211-237): stage A is a squaring of (Y-X, Y+X, T, Z), followed by one fe_mul
+//   with the lane's constant (1, 1, 2d, 2); stage B is the same.
+//
+// The addend's factors (y-x, y+x, 2d*t, -2d*t, 2z) are loop invariants: the set-up kernel stores
+// them per item and a lane loads the one its role and the digit's sign select (negating the addend
+// swaps y-x with y+x and negates 2d*t: ed_sub, ed.c:245-273).  Every value is a field element and
+// multiplication in GF(p) is associative and commutative, so T*(2d*t) is the reference's (T*t)*2d
+// and Z*(2z) its 2*(Z*z): the accumulator holds the reference's coordinates mod p (up to the common
+// factor discussed in lanes.h: verify_exact_setup_reuse_lane) after every step; the arguments of
+// lanes.h: ref_dual_scale_chain for the uniform control flow apply unchanged.
+// Lanes exchange values with DPP quad permutations (v_mov_b32_dpp, no LDS).
+//
+// A step is about 1200 instructions instead of 2800 (the exchanges and selects cost 45 % on top of
+// the five multiplications), the chain 0.7 ms on an idle chip.  Device only: this file is not part
+// of the -DED_HOST_CHECK build; it is covered on the GPU by the parity tests (golden edge cases,
+// random off-curve keys against the oracle at several batch sizes, and self-check mode 2, which
+// sends genuine signatures through it).
+#pragma once
+#include "lanes.h"
+
+namespace ed {
+
+#define QUAD_VALUE_WORDS 12                            /* 10 limbs + 2 padding words: three 16-byte loads */
+#define QUAD_ADDEND_WORDS (5 * QUAD_VALUE_WORDS)       /* y-x | y+x | 2d*t | -2d*t | 2z */
+#define QUAD_DIGIT_BYTES 264                           /* REF_JSF_LEN rounded up to 8 */
+#define QUAD_ITEM_WORDS (4 * QUAD_ADDEND_WORDS + 2 * QUAD_DIGIT_BYTES / 4)   /* Q, B, Q+B, Q-B, ux, uy */
+
+// ---- set-up: one lane per item -------------------------------------------------------------------
+
+ED_DEV void quad_value_store(uint32_t* dst, const fe& v) {
+  word4* p = reinterpret_cast<word4*>(dst);
+  p[0] = word4{v.v[0], v.v[1], v.v[2], v.v[3]};
+  p[1] = word4{v.v[4], v.v[5], v.v[6], v.v[7]};
+  p[2] = word4{v.v[8], v.v[9], 0, 0};
+}
+
+ED_DEV void quad_value_load(fe& v, const uint32_t* src) {
+  const word4* p = reinterpret_cast<const word4*>(src);
+  const word4 a = p[0], b = p[1], c = p[2];
+  v.v[0] = a.x; v.v[1] = a.y; v.v[2] = a.z; v.v[3] = a.w;
+  v.v[4] = b.x; v.v[5] = b.y; v.v[6] = b.z; v.v[7] = b.w;
+  v.v[8] = c.x; v.v[9] = c.y;
+}
+
+// the five factors of one addend given as an extended point, every one tight
+ED_DEV void quad_addend_store(uint32_t* dst, const ge& p) {
+  fe t;
+  fe_sub(t, p.Y, p.X); fe_carry(t); quad_value_store(dst, t);
+  fe_add(t, p.Y, p.X); fe_carry(t); quad_value_store(dst + QUAD_VALUE_WORDS, t);
+  fe_mul(t, p.T, fe_const_2d());    quad_value_store(dst + 2 * QUAD_VALUE_WORDS, t);
+  fe_neg(t, t); fe_carry(t);        quad_value_store(dst + 3 * QUAD_VALUE_WORDS, t);
+  fe_add(t, p.Z, p.Z); fe_carry(t); quad_value_store(dst + 4 * QUAD_VALUE_WORDS, t);
+}
+
+// The loop invariants of ed.c:455-478 from what k_verify_prepare left in the workspace (the digit
+// words and entry 1 of the item's table), as lanes.h: verify_exact_setup_reuse_lane, laid out for
+// the quad chain: four addends x five factors, then the two digit strings.
+ED_DEV void verify_exact_setup_quad_lane(const uint32_t* digits, const uint32_t* tab, const uint32_t* base1,
+                                         uint32_t* item) {
+  uint32_t tw[8], sw[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { tw[k] = digits[k]; sw[k] = digits[8 + k]; }
+  words_sub_pattern(tw, 0x88888888u);
+  words_sub_pattern(sw, 0x80008000u);
+  int8_t* ux = reinterpret_cast<int8_t*>(item + 4 * QUAD_ADDEND_WORDS);
+  int8_t* uy = ux + QUAD_DIGIT_BYTES;
+  const int n = ref_jsf_strided(ux, uy, 1, sw, tw);
+  for (int i = n + 1; i < QUAD_DIGIT_BYTES; i++) { ux[i] = 0; uy[i] = 0; }
+  ge_cached c1;
+  cached_load(c1, tab, 1);
+  ge q, p;                                       // Q = -A with every coordinate doubled
+  fe_sub(q.X, c1.ypx, c1.ymx); fe_carry(q.X);
+  fe_add(q.Y, c1.ypx, c1.ymx); fe_carry(q.Y);
+  q.Z = c1.z2;
+  fe_mul(q.T, c1.t2d, fe_const_inv_d());
+  ge_niels pcB;
+  niels_load(pcB, base1);
+  quad_addend_store(item, q);
+  ge_base(p);
+  quad_addend_store(item + QUAD_ADDEND_WORDS, p);
+  ref_add_pc(p, q, pcB, false);
+  quad_addend_store(item + 2 * QUAD_ADDEND_WORDS, p);   // Q + B
+  ref_add_pc(p, q, pcB, true);
+  quad_addend_store(item + 3 * QUAD_ADDEND_WORDS, p);   // Q - B
+}
+
+// ---- the chain: four lanes per item ------------------------------------------------------------
+
+// quad permutation: lane l of every quad reads lane P_l
+template <int P0, int P1, int P2, int P3>
+ED_DEV void fe_quad_perm(fe& o, const fe& a) {
+  constexpr int ctrl = P0 | (P1 << 2) | (P2 << 4) | (P3 << 6);
+#pragma unroll
+  for (int j = 0; j < 10; j++)
+    o.v[j] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.v[j], ctrl, 0xf, 0xf, false);
+}
+
+// the first factor of stage A: (Y - X, Y + X, T, Z); r tight, result < 3u
+ED_DEV void quad_stage_a_operand(fe& first, const fe& r, int q) {
+  fe p, s, d;
+  fe_quad_perm<1, 0, 2, 3>(p, r);                // lane 0 sees Y, lane 1 sees X
+  fe_add(s, r, p);                               // 2u
+  fe_sub(d, p, r);                               // 3u
+  first = r;
+  fe_cmov(first, d, q == 0);
+  fe_cmov(first, s, q == 1);
+}
+
+// stage B: m = (a, b, c, d) across the quad, tight -> (X, Y, T, Z) = (f*e, h*g, h*e, f*g)
+ED_DEV void quad_stage_b(fe& out, const fe& m, int q) {
+  fe a, b, c, d, e, f, g, h;
+  fe_quad_perm<0, 0, 0, 0>(a, m);
+  fe_quad_perm<1, 1, 1, 1>(b, m);
+  fe_quad_perm<2, 2, 2, 2>(c, m);
+  fe_quad_perm<3, 3, 3, 3>(d, m);
+  fe_sub(e, b, a);                               // 3u
+  fe_sub(f, d, c);                               // 3u
+  fe_add(g, d, c);                               // 2u
+  fe_add(h, b, a);                               // 2u
+  fe x = h, y = g;
+  fe_cmov(x, f, q == 0 || q == 3);               // first factor  < 8u
+  fe_cmov(y, e, q == 0 || q == 2);               // second factor < 3.36u
+  fe_mul(out, x, y);
+}
+
+// ed.c:479-506 for one item; `item` = its scratchpad, q = lane & 3.  Returns (in every lane, but
+// lane 1 is the one that holds y) whether the encoding of the result equals R's bytes.
+ED_DEV bool verify_exact_chain_quad(const uint32_t rw[8], const uint32_t* item, int q) {
+  const uint32_t* uxw = item + 4 * QUAD_ADDEND_WORDS;          // digit strings, four steps per word
+  const uint32_t* uyw = uxw + QUAD_DIGIT_BYTES / 4;
+  fe r, k;
+  fe_set(r, (uint32_t)(q & 1));                  // neutral element (0, 1, 0, 1) as (X, Y, T, Z)
+  fe_set(k, 1);                                  // the doubling's constants (1, 1, 2d, 2)
+  { fe two; fe_set(two, 2); fe_cmov(k, fe_const_2d(), q == 2); fe_cmov(k, two, q == 3); }
+  // Two dependent loads stand before every step (digits, then the factor they select); both are
+  // issued ahead -- the factor one step, the digits one word = four steps -- so that their latency
+  // (microseconds beside k_verify_main's table traffic) hides behind the current step.
+  int i = REF_JSF_LEN - 1;
+  uint32_t wx = uxw[i >> 2], wy = uyw[i >> 2];   // word holding step i
+  uint32_t nx = uxw[(i >> 2) - 1], ny = uyw[(i >> 2) - 1];
+  fe mult_next;
+  bool skip_next;
+  // decode step j from the current words and start the load of its factor
+#define QUAD_PREPARE_STEP(j)                                                                        \
+  {                                                                                                 \
+    const int da = (int)(int8_t)(wx >> (8 * ((j) & 3))), db = (int)(int8_t)(wy >> (8 * ((j) & 3))); \
+    const bool both = (da != 0) && (db != 0);                                                       \
+    skip_next = (da == 0) && (db == 0);                                                             \
+    /* which addend: 2 = Q+B (digits equal), 3 = Q-B (digits opposite), 1 = B, 0 = Q; negated? */   \
+    const int which = both ? (da == db ? 2 : 3) : (da != 0 ? 1 : 0);                                \
+    const int neg = (which == 2 ? (da < 0) : which == 3 ? (da > 0) : which == 1 ? (da < 0) : (db < 0)) ? 1 : 0; \
+    const int v = q == 0 ? neg : q == 1 ? 1 - neg : q == 2 ? 2 + neg : 4;                           \
+    quad_value_load(mult_next, item + QUAD_ADDEND_WORDS * which + QUAD_VALUE_WORDS * v);            \
+  }
+  QUAD_PREPARE_STEP(i)
+#pragma unroll 1
+  for (;;) {
+    const fe mult = mult_next;
+    const bool skip = skip_next;
+    if (i > 0) {
+      const int j = i - 1;
+      if ((j & 3) == 3) {                        // step j starts the next word (wave-uniform)
+        wx = nx; wy = ny;
+        if (j >= 4) { nx = uxw[(j >> 2) - 1]; ny = uyw[(j >> 2) - 1]; }
+      }
+      QUAD_PREPARE_STEP(j)
+    }
+    fe first, m, sum;
+    quad_stage_a_operand(first, r, q);
+    fe_mul(m, first, mult);
+    quad_stage_b(sum, m, q);
+    fe_cmov(r, sum, !skip);
+    if (i == 0) break;
+    quad_stage_a_operand(first, r, q);
+    fe_sq(m, first);
+    fe_mul(m, m, k);
+    quad_stage_b(r, m, q);
+    i--;
+  }
+#undef QUAD_PREPARE_STEP
+  // ed_export (ed.c:155-169): every lane inverts Z (fld_inv(0) = 0 as in the reference); lane 0
+  // ends up with x, lane 1 with y
+  fe z, zi, aff;
+  fe_quad_perm<3, 3, 3, 3>(z, r);
+  fe_inv(zi, z);
+  fe_mul(aff, r, zi);
+  uint32_t w[8];
+  fe_tobytes(w, aff);
+  const uint32_t xpar = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[0], 0, 0xf, 0xf, false) & 1u;
+  w[7] |= xpar << 31;
+  uint32_t diff = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) diff |= w[j] ^ rw[j];
+  return diff == 0;
+}
+
+}  // namespace ed

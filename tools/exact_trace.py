@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import libeddsa_amd as ed, workload
 ed.init(0)
-n = 1 << 20
+n = 1 << int(os.environ.get("LOG2N", "20"))
 step = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 sk, msg = workload.sign_inputs(n)
 d = lambda a: torch.from_numpy(a).cuda()
