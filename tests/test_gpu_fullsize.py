@@ -68,3 +68,22 @@ def test_verify_across_workspace_chunks(engine):
     expect = workload.corrupt_for_verify(sig, pk, msg, seed=9, config=4)
     ok = engine.ed25519_verify_batch(dev(sig), dev(pk), dev(msg)).cpu().numpy()
     assert np.array_equal(ok, expect)
+
+
+def test_reference_order_kernels_on_a_large_pass(engine):
+    """self-check mode 2 on a pass of more than 2^19 items: the one-lane chain decides the first 65 536
+    items and the strided k_verify_exact the rest; verdicts equal the windowed kernels' (the smaller
+    pass of tests/test_gpu_parity.py covers the four-lane chain)"""
+    import workload
+    n = (1 << 19) + 5000
+    sk, msg = workload.sign_inputs(n, seed=12, config=2)
+    pk = engine.ed25519_genpub_batch(dev(sk))
+    sig = engine.ed25519_sign_batch(dev(sk), pk, dev(msg)).cpu().numpy()
+    pk = pk.cpu().numpy()
+    expect = workload.corrupt_for_verify(sig, pk, msg)
+    engine.set_offcurve_mode(2)
+    try:
+        replay = engine.ed25519_verify_batch(dev(sig), dev(pk), dev(msg), msg_len=32).cpu().numpy()
+    finally:
+        engine.set_offcurve_mode(True)
+    assert np.array_equal(replay, expect) and 0 < expect.sum() < n
