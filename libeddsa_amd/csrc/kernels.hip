@@ -176,20 +176,23 @@ k_verify_exact(uint8_t* ok, edk_verify_src src, const uint32_t* offlist, const u
   }
 }
 
-// The first EXACT_MAX_BLOCKS * 64 entries of the work list take a faster route.  The short first
-// half (joint sparse form of the two scalars and the addends Q, B, Q+B, Q-B, all from what
-// k_verify_prepare left in the workspace: lanes.h verify_exact_setup_reuse_lane; about 0.07 ms
-// whatever the count) is a kernel of its own on the caller's stream right after k_verify_prepare; the long second half, the
-// chain, is the ONLY kernel on the side stream, so that it is dispatched together with
+// Passes of more than 2^19 items: the first EXACT_MAX_BLOCKS * 64 entries of the work list take
+// this route (smaller passes: the four-lane chain further down).  The short first half (joint
+// sparse form of the two scalars and the addends Q, B, Q+B, Q-B, all from what k_verify_prepare
+// left in the workspace: lanes.h verify_exact_setup_reuse_lane; about 0.12 ms whatever the count)
+// is a kernel of its own on the caller's stream right after k_verify_prepare; the long second half,
+// the chain, is the ONLY kernel on the side stream, so that it is dispatched together with
 // k_verify_main's first workgroups (a kernel that reaches the side queue later only runs once
 // k_verify_main has drained).  Its blocks are four waves -- one per SIMD, the footprint of exactly
-// one k_verify_main block -- with 152 VGPRs, which fit beside three of the main kernel's waves.
+// one k_verify_main block -- with 152 VGPRs, which fit beside three of the main kernel's waves,
+// at raised wave priority.
 // Measured (tools/exact_path_time.py, rocprofv3 timelines via tools/exact_trace.py): beside the
-// main kernel the chain takes 4.2-4.4 ms (about two of the main kernel's four rounds of 1024
-// resident blocks), so every chain block displaces two main blocks; because 2^20 items are
-// exactly 4 x 1024 blocks there is no slack and ANY displaced block costs a fifth, nearly empty
-// round: +0.6 ms for 1024 listed keys as for 8192, +1.0 ms for 65536 (it was +1.6 ms with
-// single-wave chain blocks, which displaced a main block each).
+// main kernel the chain takes 2.7 ms (4.4 ms before the priority was raised; 1.3 ms on an idle
+// chip), more than one of the main kernel's four rounds of 1024 resident blocks, so every chain
+// block displaces main blocks; because 2^20 items are exactly 4 x 1024 blocks there is no slack
+// and ANY displaced block costs a fifth, nearly empty round: +0.6 ms for 1024 listed keys as for
+// 8192, +1.0 ms for 65536 (it was +1.6 ms with single-wave chain blocks, which displaced a main
+// block each).
 __global__ void __launch_bounds__(EXACT_BLOCK, 2)
 k_verify_exact_setup(const uint32_t* digits, const uint32_t* table, const uint32_t* offlist, const uint32_t* offcount,
                      const uint32_t* base16, uint32_t* pad) {
