@@ -387,6 +387,21 @@ struct verify_finish_policy {
   }
 };
 
+// small passes: four lanes per item (quad_exact.h: verify_main_quad); writes the same workspace
+constexpr size_t QUAD_MAIN_MAX_N = (size_t)1 << 14;   // measured: 0.57 vs 0.86 ms at 2^14, equal at 2^15 (tools/verify_sizes.py)
+__global__ void __launch_bounds__(QUAD_BLOCK, 2)
+k_verify_main_quad(const uint32_t* digits, const uint32_t* table, const uint32_t* base16, uint32_t* accout, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;       // quads are all-or-nothing
+  if (i >= n) return;
+  const int q = (int)(threadIdx.x & 3u);
+  fe r;
+  verify_main_quad(r, digits + 16 * i, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16, q);
+  if (q == 2) return;                            // T is not part of the result
+  uint32_t* o = accout + (i / BLOCK) * (30 * BLOCK) + (i % BLOCK) + (q == 0 ? 0 : q == 1 ? 10 : 20) * BLOCK;
+#pragma unroll
+  for (int j = 0; j < 10; j++) o[j * BLOCK] = r.v[j];
+}
+
 __global__ void __launch_bounds__(BLOCK, 2)
 k_verify_finish(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, uint32_t* acc, uint8_t* flags, size_t n,
                 int exact_offcurve) {
@@ -665,7 +680,11 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
                        0, ws->side, ok, src.sigs, src.sig_stride, ws->offlist, ws->offcount, ws->exact_pad);
     (void)hipEventRecord(ws->ev_exact, ws->side);
   }
-  hipLaunchKernelGGL(k_verify_main, dim3(blocks), dim3(BLOCK), 0, stream, ws->digits, ws->table, base16, ws->acc);
+  if (n <= QUAD_MAIN_MAX_N)
+    hipLaunchKernelGGL(k_verify_main_quad, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0,
+                       stream, ws->digits, ws->table, base16, ws->acc, n);
+  else
+    hipLaunchKernelGGL(k_verify_main, dim3(blocks), dim3(BLOCK), 0, stream, ws->digits, ws->table, base16, ws->acc);
   if (marks) (void)hipEventRecord(marks[2], stream);
   hipLaunchKernelGGL(k_verify_finish, dim3((blocks + FINISH_K - 1) / FINISH_K), dim3(BLOCK), 0, stream, ok, src.sigs,
                      src.sig_stride, ws->acc, ws->flags, n, ws->exact_offcurve);

@@ -7,7 +7,7 @@ import libeddsa_amd as ed
 import workload
 ed.init(0)
 if os.environ.get("OFFCURVE_MODE"): ed.set_offcurve_mode(int(os.environ["OFFCURVE_MODE"]))
-for lg in (20, 19, 18, 17, 16, 14, 12):
+for lg in [int(x) for x in os.environ.get("SIZES", "20,19,18,17,16,15,14,13,12").split(",")]:
     n = 1 << lg
     sk, msg = workload.sign_inputs(n, seed=1, config=2)
     pk = ed.ed25519_genpub_batch(sk); sig = ed.ed25519_sign_batch(sk, pk, msg)
