@@ -14,7 +14,7 @@
 //   k_init_tables    generates what the reference ships as lib/ed_lookup64.h
 #include "eddsa_kernels.h"
 #include "lanes.h"
-#include "quad_exact.h"
+#include "quad_lanes.h"
 
 namespace ed {
 
@@ -224,7 +224,7 @@ k_verify_exact_chain(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const 
 }
 
 // Passes of up to QUAD_ROUTE_MAX_N items wait for the chain (k_verify_main is at most two rounds
-// long there), so they take the low-latency form: four lanes per item (quad_exact.h), for the first
+// long there), so they take the low-latency form: four lanes per item (quad_lanes.h), for the first
 // QUAD_MAX_ITEMS entries of the work list.
 constexpr size_t QUAD_ROUTE_MAX_N = (size_t)1 << 19;
 constexpr int QUAD_MAX_ITEMS = 32768;
@@ -387,7 +387,7 @@ struct verify_finish_policy {
   }
 };
 
-// small passes: four lanes per item (quad_exact.h: verify_main_quad); writes the same workspace
+// small passes: four lanes per item (quad_lanes.h: verify_main_quad); writes the same workspace
 constexpr size_t QUAD_MAIN_MAX_N = (size_t)1 << 14;   // measured: 0.57 vs 0.86 ms at 2^14, equal at 2^15 (tools/verify_sizes.py)
 __global__ void __launch_bounds__(QUAD_BLOCK, 2)
 k_verify_main_quad(const uint32_t* digits, const uint32_t* table, const uint32_t* base16, uint32_t* accout, size_t n) {

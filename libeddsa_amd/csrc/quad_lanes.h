@@ -1,4 +1,4 @@
-// quad_exact.h - the exact (reference-order) verify chain with FOUR lanes per item.
+// quad_lanes.h - four lanes per item: the exact (reference-order) verify chain and the windowed evaluation for small passes.
 //
 // lanes.h: ref_dual_scale_chain replays the reference's JSF/Shamir chain (ed.c:455-507) for public
 // keys that are not curve points with one lane per item: 261 steps of "uniform addition, then
