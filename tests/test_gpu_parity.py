@@ -241,6 +241,23 @@ def test_verify_records(engine, oracle, stride, sig_off, pub_off, msg_off, mlen)
     assert np.array_equal(engine.ed25519_verify_records(dev(rec), sig_off, pub_off, msg_off, mlen).cpu().numpy(), want)
 
 
+def test_route_boundaries_agree(engine, oracle):
+    """the same items decided by the four-lane kernels (pass of 2^14 items) and by the one-lane kernels
+    (pass of 2^14 + 1 items) get the same verdicts, equal to the oracle's; keys on and off the curve"""
+    n = (1 << 14) + 1
+    rng = np.random.default_rng(99)
+    sk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    msg = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    pk = engine.ed25519_genpub_batch(sk)
+    sig = engine.ed25519_sign_batch(sk, pk, msg)
+    sig[::5, 40] ^= 8
+    pk[2::9] = rng.integers(0, 256, (len(pk[2::9]), 32), dtype=np.uint8)       # garbage keys: half are off the curve
+    want = oracle.verify_batch(sig, pk, msg, 32)
+    big = engine.ed25519_verify_batch(dev(sig), dev(pk), dev(msg), msg_len=32).cpu().numpy()
+    small = engine.ed25519_verify_batch(dev(sig[:-1]), dev(pk[:-1]), dev(msg[:-1]), msg_len=32).cpu().numpy()
+    assert np.array_equal(big, want) and np.array_equal(small, want[:-1]) and 0 < want.sum() < n
+
+
 def test_unaligned_device_buffers(engine, oracle):
     """device pointers that are not 16-byte aligned take the byte-wise load/store path"""
     import torch
