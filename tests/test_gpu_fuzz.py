@@ -1,0 +1,68 @@
+"""Seeded differential fuzz on the GPU: random batch sizes (on both sides of every route boundary),
+message lengths (fixed and ragged), corruptions and garbage keys, every batched entry point against
+the oracle, host-pointer and device-pointer paths.  Bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+SIZES = [1, 2, 3, 63, 64, 65, 255, 256, 257, 511, 777, 1024, 2047, 4099, 16383, 16384, 16385, 20011, 33000]
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_fuzz_against_the_oracle(engine, oracle, case):
+    rng = np.random.default_rng(1000 + case)
+    n = int(SIZES[case % len(SIZES)]) if case < len(SIZES) else int(rng.integers(1, 9000))
+    sk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ragged = case % 3 == 1
+    if ragged:
+        lens = rng.integers(0, 200, n)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        msgs = rng.integers(0, 256, int(off[-1]), dtype=np.uint8)
+        one = lambda i: msgs[int(off[i]):int(off[i + 1])].tobytes()   # noqa: E731
+    else:
+        mlen = int(rng.choice([0, 1, 31, 32, 47, 48, 64, 111, 112, 113, 129]))
+        msgs = rng.integers(0, 256, (n, mlen), dtype=np.uint8)
+    # genpub, sign: device results against the oracle
+    pk = oracle.genpub_batch(sk)
+    assert np.array_equal(engine.ed25519_genpub_batch(sk), pk)
+    if ragged:
+        sig = np.stack([np.frombuffer(oracle.sign(sk[i].tobytes(), pk[i].tobytes(), one(i)), np.uint8) for i in range(min(n, 300))])
+        got = engine.ed25519_sign_batch(dev(sk), dev(pk), dev(msgs), msg_off=dev(off.astype(np.int64))).cpu().numpy()
+        assert np.array_equal(got[:len(sig)], sig)
+        sig = got.copy()
+    else:
+        sig = oracle.sign_batch(sk, pk, msgs, mlen)
+        assert np.array_equal(engine.ed25519_sign_batch(dev(sk), dev(pk), dev(msgs), msg_len=mlen).cpu().numpy(), sig)
+    # corrupt: R, S, A, garbage keys (about half of those are off the curve), S + l
+    kind = rng.integers(0, 8, n)
+    bit = rng.integers(0, 256, n)
+    for i in np.nonzero(kind == 1)[0]: sig[i, bit[i] // 8 % 32] ^= 1 << (bit[i] % 8)
+    for i in np.nonzero(kind == 2)[0]: sig[i, 32 + bit[i] // 8 % 32] ^= 1 << (bit[i] % 8)
+    for i in np.nonzero(kind == 3)[0]: pk[i, bit[i] // 8 % 32] ^= 1 << (bit[i] % 8)
+    g = np.nonzero(kind == 4)[0]
+    pk[g] = rng.integers(0, 256, (len(g), 32), dtype=np.uint8)
+    ell = 2**252 + 27742317777372353535851937790883648493
+    for i in np.nonzero(kind == 5)[0]:
+        s = int.from_bytes(sig[i, 32:].tobytes(), "little") + ell
+        if s < 2**256: sig[i, 32:] = np.frombuffer(s.to_bytes(32, "little"), np.uint8)
+    if ragged:
+        want = np.array([oracle.verify(sig[i].tobytes(), pk[i].tobytes(), one(i)) for i in range(n)], np.uint8)
+        got_h = engine.ed25519_verify_batch(sig, pk, msgs, msg_off=off)
+        got_d = engine.ed25519_verify_batch(dev(sig), dev(pk), dev(msgs), msg_off=dev(off.astype(np.int64))).cpu().numpy()
+    else:
+        want = oracle.verify_batch(sig, pk, msgs, mlen)
+        got_h = engine.ed25519_verify_batch(sig, pk, msgs, msg_len=mlen)
+        got_d = engine.ed25519_verify_batch(dev(sig), dev(pk), dev(msgs), msg_len=mlen).cpu().numpy()
+    assert np.array_equal(got_h, want) and np.array_equal(got_d, want)
+    # x25519 and x25519_base on the same random bytes
+    assert np.array_equal(engine.x25519_batch(dev(sk), dev(pk)).cpu().numpy(), oracle.x25519_batch(sk, pk))
+    m = min(n, 500)
+    xb = np.stack([np.frombuffer(oracle.x25519_base(sk[i].tobytes()), np.uint8) for i in range(m)])
+    assert np.array_equal(engine.x25519_base_batch(dev(sk)).cpu().numpy()[:m], xb)
