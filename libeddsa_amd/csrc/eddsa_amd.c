@@ -22,14 +22,28 @@
 #define CHUNK_MAX ((size_t)1 << 20)   /* verify items per workspace pass: 1.6 GB of HBM workspace */
 #define MARK_SLOTS 256                /* profiled verify passes kept for eddsa_amd_verify_phase_ms */
 
+/* Verify workspaces: a small pool, so that passes issued on DIFFERENT streams (host threads that
+ * each own a stream) overlap on the GPU instead of queueing behind one workspace.  A stream keeps the
+ * slot it used last (passes on one stream are ordered anyway, and the slot has the right size);
+ * another stream takes an idle slot, or the least recently used one. */
+#define VERIFY_SLOTS 4
+struct vslot {
+    edk_verify_ws ws;                 /* grown on demand up to CHUNK_MAX items; owns a side stream and two events */
+    hipEvent_t free;                  /* recorded after the last kernel that touches ws */
+    hipStream_t last_stream;
+    unsigned long stamp;              /* for least-recently-used */
+};
+
 struct engine {
     int ready;
     int device;
     uint32_t *base16, *comb;           /* generated base-point tables (HBM) */
     uint32_t *comb_img;                /* the comb as the point kernels stage it in LDS (lanes.h: comb_select) */
-    edk_verify_ws ws;                 /* verify workspace, grown on demand up to CHUNK_MAX items */
-    edk_fixed_ws fws;                 /* sign / genpub / x25519_base workspace, same policy */
-    hipEvent_t ws_free;               /* recorded after the last kernel that touches ws or fws */
+    struct vslot vs[VERIFY_SLOTS];
+    unsigned long clock;
+    int offcurve_mode;                /* eddsa_amd_set_offcurve_mode: 0 reject, 1 exact (default), 2 all exact */
+    edk_fixed_ws fws;                 /* sign / genpub / x25519_base / x25519 workspace, grown on demand */
+    hipEvent_t fws_free;              /* recorded after the last kernel that touches fws */
     int profiling;                    /* record marks around the three verify kernels */
     int marks_used;                   /* passes recorded since profiling was switched on */
     hipEvent_t marks[MARK_SLOTS][4];
@@ -48,18 +62,18 @@ const char *eddsa_amd_strerror(int err)
     return hipGetErrorString((hipError_t)(-err));
 }
 
-static void ws_release(struct engine *e)
+static void ws_release(struct vslot *v)
 {
-    if (e->ws.digits) (void)hipFree(e->ws.digits);
-    if (e->ws.table) (void)hipFree(e->ws.table);
-    if (e->ws.acc) (void)hipFree(e->ws.acc);
-    if (e->ws.flags) (void)hipFree(e->ws.flags);
-    if (e->ws.offlist) (void)hipFree(e->ws.offlist);
-    if (e->ws.offcount) (void)hipFree(e->ws.offcount);
-    if (e->ws.exact_pad) (void)hipFree(e->ws.exact_pad);
-    e->ws.capacity = 0;
-    e->ws.digits = e->ws.table = e->ws.acc = e->ws.offlist = e->ws.offcount = e->ws.exact_pad = NULL;
-    e->ws.flags = NULL;
+    if (v->ws.digits) (void)hipFree(v->ws.digits);
+    if (v->ws.table) (void)hipFree(v->ws.table);
+    if (v->ws.acc) (void)hipFree(v->ws.acc);
+    if (v->ws.flags) (void)hipFree(v->ws.flags);
+    if (v->ws.offlist) (void)hipFree(v->ws.offlist);
+    if (v->ws.offcount) (void)hipFree(v->ws.offcount);
+    if (v->ws.exact_pad) (void)hipFree(v->ws.exact_pad);
+    v->ws.capacity = 0;
+    v->ws.digits = v->ws.table = v->ws.acc = v->ws.offlist = v->ws.offcount = v->ws.exact_pad = NULL;
+    v->ws.flags = NULL;
 }
 
 static void fws_release(struct engine *e)
@@ -76,7 +90,7 @@ static int fws_reserve(struct engine *e, size_t items)
     size_t cap = (items + VERIFY_TILE - 1) / VERIFY_TILE * VERIFY_TILE;
     cap = (cap + 8 * VERIFY_TILE - 1) / (8 * VERIFY_TILE) * (8 * VERIFY_TILE);   /* whole finish blocks */
     if (cap <= e->fws.capacity) return 0;
-    TRY(hipEventSynchronize(e->ws_free));
+    TRY(hipEventSynchronize(e->fws_free));
     fws_release(e);
     TRY(hipMalloc((void **)&e->fws.acc, cap * 30 * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&e->fws.aux, cap * 16 * sizeof(uint32_t)));
@@ -87,26 +101,64 @@ out:
 }
 
 /* caller holds g_lock */
-static int ws_reserve(struct engine *e, size_t items)
+static int ws_reserve(struct vslot *v, size_t items)
 {
     int rc = 0;
     size_t cap = (items + VERIFY_TILE - 1) / VERIFY_TILE * VERIFY_TILE;
     cap = (cap + 8 * VERIFY_TILE - 1) / (8 * VERIFY_TILE) * (8 * VERIFY_TILE);   /* whole finish blocks */
-    if (cap <= e->ws.capacity) return 0;
+    if (cap <= v->ws.capacity) return 0;
     /* the old buffers may still be in use by enqueued kernels */
-    TRY(hipEventSynchronize(e->ws_free));
-    ws_release(e);
-    TRY(hipMalloc((void **)&e->ws.digits, cap * 16 * sizeof(uint32_t)));
-    TRY(hipMalloc((void **)&e->ws.table, cap / VERIFY_TILE * (size_t)VERIFY_TABLE_WORDS_PER_TILE * sizeof(uint32_t)));
-    TRY(hipMalloc((void **)&e->ws.acc, cap * 30 * sizeof(uint32_t)));
-    TRY(hipMalloc((void **)&e->ws.flags, cap));
-    TRY(hipMalloc((void **)&e->ws.offlist, cap * sizeof(uint32_t)));
-    TRY(hipMalloc((void **)&e->ws.offcount, 256));
-    TRY(hipMalloc((void **)&e->ws.exact_pad, EDK_EXACT_PAD_BYTES));
-    e->ws.capacity = cap;
+    TRY(hipEventSynchronize(v->free));
+    ws_release(v);
+    TRY(hipMalloc((void **)&v->ws.digits, cap * 16 * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&v->ws.table, cap / VERIFY_TILE * (size_t)VERIFY_TABLE_WORDS_PER_TILE * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&v->ws.acc, cap * 30 * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&v->ws.flags, cap));
+    TRY(hipMalloc((void **)&v->ws.offlist, cap * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&v->ws.offcount, 256));
+    TRY(hipMalloc((void **)&v->ws.exact_pad, EDK_EXACT_PAD_BYTES));
+    v->ws.capacity = cap;
 out:
-    if (rc) ws_release(e);
+    if (rc) ws_release(v);
     return rc;
+}
+
+/* caller holds g_lock: the slot a pass on stream `st` uses */
+static struct vslot *ws_pick(struct engine *e, hipStream_t st)
+{
+    struct vslot *idle = NULL, *lru = &e->vs[0];
+    for (int i = 0; i < VERIFY_SLOTS; i++) {
+        struct vslot *v = &e->vs[i];
+        if (v->stamp && v->last_stream == st) { lru = v; idle = NULL; goto found; }
+        if (!idle && (v->stamp == 0 || hipEventQuery(v->free) == hipSuccess)) idle = v;
+        if (v->stamp < lru->stamp) lru = v;
+    }
+found:
+    if (idle) lru = idle;
+    lru->last_stream = st;
+    lru->stamp = ++e->clock;
+    return lru;
+}
+
+/* everything the engine holds on the device; caller holds g_lock */
+static void engine_release(struct engine *e)
+{
+    (void)hipDeviceSynchronize();
+    pipe_release();
+    for (int i = 0; i < VERIFY_SLOTS; i++) {
+        struct vslot *v = &e->vs[i];
+        ws_release(v);
+        if (v->ws.side) (void)hipStreamDestroy(v->ws.side);
+        if (v->ws.ev_prepared) (void)hipEventDestroy(v->ws.ev_prepared);
+        if (v->ws.ev_exact) (void)hipEventDestroy(v->ws.ev_exact);
+        if (v->free) (void)hipEventDestroy(v->free);
+    }
+    fws_release(e);
+    if (e->fws_free) (void)hipEventDestroy(e->fws_free);
+    (void)hipFree(e->base16); (void)hipFree(e->comb); (void)hipFree(e->comb_img);
+    for (int s = 0; s < MARK_SLOTS; s++)
+        for (int i = 0; i < 4; i++) if (e->marks[s][i]) (void)hipEventDestroy(e->marks[s][i]);
+    memset(e, 0, sizeof(*e));
 }
 
 int eddsa_amd_init(int device)
@@ -115,32 +167,31 @@ int eddsa_amd_init(int device)
     hipDeviceProp_t prop;
     pthread_mutex_lock(&g_lock);
     if (g_eng.ready && g_eng.device == device) goto out;
-    if (g_eng.ready) {                /* re-bind to another device */
-        ws_release(&g_eng); fws_release(&g_eng);
-        (void)hipFree(g_eng.base16); (void)hipFree(g_eng.comb); (void)hipFree(g_eng.comb_img); (void)hipEventDestroy(g_eng.ws_free);
-        (void)hipStreamDestroy(g_eng.ws.side); (void)hipEventDestroy(g_eng.ws.ev_prepared); (void)hipEventDestroy(g_eng.ws.ev_exact);
-        memset(&g_eng, 0, sizeof(g_eng));
-    }
+    if (g_eng.ready) engine_release(&g_eng);   /* re-bind to another device */
     TRY(hipSetDevice(device));
     TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { rc = -100000; goto out; }
     TRY(hipMalloc((void **)&g_eng.base16, (size_t)TABLE_BASE16_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&g_eng.comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&g_eng.comb_img, COMB_IMG_WORDS * sizeof(uint32_t)));
-    TRY(hipEventCreateWithFlags(&g_eng.ws_free, hipEventDisableTiming));
-    {   /* highest queue priority: its few workgroups must be dispatched while k_verify_main still
-         * has thousands waiting, not after them */
+    TRY(hipEventCreateWithFlags(&g_eng.fws_free, hipEventDisableTiming));
+    for (int i = 0; i < VERIFY_SLOTS; i++) {
+        /* highest queue priority for the side streams: their few workgroups must be dispatched while
+         * k_verify_main still has thousands waiting, not after them */
         int lo = 0, hi = 0;
+        struct vslot *v = &g_eng.vs[i];
         TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        TRY(hipStreamCreateWithPriority(&g_eng.ws.side, hipStreamNonBlocking, hi));
+        TRY(hipStreamCreateWithPriority(&v->ws.side, hipStreamNonBlocking, hi));
+        TRY(hipEventCreateWithFlags(&v->ws.ev_prepared, hipEventDisableTiming));
+        TRY(hipEventCreateWithFlags(&v->ws.ev_exact, hipEventDisableTiming));
+        TRY(hipEventCreateWithFlags(&v->free, hipEventDisableTiming));
+        TRY(hipEventRecord(v->free, NULL));
     }
-    TRY(hipEventCreateWithFlags(&g_eng.ws.ev_prepared, hipEventDisableTiming));
-    TRY(hipEventCreateWithFlags(&g_eng.ws.ev_exact, hipEventDisableTiming));
-    g_eng.ws.exact_offcurve = 1;
+    g_eng.offcurve_mode = 1;
     for (int s = 0; s < MARK_SLOTS; s++)
         for (int i = 0; i < 4; i++) TRY(hipEventCreate(&g_eng.marks[s][i]));
     TRY(edk_init_tables(g_eng.base16, g_eng.comb, g_eng.comb_img, NULL));
-    TRY(hipEventRecord(g_eng.ws_free, NULL));
+    TRY(hipEventRecord(g_eng.fws_free, NULL));
     TRY(hipDeviceSynchronize());
     g_eng.device = device;
     g_eng.ready = 1;
@@ -152,16 +203,7 @@ out:
 void eddsa_amd_shutdown(void)
 {
     pthread_mutex_lock(&g_lock);
-    if (g_eng.ready) {
-        (void)hipDeviceSynchronize();
-        pipe_release();
-        ws_release(&g_eng); fws_release(&g_eng);
-        (void)hipFree(g_eng.base16); (void)hipFree(g_eng.comb); (void)hipFree(g_eng.comb_img); (void)hipEventDestroy(g_eng.ws_free);
-        (void)hipStreamDestroy(g_eng.ws.side); (void)hipEventDestroy(g_eng.ws.ev_prepared); (void)hipEventDestroy(g_eng.ws.ev_exact);
-        for (int s = 0; s < MARK_SLOTS; s++)
-            for (int i = 0; i < 4; i++) if (g_eng.marks[s][i]) (void)hipEventDestroy(g_eng.marks[s][i]);
-        memset(&g_eng, 0, sizeof(g_eng));
-    }
+    if (g_eng.ready) engine_release(&g_eng);
     pthread_mutex_unlock(&g_lock);
 }
 
@@ -194,7 +236,7 @@ out:
 void eddsa_amd_set_offcurve_mode(int exact)
 {
     pthread_mutex_lock(&g_lock);
-    g_eng.ws.exact_offcurve = exact == 2 ? 2 : exact != 0;
+    g_eng.offcurve_mode = exact == 2 ? 2 : exact != 0;
     pthread_mutex_unlock(&g_lock);
 }
 
@@ -236,10 +278,12 @@ static int verify_dev(uint8_t *ok, const edk_verify_src *all, size_t n, hipStrea
     int rc = ensure_init();
     if (rc || n == 0) return rc;
     pthread_mutex_lock(&g_lock);
-    rc = ws_reserve(&g_eng, n < CHUNK_MAX ? n : CHUNK_MAX);
+    struct vslot *v = ws_pick(&g_eng, st);
+    rc = ws_reserve(v, n < CHUNK_MAX ? n : CHUNK_MAX);
     if (rc) goto out;
-    /* the workspace is shared: order this call behind the previous one even across streams */
-    TRY(hipStreamWaitEvent(st, g_eng.ws_free, 0));
+    v->ws.exact_offcurve = g_eng.offcurve_mode;
+    /* the slot may have served another stream: order this pass behind its previous one */
+    TRY(hipStreamWaitEvent(st, v->free, 0));
     for (size_t done = 0; done < n; done += CHUNK_MAX) {
         size_t m = n - done < CHUNK_MAX ? n - done : CHUNK_MAX;
         edk_verify_src src = *all;
@@ -248,9 +292,9 @@ static int verify_dev(uint8_t *ok, const edk_verify_src *all, size_t n, hipStrea
         if (all->msg_off) src.msg_off += done; else src.msgs += done * all->msg_stride;
         hipEvent_t *marks = NULL;
         if (g_eng.profiling && g_eng.marks_used < MARK_SLOTS) marks = g_eng.marks[g_eng.marks_used++];
-        TRY(edk_verify(ok + done, &src, m, g_eng.base16, &g_eng.ws, marks, st));
+        TRY(edk_verify(ok + done, &src, m, g_eng.base16, &v->ws, marks, st));
     }
-    TRY(hipEventRecord(g_eng.ws_free, st));
+    TRY(hipEventRecord(v->free, st));
 out:
     pthread_mutex_unlock(&g_lock);
     return rc;
@@ -290,10 +334,10 @@ static int run_fixed(size_t n, fixed_step step, const void *ctx, void *stream)
     pthread_mutex_lock(&g_lock);
     rc = fws_reserve(&g_eng, n < CHUNK_MAX ? n : CHUNK_MAX);
     if (rc) goto out;
-    TRY(hipStreamWaitEvent(st, g_eng.ws_free, 0));
+    TRY(hipStreamWaitEvent(st, g_eng.fws_free, 0));
     for (size_t done = 0; done < n; done += CHUNK_MAX)
         TRY(step(done, n - done < CHUNK_MAX ? n - done : CHUNK_MAX, ctx, st));
-    TRY(hipEventRecord(g_eng.ws_free, st));
+    TRY(hipEventRecord(g_eng.fws_free, st));
 out:
     pthread_mutex_unlock(&g_lock);
     return rc;
