@@ -22,14 +22,15 @@
 #define CHUNK_MAX ((size_t)1 << 20)   /* verify items per workspace pass: 1.6 GB of HBM workspace */
 #define MARK_SLOTS 256                /* profiled verify passes kept for eddsa_amd_verify_phase_ms */
 
-/* Verify workspaces: a small pool, so that passes issued on DIFFERENT streams (host threads that
+/* Workspaces: a small pool, so that passes issued on DIFFERENT streams (host threads that
  * each own a stream) overlap on the GPU instead of queueing behind one workspace.  A stream keeps the
  * slot it used last (passes on one stream are ordered anyway, and the slot has the right size);
  * another stream takes an idle slot, or the least recently used one. */
 #define VERIFY_SLOTS 4
 struct vslot {
     edk_verify_ws ws;                 /* grown on demand up to CHUNK_MAX items; owns a side stream and two events */
-    hipEvent_t free;                  /* recorded after the last kernel that touches ws */
+    edk_fixed_ws fws;                 /* sign / genpub / x25519_base / x25519 workspace, grown on demand */
+    hipEvent_t free;                  /* recorded after the last kernel that touches ws or fws */
     hipStream_t last_stream;
     unsigned long stamp;              /* for least-recently-used */
 };
@@ -42,8 +43,6 @@ struct engine {
     struct vslot vs[VERIFY_SLOTS];
     unsigned long clock;
     int offcurve_mode;                /* eddsa_amd_set_offcurve_mode: 0 reject, 1 exact (default), 2 all exact */
-    edk_fixed_ws fws;                 /* sign / genpub / x25519_base / x25519 workspace, grown on demand */
-    hipEvent_t fws_free;              /* recorded after the last kernel that touches fws */
     int profiling;                    /* record marks around the three verify kernels */
     int marks_used;                   /* passes recorded since profiling was switched on */
     hipEvent_t marks[MARK_SLOTS][4];
@@ -76,27 +75,27 @@ static void ws_release(struct vslot *v)
     v->ws.flags = NULL;
 }
 
-static void fws_release(struct engine *e)
+static void fws_release(struct vslot *v)
 {
-    if (e->fws.acc) (void)hipFree(e->fws.acc);
-    if (e->fws.aux) (void)hipFree(e->fws.aux);
-    memset(&e->fws, 0, sizeof(e->fws));
+    if (v->fws.acc) (void)hipFree(v->fws.acc);
+    if (v->fws.aux) (void)hipFree(v->fws.aux);
+    memset(&v->fws, 0, sizeof(v->fws));
 }
 
 /* caller holds g_lock */
-static int fws_reserve(struct engine *e, size_t items)
+static int fws_reserve(struct vslot *v, size_t items)
 {
     int rc = 0;
     size_t cap = (items + VERIFY_TILE - 1) / VERIFY_TILE * VERIFY_TILE;
     cap = (cap + 8 * VERIFY_TILE - 1) / (8 * VERIFY_TILE) * (8 * VERIFY_TILE);   /* whole finish blocks */
-    if (cap <= e->fws.capacity) return 0;
-    TRY(hipEventSynchronize(e->fws_free));
-    fws_release(e);
-    TRY(hipMalloc((void **)&e->fws.acc, cap * 30 * sizeof(uint32_t)));
-    TRY(hipMalloc((void **)&e->fws.aux, cap * 16 * sizeof(uint32_t)));
-    e->fws.capacity = cap;
+    if (cap <= v->fws.capacity) return 0;
+    TRY(hipEventSynchronize(v->free));
+    fws_release(v);
+    TRY(hipMalloc((void **)&v->fws.acc, cap * 30 * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&v->fws.aux, cap * 16 * sizeof(uint32_t)));
+    v->fws.capacity = cap;
 out:
-    if (rc) fws_release(e);
+    if (rc) fws_release(v);
     return rc;
 }
 
@@ -148,13 +147,12 @@ static void engine_release(struct engine *e)
     for (int i = 0; i < VERIFY_SLOTS; i++) {
         struct vslot *v = &e->vs[i];
         ws_release(v);
+        fws_release(v);
         if (v->ws.side) (void)hipStreamDestroy(v->ws.side);
         if (v->ws.ev_prepared) (void)hipEventDestroy(v->ws.ev_prepared);
         if (v->ws.ev_exact) (void)hipEventDestroy(v->ws.ev_exact);
         if (v->free) (void)hipEventDestroy(v->free);
     }
-    fws_release(e);
-    if (e->fws_free) (void)hipEventDestroy(e->fws_free);
     (void)hipFree(e->base16); (void)hipFree(e->comb); (void)hipFree(e->comb_img);
     for (int s = 0; s < MARK_SLOTS; s++)
         for (int i = 0; i < 4; i++) if (e->marks[s][i]) (void)hipEventDestroy(e->marks[s][i]);
@@ -174,7 +172,6 @@ int eddsa_amd_init(int device)
     TRY(hipMalloc((void **)&g_eng.base16, (size_t)TABLE_BASE16_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&g_eng.comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&g_eng.comb_img, COMB_IMG_WORDS * sizeof(uint32_t)));
-    TRY(hipEventCreateWithFlags(&g_eng.fws_free, hipEventDisableTiming));
     for (int i = 0; i < VERIFY_SLOTS; i++) {
         /* highest queue priority for the side streams: their few workgroups must be dispatched while
          * k_verify_main still has thousands waiting, not after them */
@@ -191,7 +188,6 @@ int eddsa_amd_init(int device)
     for (int s = 0; s < MARK_SLOTS; s++)
         for (int i = 0; i < 4; i++) TRY(hipEventCreate(&g_eng.marks[s][i]));
     TRY(edk_init_tables(g_eng.base16, g_eng.comb, g_eng.comb_img, NULL));
-    TRY(hipEventRecord(g_eng.fws_free, NULL));
     TRY(hipDeviceSynchronize());
     g_eng.device = device;
     g_eng.ready = 1;
@@ -324,7 +320,7 @@ int ed25519_verify_records_dev(uint8_t *ok, const uint8_t *records, size_t strid
 }
 
 /* the three fixed-base operations share one driver: chunks of at most CHUNK_MAX items through fws */
-typedef hipError_t (*fixed_step)(size_t done, size_t m, const void *ctx, hipStream_t st);
+typedef hipError_t (*fixed_step)(size_t done, size_t m, const void *ctx, const edk_fixed_ws *fws, hipStream_t st);
 
 static int run_fixed(size_t n, fixed_step step, const void *ctx, void *stream)
 {
@@ -332,12 +328,13 @@ static int run_fixed(size_t n, fixed_step step, const void *ctx, void *stream)
     hipStream_t st = (hipStream_t)stream;
     if (rc || n == 0) return rc;
     pthread_mutex_lock(&g_lock);
-    rc = fws_reserve(&g_eng, n < CHUNK_MAX ? n : CHUNK_MAX);
+    struct vslot *v = ws_pick(&g_eng, st);
+    rc = fws_reserve(v, n < CHUNK_MAX ? n : CHUNK_MAX);
     if (rc) goto out;
-    TRY(hipStreamWaitEvent(st, g_eng.fws_free, 0));
+    TRY(hipStreamWaitEvent(st, v->free, 0));
     for (size_t done = 0; done < n; done += CHUNK_MAX)
-        TRY(step(done, n - done < CHUNK_MAX ? n - done : CHUNK_MAX, ctx, st));
-    TRY(hipEventRecord(g_eng.fws_free, st));
+        TRY(step(done, n - done < CHUNK_MAX ? n - done : CHUNK_MAX, ctx, &v->fws, st));
+    TRY(hipEventRecord(v->free, st));
 out:
     pthread_mutex_unlock(&g_lock);
     return rc;
@@ -345,13 +342,13 @@ out:
 
 struct sign_ctx { uint8_t *sigs; const uint8_t *secs, *pubs, *msgs; const uint64_t *msg_off; size_t msg_len; };
 
-static hipError_t sign_step(size_t done, size_t m, const void *vctx, hipStream_t st)
+static hipError_t sign_step(size_t done, size_t m, const void *vctx, const edk_fixed_ws *fws, hipStream_t st)
 {
     const struct sign_ctx *c = (const struct sign_ctx *)vctx;
     const uint8_t *mp = c->msg_off ? c->msgs : c->msgs + done * c->msg_len;
     const uint64_t *op = c->msg_off ? c->msg_off + done : NULL;
     return edk_sign(c->sigs + 64 * done, c->secs + 32 * done, c->pubs + 32 * done, mp, op, c->msg_len, m,
-                    g_eng.comb_img, &g_eng.fws, st);
+                    g_eng.comb_img, fws, st);
 }
 
 int ed25519_sign_batch_dev(uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs, const uint8_t *msgs,
@@ -363,10 +360,10 @@ int ed25519_sign_batch_dev(uint8_t *sigs, const uint8_t *secs, const uint8_t *pu
 
 struct io_ctx { uint8_t *out; const uint8_t *in; };
 
-static hipError_t genpub_step(size_t done, size_t m, const void *vctx, hipStream_t st)
+static hipError_t genpub_step(size_t done, size_t m, const void *vctx, const edk_fixed_ws *fws, hipStream_t st)
 {
     const struct io_ctx *c = (const struct io_ctx *)vctx;
-    return edk_genpub(c->out + 32 * done, c->in + 32 * done, m, g_eng.comb_img, &g_eng.fws, st);
+    return edk_genpub(c->out + 32 * done, c->in + 32 * done, m, g_eng.comb_img, fws, st);
 }
 
 int ed25519_genpub_batch_dev(uint8_t *pubs, const uint8_t *secs, size_t n, void *stream)
@@ -377,10 +374,10 @@ int ed25519_genpub_batch_dev(uint8_t *pubs, const uint8_t *secs, size_t n, void 
 
 struct io2_ctx { uint8_t *out; const uint8_t *a, *b; };
 
-static hipError_t x25519_step(size_t done, size_t m, const void *vctx, hipStream_t st)
+static hipError_t x25519_step(size_t done, size_t m, const void *vctx, const edk_fixed_ws *fws, hipStream_t st)
 {
     const struct io2_ctx *c = (const struct io2_ctx *)vctx;
-    return edk_x25519(c->out + 32 * done, c->a + 32 * done, c->b + 32 * done, m, &g_eng.fws, st);
+    return edk_x25519(c->out + 32 * done, c->a + 32 * done, c->b + 32 * done, m, fws, st);
 }
 
 int x25519_batch_dev(uint8_t *out, const uint8_t *scalars, const uint8_t *points, size_t n, void *stream)
@@ -389,10 +386,10 @@ int x25519_batch_dev(uint8_t *out, const uint8_t *scalars, const uint8_t *points
     return run_fixed(n, x25519_step, &c, stream);
 }
 
-static hipError_t xbase_step(size_t done, size_t m, const void *vctx, hipStream_t st)
+static hipError_t xbase_step(size_t done, size_t m, const void *vctx, const edk_fixed_ws *fws, hipStream_t st)
 {
     const struct io_ctx *c = (const struct io_ctx *)vctx;
-    return edk_x25519_base(c->out + 32 * done, c->in + 32 * done, m, g_eng.comb_img, &g_eng.fws, st);
+    return edk_x25519_base(c->out + 32 * done, c->in + 32 * done, m, g_eng.comb_img, fws, st);
 }
 
 int x25519_base_batch_dev(uint8_t *out, const uint8_t *scalars, size_t n, void *stream)
