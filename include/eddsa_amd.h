@@ -28,8 +28,9 @@
  * reference has no error channel; a loop over it cannot fail).  On error the outputs are
  * unspecified.  Ownership: the caller owns every buffer; the library keeps no pointer after a
  * host-pointer call returns / after the stream work of a device-pointer call completes.
- * Threading: calls may be issued from several host threads; calls that target the same device
- * serialise on that device's workspace.
+ * Threading: calls may be issued from several host threads.  Device-pointer calls on different
+ * streams use different workspaces (a pool of four) and overlap on the GPU; calls on one stream are
+ * ordered by the stream; host-pointer calls share one staging pipeline and run one after the other.
  */
 #ifndef EDDSA_AMD_H
 #define EDDSA_AMD_H
