@@ -276,6 +276,43 @@ def test_unaligned_device_buffers(engine, oracle):
     assert engine.ed25519_verify_batch(dev(sig), dev(pk), dev(msg), msg_len=33).all()
 
 
+def test_device_calls_on_several_streams(engine, oracle):
+    """host threads that each own a stream use different workspaces of the pool and overlap on the
+    GPU: six threads (more than the pool has slots), mixed operations and sizes, all results right"""
+    import threading
+    import torch
+    rng = np.random.default_rng(31)
+    jobs = []
+    for k in range(6):
+        n = int(rng.choice([300, 5000, 20000, 70000]))
+        sk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        msg = rng.integers(0, 256, (n, 24), dtype=np.uint8)
+        pk = oracle.genpub_batch(sk)
+        sig = oracle.sign_batch(sk, pk, msg, 24)
+        sig[::3, 1] ^= 1
+        jobs.append((dev(sk), dev(pk), dev(msg), dev(sig), sig.copy(), oracle.verify_batch(sig, pk, msg, 24), pk))
+    torch.cuda.synchronize()
+    bad = []
+
+    def worker(k):
+        d_sk, d_pk, d_msg, d_sig, sig, want, pk = jobs[k]
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            for _ in range(4):
+                ok = engine.ed25519_verify_batch(d_sig, d_pk, d_msg, msg_len=24)
+                pub = engine.ed25519_genpub_batch(d_sk)
+                x = engine.x25519_batch(d_sk, d_pk)
+            st.synchronize()
+        if not np.array_equal(ok.cpu().numpy(), want) or not np.array_equal(pub.cpu().numpy(), pk) \
+                or not np.array_equal(x.cpu().numpy(), oracle.x25519_batch(d_sk.cpu().numpy(), pk)):
+            bad.append(k)
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not bad
+
+
 def test_shutdown_and_implicit_reinit(engine, golden):
     """eddsa_amd_shutdown releases everything; the next call builds tables and workspaces again"""
     t = np.frombuffer(golden("x25519_table.bin"), np.uint8).reshape(-1, 96)
