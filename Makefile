@@ -21,8 +21,15 @@ $(BUILD)/eddsa_amd.o: $(CSRC)/eddsa_amd.c $(CSRC)/eddsa_kernels.h include/eddsa.
 	@mkdir -p $(BUILD)
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(LIB): $(BUILD)/kernels.o $(BUILD)/eddsa_amd.o
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -lpthread
+# SONAME = the reference's (libeddsa.so.0, reference lib/CMakeLists.txt:43-44): a program linked against
+# the reference loads this library through the libeddsa.so.0 link without being relinked.
+$(LIB): $(BUILD)/kernels.o $(BUILD)/rlc.o $(BUILD)/eddsa_amd.o
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -Wl,-soname,libeddsa.so.0 -o $@ $^ -lpthread -ldl
+	ln -sf libeddsa_amd.so libeddsa_amd/libeddsa.so.0
+
+$(BUILD)/rlc.o: $(CSRC)/rlc.hip $(wildcard $(CSRC)/*.h)
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 oracle:
 	$(MAKE) -C oracle all
@@ -32,7 +39,7 @@ microbench:
 	$(HIPCC) -O3 --offload-arch=$(ARCH) -I$(CSRC) tools/microbench/fe_rates.hip -o tools/microbench/fe_rates.bin
 
 clean:
-	rm -rf $(BUILD) $(LIB)
+	rm -rf $(BUILD) $(LIB) libeddsa_amd/libeddsa.so.0
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle microbench clean

@@ -1,24 +1,35 @@
 #!/usr/bin/env python3
 """bench.py - headline benchmark of the MI355X Ed25519 / X25519 engine.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--op verify|x25519|sign] [--log2n 20]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--op all|verify|x25519|sign] [--log2n L]
 
-Metric (BASELINE.json): ed25519 verifies/s at batch 2^20 per GPU (configs[1]; --op x25519 and
---op sign measure configs[2] and configs[4]).  One "step" = one pass of the hot path over the
-whole synthetic batch, inputs already resident in HBM.  N > 1 is launched by torch.distributed.run
-with one rank per GPU: every rank owns its own 2^20-item shard (weak scaling, no data-path
-collective) and the step ends with the RCCL all-gather of the result bytes.
+Metric (BASELINE.json): ed25519 verifies/s and x25519 ops/s at batch 2^20 on 1/2/4/8 MI355X.
+One "step" = one pass of the hot path over the whole synthetic batch, inputs already resident in HBM.
+
+  N = 1   config 2: 2^20 ed25519 verifies (SURVEY 8d workload: seed 1, 1/16 corrupted, edge vectors
+          spliced in).  `value` = verifies/s.
+  N > 1   config 4: 2^24 verifies in total (seed 3), contiguous shards of 2^24/N items per GPU, one
+          rank per GPU, no data-path collective; the step ends with the RCCL all-gather of the
+          verdict bytes.  Total work fixed: "strong".  --log2n overrides the per-GPU size
+          (then "weak").
+After the verify region the same process times config 3 (2^20 x25519 per GPU) and config 5 (2^20
+signs per GPU) with the same step count and reports them under "secondary" (--op all, the default).
+
+`--gpus N` without a torch.distributed environment spawns the N ranks itself (a child
+`python -m torch.distributed.run`, started before this process touches the GPU) and relays rank 0's line.
 
 Prints ONE JSON line on rank 0 (see the driver contract), with two extra objects:
   roofline      the dominant kernel (k_verify_main) against the integer-VALU multiply-issue
                 roofline SURVEY 8(d) prescribes for this path, plus the HBM view of the same launch
   cpu_baseline  the reference itself (oracle/_ref, compiled from its own sources) timed on this
-                box's host cores on a bounded sample of the same workload
+                box's host cores on a bounded sample of the same workload (N = 1 only)
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,20 +48,24 @@ MUL32_VERIFY = 312370
 MUL32_VERIFY_MAIN = 312370 - (255 * 55 + 19 * 100) - (254 * 55 + 13 * 100)  # minus ed_import, ed_export
 MUL32_X25519 = 202050
 MUL32_SIGN = 64570
+MUL32 = {"verify": MUL32_VERIFY, "x25519": MUL32_X25519, "sign": MUL32_SIGN}
 BYTES = {"verify": 129, "x25519": 96, "sign": 160}      # algorithmic HBM bytes per item
+UNIT = {"verify": "verifies/s", "x25519": "ops/s", "sign": "signs/s"}
+KERNELS = {"verify": "k_verify_main", "x25519": "k_x25519_ladder + k_x25519_finish", "sign": "k_sign_point + k_sign_finish"}
 # v_mad_u64_u32 issue peak: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz (profiles/r01_valu_rates.txt
 # measures 36-37 T lane-MAC/s at the clock the chip holds under this load)
 PEAK_TMUL32 = 256 * 4 * 16 * 2.4e9 / 1e12
 PEAK_HBM_GBS = 8000.0
+PMC_SOURCE = "profiles/pmc_summary.json (rocprofv3 --pmc, separate passes of this command; not measured in this run)"
 
 
-def make_workload(op, n, rank, device):
-    """SURVEY 8(d) seeded synthetic batch from tools/workload.py (SplitMix64 streams; rank r owns
-    items r*n .. (r+1)*n-1 of the stream).  verify: 32-byte messages, random keys, items with
-    i % 16 == 5 corrupted by one flipped bit in R, S, A or the message (round-robin).  Signatures
-    and public keys come from the engine's own sign/genpub kernels (parity-tested separately; the
-    2^20 batches are the ones whose digests tests/golden/batch_digests.json pins)."""
-    first = rank * n
+def make_workload(op, n, first, device, seed=None, config=None):
+    """SURVEY 8(d) seeded synthetic batch from tools/workload.py (SplitMix64 streams; this rank owns
+    items first .. first+n-1 of the stream).  verify: 32-byte messages, random keys, items with
+    i % 16 == 5 corrupted by one flipped bit in R, S, A or the message (round-robin), edge vectors
+    spliced in at fixed indices.  Signatures and public keys come from the engine's own sign/genpub
+    kernels (parity-tested separately; the batches are the ones whose digests
+    tests/golden/batch_digests.json pins)."""
     up = lambda a: torch.from_numpy(a).to(device)  # noqa: E731
     if op == "x25519":
         sc, pt = workload.x25519_inputs(n, first=first)
@@ -59,13 +74,20 @@ def make_workload(op, n, rank, device):
         sk, msg = workload.sign_inputs(n, first=first)
         sk, msg = up(sk), up(msg)
         return {"secs": sk, "pubs": ed.ed25519_genpub_batch(sk), "msgs": msg}
-    sk, msg = workload.sign_inputs(n, seed=1, config=2, first=first)
+    sk, msg = workload.sign_inputs(n, seed=seed, config=config, first=first)
     d_sk = up(sk)
     pk = ed.ed25519_genpub_batch(d_sk)
     sig = ed.ed25519_sign_batch(d_sk, pk, up(msg)).cpu().numpy()
     pk = pk.cpu().numpy()
-    expect = workload.corrupt_for_verify(sig, pk, msg, first=first)
+    expect = workload.corrupt_for_verify(sig, pk, msg, seed=seed, config=config, first=first)
     return {"sigs": up(sig), "pubs": up(pk), "msgs": up(msg), "expect": up(expect)}
+
+
+def pmc_profile():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+    except (OSError, ValueError):
+        return {}
 
 
 def pmc_traffic(kernel):
@@ -73,14 +95,13 @@ def pmc_traffic(kernel):
     command, separate passes), as committed in profiles/: WRITE_SIZE (KB, exact) + 2 x FETCH_SIZE
     (KB; gfx950 reports half the bytes of 16-byte-per-lane reads, MI355X_MICROARCH.md, HBM).
     None when no profile has been committed."""
-    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
     try:
-        prof = json.load(open(path))
+        prof = pmc_profile()
         ks = [prof["ed::" + name.strip()] for name in kernel.split("+")]
         fetch, write = sum(k["FETCH_SIZE"] for k in ks), sum(k["WRITE_SIZE"] for k in ks)
         return {"bytes": (2.0 * fetch + write) * 1024.0, "fetch_size_kb_raw": fetch, "write_size_kb_raw": write,
-                "source": "profiles/pmc_summary.json (rocprofv3 --pmc, separate passes)"}
-    except (OSError, KeyError, ValueError):
+                "source": PMC_SOURCE}
+    except (KeyError, TypeError):
         return None
 
 
@@ -89,10 +110,9 @@ def pmc_valu_busy(kernel):
     x 4 clocks (one VALU instruction per SIMD per 4 clocks, profiles/r01_valu_rates.txt) / (1024 SIMDs x
     GRBM_GUI_ACTIVE / 8 XCDs).  None when the profile lacks the counters."""
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
-        k = prof["ed::" + kernel.split("+")[0].strip()]
-        return 4.0 * k["SQ_INSTS_VALU"] / (1024.0 * k["GRBM_GUI_ACTIVE"] / 8.0)
-    except (OSError, KeyError, ValueError, TypeError, ZeroDivisionError):
+        k = pmc_profile()["ed::" + kernel.split("+")[0].strip()]
+        return {"value": 4.0 * k["SQ_INSTS_VALU"] / (1024.0 * k["GRBM_GUI_ACTIVE"] / 8.0), "source": PMC_SOURCE}
+    except (KeyError, TypeError, ZeroDivisionError):
         return None
 
 
@@ -144,8 +164,7 @@ def cpu_baseline(op, w, gpu_out, sample):
         fn(*args)
         best = min(best, time.perf_counter() - t0)
     same = bool(np.array_equal(out.reshape(sample, -1), gpu_out[:sample].cpu().numpy().reshape(sample, -1)))
-    unit = {"verify": "verifies/s", "x25519": "ops/s", "sign": "signs/s"}[op]
-    return {"value": sample / best, "unit": unit, "cores": cores, "kind": kind,
+    return {"value": sample / best, "unit": UNIT[op], "cores": cores, "kind": kind,
             "sample": f"first {sample} items of the same batch, {cores} pthreads, best of 3",
             "per_core": sample / best / cores, "gpu_matches_cpu_on_sample": same}
 
@@ -184,19 +203,119 @@ def timed_region(step, steps, world, sync, device):
     return elapsed, out
 
 
+def all_ranks_agree(flag, world, device):
+    if world == 1:
+        return flag
+    t = torch.tensor([int(flag)], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+def measure(op, w, n, steps, warmup, world, device):
+    """warm up, then time `steps` steps of `op` on this rank's n items (plus the result gather);
+    -> (elapsed seconds, last output, average kernel-only ms from HIP events on the launch stream,
+        verify's per-kernel phase times or None)"""
+    marks, gathered = [], [None]
+
+    def step():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = run_step(op, w)
+        e1.record()
+        marks.append((e0, e1))
+        gathered[0] = gather_results(out, world)        # the final result gather (RCCL over xGMI)
+        return out
+
+    for _ in range(warmup):
+        step()
+    marks.clear()
+    if op == "verify":
+        ed.set_profiling(True)
+    elapsed, out = timed_region(step, steps, world, torch.cuda.synchronize, device)
+    phases = ed.verify_phase_ms() if op == "verify" else None
+    ed.set_profiling(False)
+    k_ms = sum(a.elapsed_time(b) for a, b in marks) / len(marks)
+    return elapsed, out, k_ms, phases, gathered[0]
+
+
+def fixture_check(full, world, n, seed, config):
+    """verify: SHA-512 of the whole (gathered) verdict vector against the digest the compiled reference
+    produced for this seeded batch (tests/golden/batch_digests.json, data only); None when the batch
+    is not one of the pinned ones"""
+    import hashlib
+    ok = full.reshape(-1).cpu().numpy()
+    digest = hashlib.sha512(ok.tobytes()).hexdigest()
+    try:
+        pinned = json.load(open(os.path.join(ROOT, "tests", "golden", "batch_digests.json")))
+        total = world * n
+        key = f"verify_2^{total.bit_length() - 1}"
+        fx = pinned[key] if total & (total - 1) == 0 else None
+        if not fx or (fx.get("seed", 1), fx.get("config", 2)) != (seed, config):
+            fx = None
+    except (OSError, ValueError, KeyError):
+        fx = None
+    return {"verdicts_sha512": digest, "accepted": int(ok.sum()),
+            "matches_reference_digest": None if fx is None else bool(fx["verdicts_sha512"] == digest)}
+
+
+def roofline_of(op, n, k_ms, phases, ms_per_step, passes):
+    """the dominant kernel against the integer-VALU multiply-issue roofline; for verify k_verify_main
+    (HIP events around it, averaged over the workspace passes) and the whole pass beside it"""
+    kernel = KERNELS[op]
+    if op == "verify":
+        main_ms, k_mul32, items = phases[1], MUL32_VERIFY_MAIN, n / passes     # per launch of at most 2^20 items
+    else:
+        main_ms, k_mul32, items = k_ms, MUL32[op], n
+    achieved = items * k_mul32 / (main_ms * 1e-3) / 1e12
+    r = {
+        "bound": "valu", "kernel": kernel, "achieved": achieved, "peak": PEAK_TMUL32,
+        "unit": "Tmul32/s", "frac": achieved / PEAK_TMUL32, "traffic": pmc_traffic(kernel),
+        "valu_busy": pmc_valu_busy(kernel), "kernel_ms": main_ms, "items_per_launch": items,
+        "canonical_mul32_per_item": k_mul32,
+        "whole_pass": {"kernels_ms": k_ms, "canonical_mul32_per_item": MUL32[op],
+                       "achieved": n * MUL32[op] / (k_ms * 1e-3) / 1e12,
+                       "frac": n * MUL32[op] / (k_ms * 1e-3) / 1e12 / PEAK_TMUL32},
+        "note": "integer-VALU multiply-issue roofline (SURVEY 8d): canonical 32x32->64 products of the "
+                "reference's radix-2^25.5 schoolbook per item / v_mad_u64_u32 issue peak; the path is not "
+                "HBM- or MFMA-bound",
+        "hbm": {"achieved": n * BYTES[op] / (ms_per_step * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": n * BYTES[op] / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "algorithmic_bytes_per_item": BYTES[op]},
+    }
+    if phases:
+        r["phase_ms"] = {"k_verify_prepare": phases[0], "k_verify_main": phases[1], "k_verify_finish": phases[2]}
+    return r
+
+
+def spawn_ranks(n, argv):
+    """--gpus N without a torch.distributed environment: start the N ranks as a child process, before
+    this process has touched the GPU, and hand its exit code back"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--op", choices=("verify", "x25519", "sign"), default="verify")
-    ap.add_argument("--log2n", type=int, default=20, help="items per GPU = 2^log2n")
+    ap.add_argument("--op", choices=("all", "verify", "x25519", "sign"), default="all")
+    ap.add_argument("--log2n", type=int, default=None,
+                    help="items per GPU = 2^log2n (default: 2^20 at N = 1; config 4's 2^24 / N verifies at N > 1)")
     ap.add_argument("--cpu-sample", type=int, default=1 << 18)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     # Test hooks, so that the N > 1 code path can be exercised on a one-GPU box: EDDSA_BENCH_SHARE_GPU=1
@@ -214,76 +333,64 @@ def main():
             dist.init_process_group(backend)
     ed.init(local)
 
-    op, n = args.op, 1 << args.log2n
-    w = make_workload(op, n, rank, device)
+    # sizes: config 2 at N = 1, config 4 (2^24 in total) at N > 1, unless --log2n says otherwise
+    main_op = "verify" if args.op == "all" else args.op
+    if args.log2n is not None:
+        n, scaling, seed, config = 1 << args.log2n, "weak", 1, 2
+        what = f"batch=2^{args.log2n} per GPU"
+    elif world > 1 and main_op == "verify":
+        n, scaling, seed, config = (1 << 24) // world, "strong", 3, 4
+        what = f"config 4: batch=2^24 sharded over {world} GPUs ({n} items each), RCCL gather of the verdicts"
+    else:
+        n, scaling, seed, config = 1 << 20, "weak", 1, 2
+        what = "config 2: batch=2^20 per GPU" if main_op == "verify" else "batch=2^20 per GPU"
+    n2 = min(n, 1 << 20) if args.log2n is not None else 1 << 20        # secondary ops: 2^20 per GPU
+
+    w = make_workload(main_op, n, rank * n, device, seed, config)
     torch.cuda.synchronize()
+    elapsed, out, k_ms, phases, full = measure(main_op, w, n, args.steps, args.warmup, world, device)
+    correct = bool(torch.equal(out, w["expect"])) if main_op == "verify" else True
+    correct = all_ranks_agree(correct, world, device)
+    pinned = fixture_check(full, world, n, seed, config) if main_op == "verify" and rank == 0 else None
+    if pinned and pinned["matches_reference_digest"] is False:
+        correct = False
+    # the CPU baseline is timed at N = 1 only (at N > 1 the other ranks' host threads share the cores)
+    base = cpu_baseline(main_op, w, out, min(args.cpu_sample, n)) if world == 1 and rank == 0 else None
+    correct = correct and (base is None or base["gpu_matches_cpu_on_sample"])
+    ms_per_step = elapsed / args.steps * 1e3
+    passes = (n + (1 << 20) - 1) >> 20
+    line = {
+        "metric": {"verify": "ed25519 verifies/sec", "x25519": "x25519 ops/sec", "sign": "ed25519 signs/sec"}[main_op],
+        "value": world * n * args.steps / elapsed, "unit": UNIT[main_op],
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": "u32 (radix-2^25.5 limbs, u64 accumulators)", "data": "synthetic",
+        "config": {"workload": f"{what}, " + ("x25519 variable-base" if main_op == "x25519" else f"ed25519 {main_op}"),
+                   "msg_len": 32 if main_op != "x25519" else None, "items_per_gpu": n, "total_items": world * n,
+                   "parallelism": f"shard{world}+allgather" if world > 1 else "single"},
+        "outputs_correct": correct, "verdicts": pinned,
+        "roofline": roofline_of(main_op, n, k_ms, phases, ms_per_step, passes), "cpu_baseline": base,
+    }
+    del w, out, full
 
-    marks = []                                          # (start, end) events around each kernel-only part
-
-    def step():
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = run_step(op, w)
-        e1.record()
-        marks.append((e0, e1))
-        gather_results(out, world)                      # the final result gather (RCCL over xGMI)
-        return out
-
-    for _ in range(args.warmup):
-        out = step()
-    marks.clear()
-    if op == "verify":
-        ed.set_profiling(True)
-    elapsed, out = timed_region(step, args.steps, world, torch.cuda.synchronize, device)
-    phases = ed.verify_phase_ms() if op == "verify" else None
-    ed.set_profiling(False)
-
-    correct = True
-    if op == "verify":
-        correct = bool(torch.equal(out, w["expect"]))
-    if world > 1:                                       # every rank's shard must be right
-        flag = torch.tensor([int(correct)], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        correct = bool(flag.item())
+    if args.op == "all":                                # the rest of BASELINE's metric, same process, same step count
+        secondary = {}
+        for op in ("x25519", "sign"):
+            w2 = make_workload(op, n2, rank * n2, device)
+            torch.cuda.synchronize()
+            el2, out2, k2, _, _ = measure(op, w2, n2, args.steps, max(1, args.warmup), world, device)
+            base2 = cpu_baseline(op, w2, out2, min(4096, n2)) if world == 1 and rank == 0 else None
+            ok2 = all_ranks_agree(base2 is None or base2["gpu_matches_cpu_on_sample"], world, device)
+            correct = correct and ok2
+            ms2 = el2 / args.steps * 1e3
+            secondary[op] = {"metric": {"x25519": "x25519 ops/sec", "sign": "ed25519 signs/sec"}[op],
+                             "value": world * n2 * args.steps / el2, "unit": UNIT[op], "ms_per_step": ms2,
+                             "items_per_gpu": n2, "scaling": "weak", "outputs_correct": ok2,
+                             "roofline": roofline_of(op, n2, k2, None, ms2, 1), "cpu_baseline": base2}
+            del w2, out2
+        line["secondary"] = secondary
+        line["outputs_correct"] = correct
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = world * n * args.steps / elapsed
-        mul32 = {"verify": MUL32_VERIFY, "x25519": MUL32_X25519, "sign": MUL32_SIGN}[op]
-        if op == "verify":
-            kernel, k_ms, k_mul32 = "k_verify_main", phases[1], MUL32_VERIFY_MAIN
-        else:
-            k_ms = sum(a.elapsed_time(b) for a, b in marks) / len(marks)      # HIP events, launch stream
-            kernel, k_mul32 = {"x25519": "k_x25519_ladder + k_x25519_finish", "sign": "k_sign_point + k_sign_finish"}[op], mul32
-        achieved = n * k_mul32 / (k_ms * 1e-3) / 1e12
-        roofline = {
-            "bound": "valu", "kernel": kernel, "achieved": achieved, "peak": PEAK_TMUL32,
-            "unit": "Tmul32/s", "frac": achieved / PEAK_TMUL32, "traffic": pmc_traffic(kernel),
-            "valu_busy": pmc_valu_busy(kernel),
-            "kernel_ms": k_ms, "canonical_mul32_per_item": k_mul32,
-            "note": "integer-VALU multiply-issue roofline (SURVEY 8d): canonical 32x32->64 products of the "
-                    "reference's radix-2^25.5 schoolbook per item / v_mad_u64_u32 issue peak; the path is not "
-                    "HBM- or MFMA-bound",
-            "hbm": {"achieved": n * BYTES[op] / (ms_per_step * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": n * BYTES[op] / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                    "algorithmic_bytes_per_item": BYTES[op]},
-        }
-        if phases:
-            roofline["phase_ms"] = {"k_verify_prepare": phases[0], "k_verify_main": phases[1], "k_verify_finish": phases[2]}
-        # the CPU baseline is timed at N = 1 only (at N > 1 the other ranks' host threads share the cores)
-        base = cpu_baseline(op, w, out, min(args.cpu_sample, n)) if world == 1 else None
-        correct = correct and (base is None or base["gpu_matches_cpu_on_sample"])
-        line = {
-            "metric": {"verify": "ed25519 verifies/sec", "x25519": "x25519 ops/sec", "sign": "ed25519 signs/sec"}[op],
-            "value": value, "unit": {"verify": "verifies/s", "x25519": "ops/s", "sign": "signs/s"}[op],
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 (radix-2^25.5 limbs, u64 accumulators)", "data": "synthetic",
-            "config": {"workload": f"batch=2^{args.log2n} per GPU, ed25519 {op}" if op != "x25519" else
-                       f"batch=2^{args.log2n} per GPU, x25519 variable-base", "msg_len": 32 if op != "x25519" else None,
-                       "items_per_gpu": n, "parallelism": f"shard{world}+allgather" if world > 1 else "single"},
-            "outputs_correct": correct,
-            "roofline": roofline, "cpu_baseline": base,
-        }
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

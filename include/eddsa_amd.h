@@ -28,9 +28,19 @@
  * reference has no error channel; a loop over it cannot fail).  On error the outputs are
  * unspecified.  Ownership: the caller owns every buffer; the library keeps no pointer after a
  * host-pointer call returns / after the stream work of a device-pointer call completes.
+ * Devices: the library keeps one engine (tables, workspaces, staging pipeline) per HIP device,
+ * created on first use.  A device-pointer call runs on the device that holds its output buffer; a
+ * host-pointer call runs on the default device (eddsa_amd_init; otherwise the calling thread's
+ * current device at the first call); the *_multi calls run on every device of the set bound by
+ * eddsa_amd_init_devices, one contiguous shard each.  Every call makes its device current for its
+ * own duration and restores the caller's before it returns.
  * Threading: calls may be issued from several host threads.  Device-pointer calls on different
- * streams use different workspaces (a pool of four) and overlap on the GPU; calls on one stream are
- * ordered by the stream; host-pointer calls share one staging pipeline and run one after the other.
+ * streams use different workspaces (a pool of four per device) and overlap on the GPU; calls on one
+ * stream are ordered by the stream; host-pointer calls on one device share its staging pipeline
+ * and run one after the other.  eddsa_amd_shutdown waits for calls in flight.
+ * Secrets: the staging copies of secret keys / scalars / shared secrets and the secret scalars that
+ * cross kernel boundaries are zeroed in HBM before a call's stream work completes (the reference
+ * wipes its stack after the same operations, lib/ed25519-sha512.c:77,136, lib/x25519.c:208,221).
  */
 #ifndef EDDSA_AMD_H
 #define EDDSA_AMD_H
@@ -48,12 +58,41 @@
 extern "C" {
 #endif
 
-/* Bind the calling process to HIP device `device` (>= 0), build the base-point tables there
- * (what the reference ships as lib/ed_lookup64.h) and allocate the workspace.  Idempotent.
- * The eddsa.h single-item functions and the *_batch functions call it with the current HIP
- * device if it was never called. */
+/* Make HIP device `device` (>= 0) the default device of the host-pointer entry points and of the
+ * eddsa.h single-item functions, and build its engine: the base-point tables (what the reference
+ * ships as lib/ed_lookup64.h) and the workspace pool.  Idempotent; engines of other devices stay.
+ * Without it the first host-pointer call adopts the calling thread's current HIP device. */
 EDDSA_AMD_DECL int eddsa_amd_init(int device);
+/* Release every engine on every device (waits for calls in flight); the next call builds anew. */
 EDDSA_AMD_DECL void eddsa_amd_shutdown(void);
+
+/* ---- several devices in one process (host thread or stream per device, one result
+ *      gather over RCCL/xGMI; the loop being sharded is ed25519_verify, lib/ed25519-sha512.c:148-181) ----
+ * Bind the device set of the *_multi entry points: an engine on each device of `devices` (n entries,
+ * no duplicates; NULL / 0 = every visible device) and, for the device-pointer form's result gather,
+ * one RCCL communicator per device (ncclCommInitAll; librccl.so.1 is loaded here, not at link time).
+ * Device d of the set owns items [lo, hi) = eddsa_amd_shard_bounds(n, d, count): contiguous,
+ * balanced (shards differ by at most one item). */
+EDDSA_AMD_DECL int eddsa_amd_init_devices(const int *devices, int n);
+EDDSA_AMD_DECL int eddsa_amd_device_count(void);
+EDDSA_AMD_DECL void eddsa_amd_shard_bounds(size_t n, int rank, int world, size_t *lo, size_t *hi);
+/* host pointers, whole batch in host memory: one host thread per device runs that device's streaming
+ * pipeline on its shard and copies the results straight into the caller's buffer (no collective) */
+EDDSA_AMD_DECL int ed25519_verify_batch_multi(uint8_t *ok, const uint8_t *sigs, const uint8_t *pubs,
+                                              const uint8_t *msgs, const uint64_t *msg_off,
+                                              size_t msg_len, size_t n);
+EDDSA_AMD_DECL int ed25519_sign_batch_multi(uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs,
+                                            const uint8_t *msgs, const uint64_t *msg_off,
+                                            size_t msg_len, size_t n);
+EDDSA_AMD_DECL int x25519_batch_multi(uint8_t *out, const uint8_t *scalars, const uint8_t *points, size_t n);
+/* device pointers: sigs[d] / pubs[d] / msgs[d] (fixed msg_len) hold shard d in device d's HBM,
+ * ok_full[d] is a buffer of n_total bytes there, streams[d] a stream of device d (NULL entries =
+ * default stream).  Shard d is verified on device d into its slice of ok_full[d]; then ONE RCCL
+ * all-gather (grouped broadcasts when the shards differ in length) leaves the whole verdict vector
+ * in every ok_full[d].  Enqueues and returns; the streams order the work. */
+EDDSA_AMD_DECL int ed25519_verify_batch_multi_dev(uint8_t *const ok_full[], const uint8_t *const sigs[],
+                                                  const uint8_t *const pubs[], const uint8_t *const msgs[],
+                                                  size_t msg_len, size_t n_total, void *const streams[]);
 /* human-readable text for a negative return value */
 EDDSA_AMD_DECL const char *eddsa_amd_strerror(int err);
 /* copy the device's generated tables out for inspection: base16 = 32769 entries k*B; comb = 416
@@ -76,6 +115,12 @@ EDDSA_AMD_DECL void eddsa_amd_set_offcurve_mode(int exact);
  * the average duration of each kernel (prepare, main, finish) in milliseconds. */
 EDDSA_AMD_DECL void eddsa_amd_set_profiling(int on);
 EDDSA_AMD_DECL int eddsa_amd_verify_phase_ms(float out[3]);
+/* diagnostic for the secret-hygiene tests: waits for the default device to go idle and counts the
+ * non-zero bytes left in out[0] the scalar workspace (sign's secret scalars a, r between its two
+ * kernels), out[1] the point workspace (x25519's (x2 : z2); public for the other operations),
+ * out[2] the host pipeline's first input staging buffers (secret keys / scalars), out[3] its output
+ * staging buffer. */
+EDDSA_AMD_DECL int eddsa_amd_secret_residue(uint64_t out[4]);
 
 /* ---- host-pointer entry points ---- */
 EDDSA_AMD_DECL int ed25519_verify_batch(uint8_t *ok, const uint8_t *sigs, const uint8_t *pubs,

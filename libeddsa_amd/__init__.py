@@ -16,6 +16,13 @@ from .api import (  # noqa: F401
     ed25519_sign_batch,
     ed25519_verify,
     ed25519_verify_batch,
+    ed25519_verify_batch_multi,
+    ed25519_verify_batch_multi_dev,
+    ed25519_sign_batch_multi,
+    x25519_batch_multi,
+    init_devices,
+    device_count,
+    secret_residue,
     ed25519_verify_records,
     eddsa_genpub,
     eddsa_pk_eddsa_to_dh,

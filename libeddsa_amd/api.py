@@ -85,6 +85,29 @@ def set_profiling(on):
     library().eddsa_amd_set_profiling(int(bool(on)))
 
 
+def secret_residue():
+    """(aux, acc, staging-in, staging-out): non-zero bytes left in the engine's secret-bearing HBM
+    buffers on the default device (diagnostic for the hygiene tests; waits for the device)."""
+    out = (ctypes.c_uint64 * 4)()
+    _check(library().eddsa_amd_secret_residue(out), "eddsa_amd_secret_residue")
+    return tuple(int(x) for x in out)
+
+
+def init_devices(devices=None):
+    """Bind the device set of the *_multi entry points (default: every visible device): one engine and
+    one RCCL communicator per device, single process."""
+    if devices is None:
+        _check(library().eddsa_amd_init_devices(None, 0), "eddsa_amd_init_devices")
+    else:
+        arr = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        _check(library().eddsa_amd_init_devices(arr, len(devices)), "eddsa_amd_init_devices")
+    return int(library().eddsa_amd_device_count())
+
+
+def device_count():
+    return int(library().eddsa_amd_device_count())
+
+
 # ---------------------------------------------------------------------------------------------
 # argument plumbing
 # ---------------------------------------------------------------------------------------------
@@ -114,6 +137,16 @@ def _torch_check(t, width, name):
     if width and t.numel() % width:
         raise ValueError(f"{name}: size {t.numel()} is not a multiple of {width}")
     return t
+
+
+def _torch_off_check(off, n):
+    """ragged-message offsets on the device: n+1 64-bit words (the kernels read them as uint64)"""
+    import torch
+    if off is None:
+        return
+    if not _is_torch(off) or not off.is_cuda or not off.is_contiguous() or \
+            off.dtype not in (torch.int64, torch.uint64) or off.numel() != n + 1:
+        raise ValueError("msg_off: expected n+1 contiguous int64/uint64 offsets on the device")
 
 
 def _stream():
@@ -210,8 +243,7 @@ def ed25519_verify_batch(sigs, pubs, msgs, msg_off=None, msg_len=None):
         if pubs.numel() // 32 != n:
             raise ValueError("ed25519_verify_batch: sigs and pubs disagree on the batch size")
         _, off, mlen = _msg_args(msgs, msg_off, msg_len, n, True)
-        if off is not None and (off.dtype != torch.int64 and off.dtype != torch.uint64 or off.numel() != n + 1):
-            raise ValueError("msg_off: expected n+1 int64/uint64 offsets on the device")
+        _torch_off_check(off, n)
         ok = torch.empty((n,), dtype=torch.uint8, device=sigs.device)
         _check(lib.ed25519_verify_batch_dev(_c_ptr(ok.data_ptr()), _c_ptr(sigs.data_ptr()), _c_ptr(pubs.data_ptr()),
                                             _c_ptr(msgs.data_ptr()), _c_ptr(off.data_ptr()) if off is not None else None,
@@ -269,6 +301,7 @@ def ed25519_sign_batch(secs, pubs, msgs, msg_off=None, msg_len=None):
         if pubs.numel() // 32 != n:
             raise ValueError("ed25519_sign_batch: secs and pubs disagree on the batch size")
         _, off, mlen = _msg_args(msgs, msg_off, msg_len, n, True)
+        _torch_off_check(off, n)
         sig = torch.empty((n, 64), dtype=torch.uint8, device=secs.device)
         _check(lib.ed25519_sign_batch_dev(_c_ptr(sig.data_ptr()), _c_ptr(secs.data_ptr()), _c_ptr(pubs.data_ptr()),
                                           _c_ptr(msgs.data_ptr()), _c_ptr(off.data_ptr()) if off is not None else None,
@@ -288,6 +321,78 @@ def ed25519_sign_batch(secs, pubs, msgs, msg_off=None, msg_len=None):
                                   _np_ptr(off) if off is not None else None, _c_size(mlen), _c_size(n)),
            "ed25519_sign_batch")
     return sig
+
+
+# ---------------------------------------------------------------------------------------------
+# several devices in one process (include/eddsa_amd.h: *_multi), after init_devices()
+# ---------------------------------------------------------------------------------------------
+
+def _host_msgs(msgs, msg_off, msg_len, n):
+    msgs = _as_np(msgs, 0, "msgs")
+    _, off, mlen = _msg_args(msgs, msg_off, msg_len, n, False)
+    if off is not None:
+        off = np.ascontiguousarray(np.asarray(off, dtype=np.uint64))
+        if off.size != n + 1 or (n and int(off[-1]) > msgs.size):
+            raise ValueError("msg_off: expected n+1 offsets within msgs")
+    return msgs, off, mlen
+
+
+def ed25519_verify_batch_multi(sigs, pubs, msgs, msg_off=None, msg_len=None):
+    """ed25519_verify_batch over the device set: contiguous shards, one host thread per device"""
+    sigs = _as_np(sigs, 64, "sigs"); pubs = _as_np(pubs, 32, "pubs")
+    n = sigs.size // 64
+    if pubs.size // 32 != n:
+        raise ValueError("ed25519_verify_batch_multi: sigs and pubs disagree on the batch size")
+    msgs, off, mlen = _host_msgs(msgs, msg_off, msg_len, n)
+    ok = np.zeros((n,), dtype=np.uint8)
+    _check(library().ed25519_verify_batch_multi(_np_ptr(ok), _np_ptr(sigs), _np_ptr(pubs), _np_ptr(msgs),
+                                                _np_ptr(off) if off is not None else None, _c_size(mlen), _c_size(n)),
+           "ed25519_verify_batch_multi")
+    return ok
+
+
+def ed25519_sign_batch_multi(secs, pubs, msgs, msg_off=None, msg_len=None):
+    secs = _as_np(secs, 32, "secs"); pubs = _as_np(pubs, 32, "pubs")
+    n = secs.size // 32
+    if pubs.size // 32 != n:
+        raise ValueError("ed25519_sign_batch_multi: secs and pubs disagree on the batch size")
+    msgs, off, mlen = _host_msgs(msgs, msg_off, msg_len, n)
+    sig = np.zeros((n, 64), dtype=np.uint8)
+    _check(library().ed25519_sign_batch_multi(_np_ptr(sig), _np_ptr(secs), _np_ptr(pubs), _np_ptr(msgs),
+                                              _np_ptr(off) if off is not None else None, _c_size(mlen), _c_size(n)),
+           "ed25519_sign_batch_multi")
+    return sig
+
+
+def x25519_batch_multi(scalars, points):
+    scalars = _as_np(scalars, 32, "scalars"); points = _as_np(points, 32, "points")
+    n = scalars.size // 32
+    if points.size // 32 != n:
+        raise ValueError("x25519_batch_multi: scalars and points disagree on the batch size")
+    out = np.zeros((n, 32), dtype=np.uint8)
+    _check(library().x25519_batch_multi(_np_ptr(out), _np_ptr(scalars), _np_ptr(points), _c_size(n)), "x25519_batch_multi")
+    return out
+
+
+def ed25519_verify_batch_multi_dev(sigs, pubs, msgs, msg_len, n_total):
+    """sigs[d], pubs[d], msgs[d]: CUDA tensors holding shard d (shard_bounds(n_total, d, G)) on device d
+    of the set.  Returns one (n_total,) uint8 tensor per device, each holding the WHOLE verdict vector
+    after the RCCL all-gather; work is enqueued on each device's current torch stream."""
+    import torch
+    g = device_count()
+    if not (len(sigs) == len(pubs) == len(msgs) == g):
+        raise ValueError(f"expected one shard per device of the set ({g})")
+    outs, streams = [], []
+    for d in range(g):
+        _torch_check(sigs[d], 64, "sigs"); _torch_check(pubs[d], 32, "pubs"); _torch_check(msgs[d], 0, "msgs")
+        outs.append(torch.empty((n_total,), dtype=torch.uint8, device=sigs[d].device))
+        streams.append(torch.cuda.current_stream(sigs[d].device).cuda_stream)
+    P = ctypes.c_void_p * g
+    _check(library().ed25519_verify_batch_multi_dev(P(*[o.data_ptr() for o in outs]), P(*[t.data_ptr() for t in sigs]),
+                                                    P(*[t.data_ptr() for t in pubs]), P(*[t.data_ptr() for t in msgs]),
+                                                    _c_size(msg_len), _c_size(n_total), P(*streams)),
+           "ed25519_verify_batch_multi_dev")
+    return outs
 
 
 # ---------------------------------------------------------------------------------------------

@@ -65,6 +65,16 @@ typedef struct edk_fixed_ws {
   uint32_t* aux;      /* capacity * 16 words: sign's secret scalars a, r between its two kernels (zeroed after use) */
 } edk_fixed_ws;
 
+/* workspace of the batch (random-linear-combination) verification for up to `capacity` items: one
+ * allocation, carved up by rlc.hip */
+typedef struct edk_rlc_ws {
+  size_t capacity;
+  void* base;
+} edk_rlc_ws;
+size_t edk_rlc_ws_bytes(size_t capacity);
+hipError_t edk_verify_rlc(uint8_t* ok, uint32_t* stats, const edk_verify_src* src, size_t n, const uint32_t* base16,
+                          const edk_verify_ws* ws, const edk_rlc_ws* rws, hipStream_t stream);
+
 hipError_t edk_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* points, size_t n,
                       const edk_fixed_ws* ws, hipStream_t stream);
 hipError_t edk_genpub(uint8_t* pubs, const uint8_t* secs, size_t n, const uint32_t* comb,

@@ -89,6 +89,7 @@ k_x25519_ladder(uint32_t* accout, const uint8_t* scalars, const uint8_t* points,
   load32(pt, points, item, 32);
   fe x2, z2;
   x25519_ladder_lane(x2, z2, s, pt);
+  if (i >= n) return;                            // an idle lane must not leave a copy of the last item's secret
   uint32_t* o = accout + (size_t)blockIdx.x * (30 * BLOCK) + threadIdx.x;
 #pragma unroll
   for (int j = 0; j < 10; j++) { o[j * BLOCK] = x2.v[j]; o[(20 + j) * BLOCK] = z2.v[j]; }
@@ -429,9 +430,14 @@ struct x25519_finish_policy {
   }
   ED_DEV void item(int k) const {
     const finish_pos p = finish_at(k, acc);
-    if (p.i >= n) return;
     fe x, zinv;
-    acc_load(x, p.acc, 0); acc_load(zinv, p.acc, 2);
+    if (p.i < n) { acc_load(x, p.acc, 0); acc_load(zinv, p.acc, 2); }
+    // (x2 : z2) and 1/z2 determine the shared secret: they do not outlive the call in HBM
+    // (x25519.c:221 burnstack); slots past the end hold the committed 1
+    uint32_t* o = acc + p.tile * (30 * BLOCK) + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 10; j++) { o[j * BLOCK] = 0; o[(20 + j) * BLOCK] = 0; }
+    if (p.i >= n) return;
     uint32_t w[8];
     x25519_finish_lane(w, x, zinv);
     store32(out, p.i, 32, w);
@@ -502,6 +508,7 @@ k_sign_point(uint32_t* accout, uint32_t* aux, const uint8_t* secs, const uint8_t
   ge R;
   sign_point_lane(R, aw, rw, sk, m, mlen, lds_comb);
   acc_store(accout, i, R);
+  if (i >= n) return;                            // an idle lane must not leave a copy of the last item's secrets
   uint4* d = reinterpret_cast<uint4*>(aux + 16 * i);     // the secret scalars a and r, for the finish step
   d[0] = make_uint4(aw[0], aw[1], aw[2], aw[3]); d[1] = make_uint4(aw[4], aw[5], aw[6], aw[7]);
   d[2] = make_uint4(rw[0], rw[1], rw[2], rw[3]); d[3] = make_uint4(rw[4], rw[5], rw[6], rw[7]);

@@ -111,7 +111,7 @@ def test_workload_is_deterministic_and_shardable():
     assert np.array_equal(a[500:800], a2) and np.array_equal(b[500:800], b2)
     assert a[0, :4].tolist() == [23, 167, 82, 220]                 # pinned first bytes of the stream
     sig = np.zeros((64, 64), np.uint8); pub = np.zeros((64, 32), np.uint8); msg = np.zeros((64, 32), np.uint8)
-    exp = workload.corrupt_for_verify(sig, pub, msg)
+    exp = workload.corrupt_for_verify(sig, pub, msg, edges=False)   # (the edge splice: see the test further down)
     assert exp.sum() == 60 and [i for i in range(64) if not exp[i]] == [5, 21, 37, 53]
     flipped = [int(np.count_nonzero(x)) for x in (sig[:, :32], sig[:, 32:], pub, msg)]
     assert flipped == [1, 1, 1, 1]                                  # R, S, A, msg round-robin
@@ -216,3 +216,68 @@ def test_bench_helpers_without_gpu(tmp_path, monkeypatch):
     t = bench.pmc_traffic("k_a + k_b")
     assert t["bytes"] == (2 * 1024.0 + 16.0) * 1024.0 and t["fetch_size_kb_raw"] == 1024.0
     assert bench.pmc_traffic("k_missing") is None
+
+
+def test_c_shard_bounds_match_the_python_sharder():
+    """eddsa_amd_shard_bounds (the C multi-device entry points) and libeddsa_amd.shard_bounds (the
+    one-process-per-GPU path) cut a batch identically: contiguous, balanced, covering"""
+    import libeddsa_amd as ed
+    lib = ctypes.CDLL(_lib_path())
+    lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+    for n in (0, 1, 7, 8, 1003, 1 << 24, (1 << 24) + 5):
+        for world in (1, 2, 3, 8):
+            end = 0
+            for r in range(world):
+                lib.eddsa_amd_shard_bounds(ctypes.c_size_t(n), r, world, ctypes.byref(lo), ctypes.byref(hi))
+                assert (lo.value, hi.value) == ed.shard_bounds(n, r, world) and lo.value == end
+                end = hi.value
+            assert end == n
+    assert ed.shard_bounds(1 << 24, 3, 8) == (3 << 21, 4 << 21)              # config 4: 2^21 per GPU
+
+
+def test_multi_device_calls_need_a_bound_device_set():
+    import libeddsa_amd as ed
+    assert ed.device_count() == 0
+    with pytest.raises(ed.EddsaAmdError):
+        ed.ed25519_verify_batch_multi(np.zeros((2, 64), np.uint8), np.zeros((2, 32), np.uint8), np.zeros((2, 8), np.uint8))
+
+
+def test_bench_spawns_ranks_and_checks_the_launcher(tmp_path):
+    """`python bench.py --gpus 2` with no launcher environment starts two ranks as a CHILD process (here
+    both stop at the missing GPU, loudly); a launcher whose world size differs from --gpus is refused"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by tests/test_gpu_multi.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and r.stderr.count("needs an MI355X") >= 2, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "--gpus 4 but the launcher started 2" in r.stderr
+
+
+def test_workload_edge_vectors_against_the_oracle(oracle):
+    """tools/workload.py: the spliced edge vectors sit where documented, never on a corrupted item, and the
+    expected verdicts (derived from the reference's semantics) are the oracle's on two full blocks"""
+    import workload
+    n = 2 * workload.EDGE_BLOCK
+    sk, msg = workload.sign_inputs(n, seed=1, config=2)
+    pk = oracle.genpub_batch(sk)
+    sig = oracle.sign_batch(sk, pk, msg, 32)
+    plain = workload.corrupt_for_verify(sig.copy(), pk.copy(), msg.copy(), edges=False)
+    s2, p2, m2 = sig.copy(), pk.copy(), msg.copy()
+    expect = workload.corrupt_for_verify(s2, p2, m2)
+    pos = [workload.edge_position(m, e) for m in range(2) for e in range(workload.EDGE_KINDS)]
+    assert all(p % 16 == 9 for p in pos) and len(set(pos)) == 128 and max(pos) < n
+    assert np.array_equal(oracle.verify_batch(s2, p2, m2, 32), expect)
+    untouched = np.ones(n, bool); untouched[pos] = False
+    assert np.array_equal(expect[untouched], plain[untouched])
+    first = [int(expect[workload.edge_position(0, e)]) for e in range(12)]
+    assert first == [1, 1, 1, 1, 0, 0, 0, 0, 1, 0, 1, 1]        # S + k l accepted; S = 0, l, 2^256-1 not; identity cases
+    # a shard that starts in the middle of the stream sees the same bytes
+    lo = workload.EDGE_BLOCK - 100
+    sk3, msg3 = workload.sign_inputs(300, seed=1, config=2, first=lo)
+    pk3 = oracle.genpub_batch(sk3); sig3 = oracle.sign_batch(sk3, pk3, msg3, 32)
+    e3 = workload.corrupt_for_verify(sig3, pk3, msg3, first=lo)
+    assert np.array_equal(sig3, s2[lo:lo + 300]) and np.array_equal(pk3, p2[lo:lo + 300]) and np.array_equal(e3, expect[lo:lo + 300])

@@ -296,6 +296,27 @@ def gen_table_digest():
 
 
 # ---------------------------------------------------------------- 6. full-size batch digests
+def verify_digest(n, seed, config):
+    """the config-2 / config-4 verify batch (seeded keys and 32-byte messages, 1/16 corrupted, the
+    8c-3 edge vectors spliced at fixed indices) through the compiled reference: digests of inputs and verdicts"""
+    sk, msg = workload.sign_inputs(n, seed=seed, config=config)
+    pk = np.zeros((n, 32), np.uint8)
+    sig = np.zeros((n, 64), np.uint8)
+    drv.refdrv_genpub_batch(PTR(pk), PTR(sk), ctypes.c_size_t(n), CORES)
+    drv.refdrv_sign_batch(PTR(sig), PTR(sk), PTR(pk), PTR(msg), ctypes.c_size_t(32), ctypes.c_size_t(n), CORES)
+    expect = workload.corrupt_for_verify(sig, pk, msg, seed=seed, config=config)
+    ok = np.zeros(n, np.uint8)
+    drv.refdrv_verify_batch(PTR(ok), PTR(sig), PTR(pk), PTR(msg), ctypes.c_size_t(32), ctypes.c_size_t(n), CORES)
+    assert np.array_equal(ok, expect), "reference verdicts differ from the construction"
+    h = hashlib.sha512()
+    for a in (sig, pk, msg):
+        h.update(a.tobytes())
+    # per-shard digests of the verdict vector, for the sharded runs (config 4: 8 shards of 2^21)
+    shards = [hashlib.sha512(ok[k * (n // 8):(k + 1) * (n // 8)].tobytes()).hexdigest() for k in range(8)]
+    return {"inputs_sha512": h.hexdigest(), "verdicts_sha512": hashlib.sha512(ok.tobytes()).hexdigest(),
+            "accepted": int(ok.sum()), "seed": seed, "config": config, "shard8_verdicts_sha512": shards}
+
+
 def gen_batch_digests():
     out = {}
     for log2n in (14, 20):
@@ -311,22 +332,18 @@ def gen_batch_digests():
         drv.refdrv_sign_batch(PTR(sig), PTR(sk), PTR(pk), PTR(msg), ctypes.c_size_t(32), ctypes.c_size_t(n), CORES)
         out[f"genpub_2^{log2n}"] = hashlib.sha512(pk.tobytes()).hexdigest()
         out[f"sign_2^{log2n}"] = hashlib.sha512(sig.tobytes()).hexdigest()
-        # verify workload (config 2): keys/messages from stream (seed 1, config 2)
-        sk, msg = workload.sign_inputs(n, seed=1, config=2)
-        drv.refdrv_genpub_batch(PTR(pk), PTR(sk), ctypes.c_size_t(n), CORES)
-        drv.refdrv_sign_batch(PTR(sig), PTR(sk), PTR(pk), PTR(msg), ctypes.c_size_t(32), ctypes.c_size_t(n), CORES)
-        expect = workload.corrupt_for_verify(sig, pk, msg)
-        ok = np.zeros(n, np.uint8)
-        drv.refdrv_verify_batch(PTR(ok), PTR(sig), PTR(pk), PTR(msg), ctypes.c_size_t(32), ctypes.c_size_t(n), CORES)
-        assert np.array_equal(ok, expect), "reference verdicts differ from the construction"
-        out[f"verify_2^{log2n}"] = {"inputs_sha512": hashlib.sha512(sig.tobytes() + pk.tobytes() + msg.tobytes()).hexdigest(),
-                                    "verdicts_sha512": hashlib.sha512(ok.tobytes()).hexdigest(), "accepted": int(ok.sum())}
+        out[f"verify_2^{log2n}"] = verify_digest(n, 1, 2)          # config 2
         print(f"batch digests for n=2^{log2n} done")
+    out["verify_2^24"] = verify_digest(1 << 24, 3, 4)             # config 4 (about 4 minutes on 8 cores)
+    print("batch digest for config 4 (n=2^24, seed 3) done")
     json.dump(out, open(os.path.join(GOLD, "batch_digests.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if sys.argv[1:] == ["digests"]:
+        gen_batch_digests()
+        sys.exit(0)
     gen_x25519_table()
     gen_ed25519_table()
     gen_verify_edges()
