@@ -144,7 +144,7 @@ static void ws_release(struct vslot *v)
 
 static void fws_release(struct vslot *v)
 {
-    wipe_free(v->fws.acc, v->fws.capacity * 30 * sizeof(uint32_t));
+    wipe_free(v->fws.acc, v->fws.capacity * ACC_WORDS * sizeof(uint32_t));
     wipe_free(v->fws.aux, v->fws.capacity * 16 * sizeof(uint32_t));
     memset(&v->fws, 0, sizeof(v->fws));
 }
@@ -169,9 +169,9 @@ static int fws_reserve(struct vslot *v, size_t items)
     if (cap <= v->fws.capacity) return 0;
     TRY(hipEventSynchronize(v->free));
     fws_release(v);
-    TRY(hipMalloc((void **)&v->fws.acc, cap * 30 * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&v->fws.acc, cap * ACC_WORDS * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&v->fws.aux, cap * 16 * sizeof(uint32_t)));
-    TRY(hipMemset(v->fws.acc, 0, cap * 30 * sizeof(uint32_t)));    /* recycled memory: start clean */
+    TRY(hipMemset(v->fws.acc, 0, cap * ACC_WORDS * sizeof(uint32_t)));    /* recycled memory: start clean */
     TRY(hipMemset(v->fws.aux, 0, cap * 16 * sizeof(uint32_t)));
     v->fws.capacity = cap;
 out:
@@ -190,7 +190,7 @@ static int ws_reserve(struct vslot *v, size_t items)
     ws_release(v);
     TRY(hipMalloc((void **)&v->ws.digits, cap * 16 * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&v->ws.table, cap / VERIFY_TILE * (size_t)VERIFY_TABLE_WORDS_PER_TILE * sizeof(uint32_t)));
-    TRY(hipMalloc((void **)&v->ws.acc, cap * 30 * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&v->ws.acc, cap * ACC_WORDS * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&v->ws.flags, cap));
     TRY(hipMalloc((void **)&v->ws.offlist, cap * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&v->ws.offcount, 256));
@@ -1259,7 +1259,7 @@ int eddsa_amd_secret_residue(uint64_t out[4])
     for (int i = 0; i < VERIFY_SLOTS && !rc; i++) {
         const struct vslot *v = &c.e->vs[i];
         rc = count_nonzero(v->fws.aux, v->fws.capacity * 16 * sizeof(uint32_t), &out[0]);
-        if (!rc) rc = count_nonzero(v->fws.acc, v->fws.capacity * 30 * sizeof(uint32_t), &out[1]);
+        if (!rc) rc = count_nonzero(v->fws.acc, v->fws.capacity * ACC_WORDS * sizeof(uint32_t), &out[1]);
     }
     for (int s = 0; s < 2 && !rc; s++) rc = count_nonzero(c.e->pipe.d_in[s][0], c.e->pipe.in_cap[s][0], &out[2]);
     if (!rc) rc = count_nonzero(c.e->pipe.d_out, c.e->pipe.out_cap, &out[3]);

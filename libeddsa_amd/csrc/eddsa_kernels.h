@@ -21,6 +21,7 @@
 #endif
 #define VERIFY_TABLE_WORDS_PER_TILE (VERIFY_TABLE_ENTRIES * 40 * 256)
 #define VERIFY_TILE 256            /* items per tile = threads per block */
+#define ACC_WORDS 40               /* point workspace per item: X, Y, Z and one slot for the finish kernels' prefix products */
 
 #ifdef __cplusplus
 extern "C" {
@@ -35,7 +36,7 @@ typedef struct edk_verify_ws {
   size_t capacity;
   uint32_t* digits;   /* capacity * 16 words */
   uint32_t* table;    /* capacity / 256 tiles * VERIFY_TABLE_WORDS_PER_TILE words */
-  uint32_t* acc;      /* capacity * 30 words */
+  uint32_t* acc;      /* capacity * ACC_WORDS words */
   uint8_t* flags;     /* capacity bytes */
   uint32_t* offlist;  /* capacity words: items whose key is off the curve */
   uint32_t* offcount; /* 1 word */
@@ -61,7 +62,7 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* src, size_t n, const ui
 /* workspace of the fixed-base operations for up to `capacity` items (a multiple of VERIFY_TILE) */
 typedef struct edk_fixed_ws {
   size_t capacity;
-  uint32_t* acc;      /* capacity * 30 words: projective result, lane-interleaved per tile */
+  uint32_t* acc;      /* capacity * ACC_WORDS words: projective result, lane-interleaved per tile */
   uint32_t* aux;      /* capacity * 16 words: sign's secret scalars a, r between its two kernels (zeroed after use) */
 } edk_fixed_ws;
 

@@ -90,7 +90,7 @@ k_x25519_ladder(uint32_t* accout, const uint8_t* scalars, const uint8_t* points,
   fe x2, z2;
   x25519_ladder_lane(x2, z2, s, pt);
   if (i >= n) return;                            // an idle lane must not leave a copy of the last item's secret
-  uint32_t* o = accout + (size_t)blockIdx.x * (30 * BLOCK) + threadIdx.x;
+  uint32_t* o = accout + (size_t)blockIdx.x * (ACC_WORDS * BLOCK) + threadIdx.x;
 #pragma unroll
   for (int j = 0; j < 10; j++) { o[j * BLOCK] = x2.v[j]; o[(20 + j) * BLOCK] = z2.v[j]; }
 }
@@ -136,12 +136,17 @@ k_verify_prepare(edk_verify_src src, size_t n, uint32_t* digits,
   const size_t item = i < n ? i : n - 1;         // idle lanes redo the last item into their own slot
   uint32_t rw[8], aw[8], sw[8], tw[8];
   const uint8_t* m; size_t mlen;
-  verify_item(rw, sw, aw, m, mlen, src, item);
-  const bool oncurve = verify_prepare_lane(tw, sw, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
-                                           rw, aw, m, mlen);
+  load32(rw, src.sigs, item, src.sig_stride);
+  load32(aw, src.pubs, item, src.pub_stride);
+  if (src.msg_off) { m = src.msgs + src.msg_off[item]; mlen = (size_t)(src.msg_off[item + 1] - src.msg_off[item]); }
+  else { m = src.msgs + item * src.msg_stride; mlen = src.msg_len; }
   uint4* d = reinterpret_cast<uint4*>(digits + 16 * i);
+  verify_hash_lane(tw, rw, aw, m, mlen);
   d[0] = make_uint4(tw[0], tw[1], tw[2], tw[3]); d[1] = make_uint4(tw[4], tw[5], tw[6], tw[7]);
+  load32(sw, src.sigs + 32, item, src.sig_stride);       // S is fetched only now: nothing to hold across the hash
+  verify_s_lane(sw);
   d[2] = make_uint4(sw[0], sw[1], sw[2], sw[3]); d[3] = make_uint4(sw[4], sw[5], sw[6], sw[7]);
+  const bool oncurve = verify_table_lane(table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), aw);
   // keys that are not curve points go to the exact (reference-order) kernels: append to their work
   // list (all_exact, a self-check mode: every item does, and the windowed result is not used)
   const bool windowed = oncurve && !all_exact;
@@ -261,7 +266,7 @@ k_verify_main(const uint32_t* digits, const uint32_t* table, const uint32_t* bas
   const size_t i = tile * BLOCK + threadIdx.x;   // < workspace capacity
   ge acc;
   verify_main_lane(acc, digits + 16 * i, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16);
-  uint32_t* o = accout + tile * (30 * BLOCK) + threadIdx.x;
+  uint32_t* o = accout + tile * (ACC_WORDS * BLOCK) + threadIdx.x;
 #pragma unroll
   for (int j = 0; j < 10; j++) {
     o[j * BLOCK] = acc.X.v[j]; o[(10 + j) * BLOCK] = acc.Y.v[j]; o[(20 + j) * BLOCK] = acc.Z.v[j];
@@ -287,7 +292,7 @@ ED_DEV finish_pos finish_at(int k, const uint32_t* accin) {
   finish_pos p;
   p.tile = (size_t)blockIdx.x * FINISH_K + k;
   p.i = p.tile * BLOCK + threadIdx.x;
-  p.acc = accin + p.tile * (30 * BLOCK) + threadIdx.x;
+  p.acc = accin + p.tile * (ACC_WORDS * BLOCK) + threadIdx.x;
   return p;
 }
 ED_DEV void acc_load(fe& f, const uint32_t* acc, int coord) {
@@ -296,50 +301,51 @@ ED_DEV void acc_load(fe& f, const uint32_t* acc, int coord) {
 }
 // i = the lane's global item slot (tile i / BLOCK, lane i % BLOCK), whatever the block size
 ED_DEV void acc_store(uint32_t* accout, size_t i, const ge& p) {
-  uint32_t* o = accout + (i / BLOCK) * (30 * BLOCK) + (i % BLOCK);
+  uint32_t* o = accout + (i / BLOCK) * (ACC_WORDS * BLOCK) + (i % BLOCK);
 #pragma unroll
   for (int j = 0; j < 10; j++) {
     o[j * BLOCK] = p.X.v[j]; o[(10 + j) * BLOCK] = p.Y.v[j]; o[(20 + j) * BLOCK] = p.Z.v[j];
   }
 }
 
-// Phase A (straight-line: an fe[8] array indexed in a loop would end up in scratch) multiplies the
-// eight denominators together, inverts once and unwinds; each denominator is written to its Z slot
-// by den() and re-read during the unwinding (keeping all eight in registers next to the seven
-// prefix products and the inversion's temporaries does not fit 256 VGPRs), then replaced by its
-// inverse.  Phase B is an ordinary loop over the items, so the (large) per-item code exists once.
-// slot k's Z in the workspace is overwritten first by the committed denominator, then by its
-// inverse (the same lane writes and later reads it)
-ED_DEV void zinv_store(uint32_t* acc, int k, const fe& zi) {
-  uint32_t* o = acc + ((size_t)blockIdx.x * FINISH_K + k) * (30 * BLOCK) + threadIdx.x;
+// Phase A multiplies the eight denominators together, inverts once and unwinds.  Each denominator is
+// written to its Z slot by den(), each prefix product z0 ... zk to the fourth slot (W) of item k, and
+// both are re-read during the unwinding: with the eight prefix products in registers beside the
+// inversion's temporaries every finish kernel needed more than 256 VGPRs and spilled 660 bytes per
+// lane.  The same lane writes and later reads these slots.  Phase B is an ordinary loop over the
+// items, so the (large) per-item code exists once.
+ED_DEV void slot_store(uint32_t* acc, int k, int coord, const fe& f) {
+  uint32_t* o = acc + ((size_t)blockIdx.x * FINISH_K + k) * (ACC_WORDS * BLOCK) + threadIdx.x;
 #pragma unroll
-  for (int j = 0; j < 10; j++) o[(20 + j) * BLOCK] = zi.v[j];
+  for (int j = 0; j < 10; j++) o[(10 * coord + j) * BLOCK] = f.v[j];
 }
-ED_DEV void den_reload(fe& z, const uint32_t* acc, int k) {
-  const uint32_t* o = acc + ((size_t)blockIdx.x * FINISH_K + k) * (30 * BLOCK) + threadIdx.x;
+ED_DEV void slot_load(fe& f, const uint32_t* acc, int k, int coord) {
+  const uint32_t* o = acc + ((size_t)blockIdx.x * FINISH_K + k) * (ACC_WORDS * BLOCK) + threadIdx.x;
 #pragma unroll
-  for (int j = 0; j < 10; j++) z.v[j] = o[(20 + j) * BLOCK];
+  for (int j = 0; j < 10; j++) f.v[j] = o[(10 * coord + j) * BLOCK];
 }
+ED_DEV void zinv_store(uint32_t* acc, int k, const fe& zi) { slot_store(acc, k, 2, zi); }
 
 template <class P>
 ED_DEV void finish_batch8(const P& pol, uint32_t* acc) {
-  fe z, p0, p1, p2, p3, p4, p5, p6, p7, u, zi;
-  pol.den(0, p0);
-  pol.den(1, z); fe_mul(p1, p0, z);
-  pol.den(2, z); fe_mul(p2, p1, z);
-  pol.den(3, z); fe_mul(p3, p2, z);
-  pol.den(4, z); fe_mul(p4, p3, z);
-  pol.den(5, z); fe_mul(p5, p4, z);
-  pol.den(6, z); fe_mul(p6, p5, z);
-  pol.den(7, z); fe_mul(p7, p6, z);
-  fe_inv(u, p7);                                 // u = 1 / (z0 ... z7)
-  fe_mul(zi, u, p6); den_reload(z, acc, 7); fe_mul(u, u, z); zinv_store(acc, 7, zi);
-  fe_mul(zi, u, p5); den_reload(z, acc, 6); fe_mul(u, u, z); zinv_store(acc, 6, zi);
-  fe_mul(zi, u, p4); den_reload(z, acc, 5); fe_mul(u, u, z); zinv_store(acc, 5, zi);
-  fe_mul(zi, u, p3); den_reload(z, acc, 4); fe_mul(u, u, z); zinv_store(acc, 4, zi);
-  fe_mul(zi, u, p2); den_reload(z, acc, 3); fe_mul(u, u, z); zinv_store(acc, 3, zi);
-  fe_mul(zi, u, p1); den_reload(z, acc, 2); fe_mul(u, u, z); zinv_store(acc, 2, zi);
-  fe_mul(zi, u, p0); den_reload(z, acc, 1); fe_mul(u, u, z); zinv_store(acc, 1, zi);
+  fe z, p, u, zi;
+  pol.den(0, p);
+  slot_store(acc, 0, 3, p);
+#pragma unroll 1
+  for (int k = 1; k < FINISH_K; k++) {
+    pol.den(k, z);
+    fe_mul(p, p, z);
+    slot_store(acc, k, 3, p);                    // z0 ... zk
+  }
+  fe_inv(u, p);                                  // u = 1 / (z0 ... z7)
+#pragma unroll 1
+  for (int k = FINISH_K - 1; k >= 1; k--) {
+    slot_load(p, acc, k - 1, 3);
+    fe_mul(zi, u, p);                            // 1 / zk
+    slot_load(z, acc, k, 2);
+    fe_mul(u, u, z);                             // 1 / (z0 ... z(k-1))
+    zinv_store(acc, k, zi);
+  }
   zinv_store(acc, 0, u);
 #pragma unroll 1
   for (int k = 0; k < FINISH_K; k++) pol.item(k);
@@ -398,7 +404,7 @@ k_verify_main_quad(const uint32_t* digits, const uint32_t* table, const uint32_t
   fe r;
   verify_main_quad(r, digits + 16 * i, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16, q);
   if (q == 2) return;                            // T is not part of the result
-  uint32_t* o = accout + (i / BLOCK) * (30 * BLOCK) + (i % BLOCK) + (q == 0 ? 0 : q == 1 ? 10 : 20) * BLOCK;
+  uint32_t* o = accout + (i / BLOCK) * (ACC_WORDS * BLOCK) + (i % BLOCK) + (q == 0 ? 0 : q == 1 ? 10 : 20) * BLOCK;
 #pragma unroll
   for (int j = 0; j < 10; j++) o[j * BLOCK] = r.v[j];
 }
@@ -421,7 +427,7 @@ struct x25519_finish_policy {
       acc_load(z, p.acc, 2);
       good = !fe_iszero(z);
       if (!good) {                               // remember it: X := 0 makes the product 0 whatever the "inverse"
-        uint32_t* o = acc + p.tile * (30 * BLOCK) + threadIdx.x;
+        uint32_t* o = acc + p.tile * (ACC_WORDS * BLOCK) + threadIdx.x;
 #pragma unroll
         for (int j = 0; j < 10; j++) o[j * BLOCK] = 0;
       }
@@ -434,7 +440,7 @@ struct x25519_finish_policy {
     if (p.i < n) { acc_load(x, p.acc, 0); acc_load(zinv, p.acc, 2); }
     // (x2 : z2) and 1/z2 determine the shared secret: they do not outlive the call in HBM
     // (x25519.c:221 burnstack); slots past the end hold the committed 1
-    uint32_t* o = acc + p.tile * (30 * BLOCK) + threadIdx.x;
+    uint32_t* o = acc + p.tile * (ACC_WORDS * BLOCK) + threadIdx.x;
 #pragma unroll
     for (int j = 0; j < 10; j++) { o[j * BLOCK] = 0; o[(20 + j) * BLOCK] = 0; }
     if (p.i >= n) return;
@@ -528,18 +534,21 @@ struct sign_finish_policy {
     if (p.i >= n) return;
     fe x, y, zinv;
     acc_load(x, p.acc, 0); acc_load(y, p.acc, 1); acc_load(zinv, p.acc, 2);
-    uint32_t Rw[8], Sw[8], aw[8], rw[8], pub[8];
+    uint32_t Rw[8], Sw[8], pub[8];
     encode_lane(Rw, x, y, zinv);
+    load32(pub, pubs, p.i, 32);
+    const uint8_t* m; size_t mlen;
+    msg_span(m, mlen, msgs, msg_off, msg_len, p.i);
+    sc t;
+    sign_challenge_lane(t, Rw, pub, m, mlen);              // the secret scalars are fetched only after the hash
+    uint32_t aw[8], rw[8];
     uint4* d = reinterpret_cast<uint4*>(aux + 16 * p.i);
     const uint4 a0 = d[0], a1 = d[1], r0 = d[2], r1 = d[3];
     aw[0] = a0.x; aw[1] = a0.y; aw[2] = a0.z; aw[3] = a0.w; aw[4] = a1.x; aw[5] = a1.y; aw[6] = a1.z; aw[7] = a1.w;
     rw[0] = r0.x; rw[1] = r0.y; rw[2] = r0.z; rw[3] = r0.w; rw[4] = r1.x; rw[5] = r1.y; rw[6] = r1.z; rw[7] = r1.w;
     const uint4 zero = make_uint4(0, 0, 0, 0);           // the secrets do not outlive the call in HBM
     d[0] = zero; d[1] = zero; d[2] = zero; d[3] = zero;
-    load32(pub, pubs, p.i, 32);
-    const uint8_t* m; size_t mlen;
-    msg_span(m, mlen, msgs, msg_off, msg_len, p.i);
-    sign_finish_lane(Sw, Rw, aw, rw, pub, m, mlen);
+    sign_response_lane(Sw, t, aw, rw);
     store32(sigs, p.i, 64, Rw);
     store32(sigs + 32, p.i, 64, Sw);
   }

@@ -215,25 +215,28 @@ ED_DEV void cached_load(ge_cached& c, const uint32_t* tab, uint32_t entry) {
   }
 }
 
-// rw = R, sw = S (raw, replaced by the digit words), aw = A as little-endian words.
-// Writes tw/sw digit words and the 9-entry table at tab; returns whether A is on the curve.
-ED_DEV bool verify_prepare_lane(uint32_t tw[8], uint32_t sw[8], uint32_t* tab, const uint32_t rw[8],
-                                const uint32_t aw[8], const uint8_t* m, size_t mlen) {
-  // t = SHA-512(R || A || M) mod l ; S mod l (not range-checked: sc.c:191-214)
-  {
-    uint32_t pre[16], dig[16];
+// The three steps of the prepare kernel, separate so that the kernel can load S only when it is needed
+// (held across the hash it cost a spill) and store each result as soon as it exists:
+// t = SHA-512(R || A || M) mod l as digit words (nibble - 8 is the signed digit)
+ED_DEV void verify_hash_lane(uint32_t tw[8], const uint32_t rw[8], const uint32_t aw[8], const uint8_t* m, size_t mlen) {
+  uint32_t pre[16], dig[16];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { pre[k] = rw[k]; pre[8 + k] = aw[k]; }
-    sha512_prefix_msg<16>(dig, pre, m, mlen);
-    sc t, s;
-    sc_from_words<16>(t, dig);
-    sc_from_words<8>(s, sw);
-    sc_to_words(tw, t);
-    sc_to_words(sw, s);
-    words_add_pattern(tw, 0x88888888u);          // nibble - 8 is the signed digit
-    words_add_pattern(sw, 0x80008000u);          // halfword - 32768 is the signed digit
-  }
-  // -A and its multiples 0..8, cached form
+  for (int k = 0; k < 8; k++) { pre[k] = rw[k]; pre[8 + k] = aw[k]; }
+  sha512_prefix_msg<16>(dig, pre, m, mlen);
+  sc t;
+  sc_from_words<16>(t, dig);
+  sc_to_words(tw, t);
+  words_add_pattern(tw, 0x88888888u);
+}
+// S mod l (not range-checked: sc.c:191-214) as digit words (halfword - 32768 is the signed digit)
+ED_DEV void verify_s_lane(uint32_t sw[8]) {
+  sc s;
+  sc_from_words<8>(s, sw);
+  sc_to_words(sw, s);
+  words_add_pattern(sw, 0x80008000u);
+}
+// -A and its multiples 0..8 in cached form at tab; returns whether A is on the curve
+ED_DEV bool verify_table_lane(uint32_t* tab, const uint32_t aw[8]) {
   bool oncurve;
   ge a, p, q;
   ge_cached c1, c;
@@ -256,6 +259,15 @@ ED_DEV bool verify_prepare_lane(uint32_t tw[8], uint32_t sw[8], uint32_t* tab, c
   ge_dbl(p, p, true);                            // 8
   ge_to_cached(c, p);  cached_store(tab, 8, c);
   return oncurve;
+}
+
+// rw = R, sw = S (raw, replaced by the digit words), aw = A as little-endian words.
+// Writes tw/sw digit words and the 9-entry table at tab; returns whether A is on the curve.
+ED_DEV bool verify_prepare_lane(uint32_t tw[8], uint32_t sw[8], uint32_t* tab, const uint32_t rw[8],
+                                const uint32_t aw[8], const uint8_t* m, size_t mlen) {
+  verify_hash_lane(tw, rw, aw, m, mlen);
+  verify_s_lane(sw);
+  return verify_table_lane(tab, aw);
 }
 
 // digits: the 16 digit words of this item (t + 0x88.. in [0,8), S + 0x8000.. in [8,16)), read from
@@ -749,20 +761,28 @@ ED_DEV void sign_point_lane(ge& R, uint32_t aw[8], uint32_t rw[8], const uint32_
   scale_base_lane(R, rdig, comb);
 }
 
-// ed25519-sha512.c:112-122 sign, from the encoded R on: S = r + H(R || A || M) * a
-ED_DEV void sign_finish_lane(uint32_t Sw[8], const uint32_t Rw[8], const uint32_t aw[8],
-                             const uint32_t rw[8], const uint32_t pub[8], const uint8_t* m, size_t mlen) {
+// ed25519-sha512.c:112-122 sign, from the encoded R on: S = r + H(R || A || M) * a, in two steps so that
+// the finish kernel holds the secret scalars only after the hash (fewer live registers: no scratch)
+ED_DEV void sign_challenge_lane(sc& t, const uint32_t Rw[8], const uint32_t pub[8], const uint8_t* m, size_t mlen) {
   uint32_t pre[16], dig[16];
 #pragma unroll
   for (int k = 0; k < 8; k++) { pre[k] = Rw[k]; pre[8 + k] = pub[k]; }
   sha512_prefix_msg<16>(dig, pre, m, mlen);      // t = H(R || A || M)
-  sc a, r, t, S;
+  sc_from_words<16>(t, dig);
+}
+ED_DEV void sign_response_lane(uint32_t Sw[8], const sc& t, const uint32_t aw[8], const uint32_t rw[8]) {
+  sc a, r, S;
   sc_from_words<8>(a, aw);
   sc_from_words<8>(r, rw);
-  sc_from_words<16>(t, dig);
   sc_mul(S, t, a);
   sc_add(S, r, S);
   sc_to_words(Sw, S);
+}
+ED_DEV void sign_finish_lane(uint32_t Sw[8], const uint32_t Rw[8], const uint32_t aw[8],
+                             const uint32_t rw[8], const uint32_t pub[8], const uint8_t* m, size_t mlen) {
+  sc t;
+  sign_challenge_lane(t, Rw, pub, m, mlen);
+  sign_response_lane(Sw, t, aw, rw);
 }
 
 // x25519.c:158-190 do_x25519_base, up to R = x*B

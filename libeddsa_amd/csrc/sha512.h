@@ -12,7 +12,10 @@
 
 namespace ed {
 
-ED_CONSTANT_MEM uint64_t SHA512_K[80] = {
+// (a constexpr function: with the 80 rounds unrolled every constant becomes an instruction literal;
+// as a __constant__ array the 80 loads were hoisted and held ~160 registers)
+ED_DEV constexpr uint64_t sha512_k(int r) {
+  constexpr uint64_t SHA512_K[80] = {
     0x428a2f98d728ae22ULL, 0x7137449123ef65cdULL, 0xb5c0fbcfec4d3b2fULL, 0xe9b5dba58189dbbcULL,
     0x3956c25bf348b538ULL, 0x59f111f1b605d019ULL, 0x923f82a4af194f9bULL, 0xab1c5ed5da6d8118ULL,
     0xd807aa98a3030242ULL, 0x12835b0145706fbeULL, 0x243185be4ee4b28cULL, 0x550c7dc3d5ffb4e2ULL,
@@ -33,6 +36,8 @@ ED_CONSTANT_MEM uint64_t SHA512_K[80] = {
     0x06f067aa72176fbaULL, 0x0a637dc5a2c898a6ULL, 0x113f9804bef90daeULL, 0x1b710b35131c471bULL,
     0x28db77f523047d84ULL, 0x32caab7b40c72493ULL, 0x3c9ebe0a15c9bebcULL, 0x431d67c49c100d4cULL,
     0x4cc5d4becb3e42b6ULL, 0x597f299cfc657e2aULL, 0x5fcb6fab3ad6faecULL, 0x6c44198c4a475817ULL};
+  return SHA512_K[r];
+}
 
 ED_DEV uint64_t rotr64(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
 
@@ -47,7 +52,7 @@ ED_DEV void sha512_compress(uint64_t st[8], uint64_t w[16]) {
                    (rotr64(w2, 19) ^ rotr64(w2, 61) ^ (w2 >> 6));
     }
     const uint64_t t1 = h + (rotr64(e, 14) ^ rotr64(e, 18) ^ rotr64(e, 41)) + ((e & f) ^ (~e & g)) +
-                        SHA512_K[r] + w[r & 15];
+                        sha512_k(r) + w[r & 15];
     const uint64_t t2 = (rotr64(a, 28) ^ rotr64(a, 34) ^ rotr64(a, 39)) + ((a & b) ^ (a & c) ^ (b & c));
     h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
   }

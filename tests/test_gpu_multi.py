@@ -208,8 +208,9 @@ def test_secrets_do_not_outlive_the_call_in_hbm(engine):
     sk = rng.integers(0, 256, (n, 32), dtype=np.uint8); pt = rng.integers(0, 256, (n, 32), dtype=np.uint8)
     engine.x25519_batch(sk, pt)
     d = engine.x25519_batch(dev(sk), dev(pt)); torch.cuda.synchronize(); del d
-    engine.x25519_base_batch(sk)
     assert engine.secret_residue()[2:] == (0, 0)
+    engine.x25519_base_batch(sk)                               # its output (a public key) may stay; its scalars may not
+    assert engine.secret_residue()[2] == 0
     engine.shutdown()
     engine.x25519_batch(dev(sk), dev(pt)); torch.cuda.synchronize()
     assert engine.secret_residue() == (0, 0, 0, 0)
