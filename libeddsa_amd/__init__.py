@@ -17,6 +17,7 @@ from .api import (  # noqa: F401
     ed25519_verify,
     ed25519_verify_batch,
     ed25519_verify_batch_multi,
+    ed25519_verify_batch_rlc,
     ed25519_verify_batch_multi_dev,
     ed25519_sign_batch_multi,
     x25519_batch_multi,

@@ -265,6 +265,41 @@ def ed25519_verify_batch(sigs, pubs, msgs, msg_off=None, msg_len=None):
     return ok
 
 
+def ed25519_verify_batch_rlc(sigs, pubs, msgs, msg_off=None, msg_len=None, return_stats=False):
+    """OPT-IN batch verification by random linear combination (include/eddsa_amd.h: the reference's TODO,
+    lib/ed25519-sha512.c:13-14): same arguments and verdicts as ed25519_verify_batch, groups that do not
+    pass fall back to the per-item kernels.  return_stats=True -> (ok, (items decided by the combination,
+    items decided per item, groups sent to the per-item kernels, groups decided by the combination))."""
+    lib = library()
+    if _is_torch(sigs):
+        import torch
+        sigs = _torch_check(sigs, 64, "sigs"); pubs = _torch_check(pubs, 32, "pubs")
+        msgs = _torch_check(msgs, 0, "msgs")
+        n = sigs.numel() // 64
+        if pubs.numel() // 32 != n:
+            raise ValueError("ed25519_verify_batch_rlc: sigs and pubs disagree on the batch size")
+        _, off, mlen = _msg_args(msgs, msg_off, msg_len, n, True)
+        _torch_off_check(off, n)
+        ok = torch.empty((n,), dtype=torch.uint8, device=sigs.device)
+        stats = torch.zeros((4,), dtype=torch.int32, device=sigs.device)
+        _check(lib.ed25519_verify_batch_rlc_dev(_c_ptr(ok.data_ptr()), _c_ptr(stats.data_ptr()), _c_ptr(sigs.data_ptr()),
+                                                _c_ptr(pubs.data_ptr()), _c_ptr(msgs.data_ptr()),
+                                                _c_ptr(off.data_ptr()) if off is not None else None,
+                                                _c_size(mlen), _c_size(n), _stream()), "ed25519_verify_batch_rlc")
+        return (ok, tuple(int(x) for x in stats.cpu())) if return_stats else ok
+    sigs = _as_np(sigs, 64, "sigs"); pubs = _as_np(pubs, 32, "pubs")
+    n = sigs.size // 64
+    if pubs.size // 32 != n:
+        raise ValueError("ed25519_verify_batch_rlc: sigs and pubs disagree on the batch size")
+    msgs, off, mlen = _host_msgs(msgs, msg_off, msg_len, n)
+    ok = np.zeros((n,), dtype=np.uint8)
+    stats = (ctypes.c_uint32 * 4)()
+    _check(lib.ed25519_verify_batch_rlc(_np_ptr(ok), stats, _np_ptr(sigs), _np_ptr(pubs), _np_ptr(msgs),
+                                        _np_ptr(off) if off is not None else None, _c_size(mlen), _c_size(n)),
+           "ed25519_verify_batch_rlc")
+    return (ok, tuple(int(x) for x in stats)) if return_stats else ok
+
+
 def ed25519_verify_records(records, sig_off, pub_off, msg_off, msg_len):
     """loop of ed25519_verify over fixed-size records: `records` is an (n, stride) uint8 array (numpy:
     host path, one upload; CUDA tensor: device path) holding each item's 64-byte signature at

@@ -152,6 +152,7 @@ static void fws_release(struct vslot *v)
 static void rws_release(struct vslot *v)
 {
     if (v->rws.base) (void)hipFree(v->rws.base);
+    if (v->rws.host_gok) (void)hipHostFree(v->rws.host_gok);
     memset(&v->rws, 0, sizeof(v->rws));
 }
 
@@ -210,6 +211,7 @@ static int rws_reserve(struct vslot *v, size_t items)
     TRY(hipEventSynchronize(v->free));
     rws_release(v);
     TRY(hipMalloc((void **)&v->rws.base, edk_rlc_ws_bytes(cap)));
+    TRY(hipHostMalloc(&v->rws.host_gok, EDK_RLC_HOST_BYTES, hipHostMallocDefault));
     v->rws.capacity = cap;
 out:
     if (rc) rws_release(v);

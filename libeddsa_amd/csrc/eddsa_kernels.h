@@ -71,7 +71,9 @@ typedef struct edk_fixed_ws {
 typedef struct edk_rlc_ws {
   size_t capacity;
   void* base;
+  void* host_gok;     /* pinned host memory, one byte per group of the largest pass: the group verdicts */
 } edk_rlc_ws;
+#define EDK_RLC_HOST_BYTES 4096
 size_t edk_rlc_ws_bytes(size_t capacity);
 hipError_t edk_verify_rlc(uint8_t* ok, uint32_t* stats, const edk_verify_src* src, size_t n, const uint32_t* base16,
                           const edk_verify_ws* ws, const edk_rlc_ws* rws, hipStream_t stream);

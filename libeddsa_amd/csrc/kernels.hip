@@ -438,11 +438,11 @@ struct x25519_finish_policy {
     const finish_pos p = finish_at(k, acc);
     fe x, zinv;
     if (p.i < n) { acc_load(x, p.acc, 0); acc_load(zinv, p.acc, 2); }
-    // (x2 : z2) and 1/z2 determine the shared secret: they do not outlive the call in HBM
-    // (x25519.c:221 burnstack); slots past the end hold the committed 1
+    // (x2 : z2), 1/z2 and the prefix products of the shared inversion determine shared secrets: they
+    // do not outlive the call in HBM (x25519.c:221 burnstack); slots past the end hold the committed 1
     uint32_t* o = acc + p.tile * (ACC_WORDS * BLOCK) + threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 10; j++) { o[j * BLOCK] = 0; o[(20 + j) * BLOCK] = 0; }
+    for (int j = 0; j < 10; j++) { o[j * BLOCK] = 0; o[(20 + j) * BLOCK] = 0; o[(30 + j) * BLOCK] = 0; }
     if (p.i >= n) return;
     uint32_t w[8];
     x25519_finish_lane(w, x, zinv);
