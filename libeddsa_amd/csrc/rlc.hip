@@ -26,12 +26,14 @@
 // never passes.
 //
 // The multi-scalar multiplication is a bucket method laid out for the wavefront: one workgroup of 128
-// lanes per (group, segment of 8 byte-windows); lane b owns bucket b+1 (signed 8-bit digits), per window
-// the workgroup counting-sorts the group's digits in LDS (17 KB), each lane then adds the points of its
-// bucket (mixed additions, ge_add_niels: 7 M) and multiplies its bucket by 2^8 between windows; the
-// weighted sum of the 128 buckets is two log-step scans through LDS.  -A_i has 32 windows (z_i t_i mod l),
-// -R_i 16 (z_i), B one entry per group: 48 mixed additions per item instead of the per-item kernel's
-// 252 doublings + 80 additions.  Algorithmic HBM bytes: the same 129 per item as verify.
+// lanes per (group, byte-window); lane b owns bucket b+1 (signed 8-bit digits): the workgroup
+// counting-sorts the group's digits of that window in LDS (17 KB), each lane adds the points of its
+// bucket (mixed additions, ed_add_pc's 7 M, software-pipelined so that the next table entry arrives
+// during the second half of the current addition), and the weighted sum of the 128 buckets is two
+// log-step scans through LDS; k_rlc_final then runs Horner over the 48 window points of each group.
+// -A_i has 32 windows (z_i t_i mod l), -R_i 16 (z_i), B one entry per group and window: 48 mixed
+// additions per item instead of the per-item kernel's 252 doublings + 80 additions.  Algorithmic HBM
+// bytes: the same 129 per item as verify.
 #include "eddsa_kernels.h"
 #include "lanes.h"
 
@@ -40,7 +42,9 @@ namespace ed {
 constexpr int RLC_G = 8192;                      // items per group
 constexpr int RLC_BUCKETS = 128;                 // |digit| in 1..128
 constexpr int RLC_WINDOWS_A = 32, RLC_WINDOWS_R = 16, RLC_WINDOWS = RLC_WINDOWS_A + RLC_WINDOWS_R;
-constexpr int RLC_SEGS = 6;                      // 4 segments of 8 windows for -A, 2 for -R
+constexpr int RLC_SEG_WINDOWS = 1;               // windows per segment
+constexpr int RLC_SEGS_A = RLC_WINDOWS_A / RLC_SEG_WINDOWS, RLC_SEGS_R = RLC_WINDOWS_R / RLC_SEG_WINDOWS;
+constexpr int RLC_SEGS = RLC_SEGS_A + RLC_SEGS_R;   // window points per group: 32 for -A, 16 for -R
 constexpr int RLC_BLOCK = 256;
 constexpr int RLC_TREE_FAN = 64;
 constexpr uint32_t RLC_BASE_IDX = RLC_G;         // list entry that stands for the base point B
@@ -63,7 +67,7 @@ __host__ inline rlc_layout rlc_carve(size_t cap) {
   L.niels_r = o; o += rlc_align(cap * 128);
   L.dig = o;     o += rlc_align(L.groups * RLC_WINDOWS * (size_t)RLC_G);
   L.flags = o;   o += rlc_align(cap);
-  L.bsum = o;    o += rlc_align((cap / RLC_BLOCK + 1) * 40);     // per block of 256 items: sum of z S, 9 words (+1 pad)
+  L.bsum = o;    o += rlc_align((L.groups * (RLC_G / RLC_BLOCK) + 1) * 40);   // per block of 256 items: sum of z S, 9 words (+1 pad)
   L.bdig = o;    o += rlc_align(L.groups * 32);
   L.gflags = o;  o += rlc_align(L.groups * 4);
   L.gok = o;     o += rlc_align(L.groups);
@@ -196,10 +200,10 @@ k_rlc_scalars(size_t n, const uint32_t* ts, const uint32_t* seed, const uint8_t*
   uint32_t zs[9];
 #pragma unroll
   for (int k = 0; k < 9; k++) zs[k] = 0;
-  if (i < n) {
+  {                                              // (the grid covers whole groups)
     const size_t g = i / RLC_G, k = i % RLC_G;
     int8_t* d = dig + g * (size_t)RLC_WINDOWS * RLC_G + k;
-    if (flags[i] & RLC_R_VALID) {
+    if (i < n && (flags[i] & RLC_R_VALID)) {
       // z_i = 126 low bits of SHA-512(seed || i || "rlc"), made odd
       uint32_t pre[16], h[16], zw[8], aw[8];
 #pragma unroll
@@ -235,7 +239,7 @@ k_rlc_scalars(size_t n, const uint32_t* ts, const uint32_t* seed, const uint8_t*
 #pragma unroll
       for (int wd = 0; wd < RLC_WINDOWS_R; wd++)
         d[(size_t)(RLC_WINDOWS_A + wd) * RLC_G] = (int8_t)((int)((zw[wd >> 2] >> (8 * (wd & 3))) & 0xffu) - 128);
-    } else {                                     // rejected outright: contributes nothing
+    } else {                                     // rejected outright, or a slot past the end: contributes nothing
 #pragma unroll
       for (int wd = 0; wd < RLC_WINDOWS; wd++) d[(size_t)wd * RLC_G] = 0;
     }
@@ -267,11 +271,11 @@ k_rlc_group_scalar(size_t n, const uint32_t* bsum, int8_t* bdig) {
   const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
   const size_t groups = (n + RLC_G - 1) / RLC_G;
   if (g >= groups) return;
-  const size_t blocks = (n + RLC_BLOCK - 1) / RLC_BLOCK, per = RLC_G / RLC_BLOCK;
+  const size_t per = RLC_G / RLC_BLOCK;
   uint32_t acc[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) acc[k] = 0;
-  for (size_t b = g * per; b < (g + 1) * per && b < blocks; b++) {
+  for (size_t b = g * per; b < (g + 1) * per; b++) {
     uint64_t c = 0;
 #pragma unroll
     for (int k = 0; k < 10; k++) { c += (uint64_t)acc[k] + (k < 9 ? bsum[10 * b + k] : 0u); acc[k] = (uint32_t)c; c >>= 32; }
@@ -324,9 +328,10 @@ k_rlc_bucket(size_t n, const int8_t* dig, const int8_t* bdig, const uint32_t* ni
   const size_t groups = (n + RLC_G - 1) / RLC_G;
   const int seg = (int)(blockIdx.x / groups);    // segment-major: the segments with the longest tails first
   const size_t g = blockIdx.x % groups;
-  const int cnt = (int)(n - g * RLC_G < (size_t)RLC_G ? n - g * RLC_G : (size_t)RLC_G);
-  const bool is_a = seg < 4;
-  const int w_hi = is_a ? 31 - 8 * seg : 15 - 8 * (seg - 4), w_lo = w_hi - 7;   // windows of this segment, high to low
+  const bool is_a = seg < RLC_SEGS_A;
+  // windows of this segment, high to low; segment s of -A and segment s - 4 of -R carry the same weight
+  const int w_hi = (is_a ? RLC_WINDOWS_A - 1 - RLC_SEG_WINDOWS * seg : RLC_WINDOWS_R - 1 - RLC_SEG_WINDOWS * (seg - RLC_SEGS_A));
+  const int w_lo = w_hi - (RLC_SEG_WINDOWS - 1);
   const uint32_t* pts = (is_a ? niels_a : niels_r) + g * (size_t)RLC_G * 32;
   const int8_t* drow = dig + (g * RLC_WINDOWS + (is_a ? 0 : RLC_WINDOWS_A)) * (size_t)RLC_G;
   const int b = (int)threadIdx.x;                // bucket b + 1
@@ -342,11 +347,19 @@ k_rlc_bucket(size_t n, const int8_t* dig, const int8_t* bdig, const uint32_t* ni
     s.hist[b + 1] = 0;
     if (b == 0) s.hist[0] = 0;
     __syncthreads();
-    const int8_t* dw = drow + (size_t)w * RLC_G;
+    // this lane's 64 digits of the window: items 16 (128 j + b) .. + 15, j < 4, one 16-byte load per j
+    // (rows are whole: k_rlc_scalars zeroes the digits of the slots past the end of the batch)
+    const uint4* dw = reinterpret_cast<const uint4*>(drow + (size_t)w * RLC_G);
     const int bd = (is_a && b == 0) ? (int)bdig[32 * g + w] : 0;             // lane 0 also files the base point
-    for (int k = b; k < cnt; k += RLC_BUCKETS) {
-      const int d = dw[k];
-      if (d != 0) atomicAdd(&s.hist[d < 0 ? -d : d], 1u);
+#pragma unroll 1
+    for (int j = 0; j < 4; j++) {
+      const uint4 v = dw[j * RLC_BUCKETS + b];
+      const uint32_t dd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int t = 0; t < 16; t++) {
+        const int d = (int)(int8_t)(dd[t >> 2] >> (8 * (t & 3)));
+        if (d != 0) atomicAdd(&s.hist[d < 0 ? -d : d], 1u);
+      }
     }
     if (bd != 0) atomicAdd(&s.hist[bd < 0 ? -bd : bd], 1u);
     __syncthreads();
@@ -355,20 +368,54 @@ k_rlc_bucket(size_t n, const int8_t* dig, const int8_t* bdig, const uint32_t* ni
     const uint32_t mine = s.hist[b + 1];
     s.cursor[b + 1] = start;
     __syncthreads();
-    for (int k = b; k < cnt; k += RLC_BUCKETS) {
-      const int d = dw[k];
-      if (d != 0) s.list[atomicAdd(&s.cursor[d < 0 ? -d : d], 1u)] = (uint16_t)(k | (d < 0 ? 0x8000 : 0));
+#pragma unroll 1
+    for (int j = 0; j < 4; j++) {
+      const uint4 v = dw[j * RLC_BUCKETS + b];
+      const uint32_t dd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int t = 0; t < 16; t++) {
+        const int d = (int)(int8_t)(dd[t >> 2] >> (8 * (t & 3)));
+        const int k = 16 * (j * RLC_BUCKETS + b) + t;
+        if (d != 0) s.list[atomicAdd(&s.cursor[d < 0 ? -d : d], 1u)] = (uint16_t)(k | (d < 0 ? 0x8000 : 0));
+      }
     }
     if (bd != 0) s.list[atomicAdd(&s.cursor[bd < 0 ? -bd : bd], 1u)] = (uint16_t)(RLC_BASE_IDX | (bd < 0 ? 0x8000 : 0));
     __syncthreads();
-    // lane b adds the points of bucket b + 1
-#pragma unroll 1
-    for (uint32_t q = start; q < start + mine; q++) {
-      const uint32_t e = s.list[q], idx = e & 0x7fffu;
+    // lane b adds the points of bucket b + 1.  Software-pipelined by hand: the three multiplications that
+    // consume the table entry come first, then the NEXT entry is fetched into the same registers and has
+    // the rest of the addition (four multiplications) to arrive.
+    {
       ge_niels nl;
-      niels_load(nl, idx == RLC_BASE_IDX ? base16 + TABLE_ENTRY_WORDS : pts + 32 * (size_t)idx);
-      ge_niels_cneg(nl, (e & 0x8000u) != 0);
-      ge_add_niels(acc, acc, nl, true);
+      uint32_t e = 0;
+      if (mine) {
+        e = s.list[start];
+        const uint32_t idx = e & 0x7fffu;
+        niels_load(nl, idx == RLC_BASE_IDX ? base16 + TABLE_ENTRY_WORDS : pts + 32 * (size_t)idx);
+      }
+#pragma unroll 1
+      for (uint32_t q = 0; q < mine; q++) {
+        fe a, bb, c, d, ee, f, gg, h;                // ge_add_niels (ge25519.h; ed.c:282-305 ed_add_pc) in two halves
+        ge_niels_cneg(nl, (e & 0x8000u) != 0);
+        fe_sub(a, acc.Y, acc.X);
+        fe_mul(a, a, nl.ymx);
+        fe_add(bb, acc.Y, acc.X);
+        fe_mul(bb, bb, nl.ypx);
+        fe_mul(c, acc.T, nl.t2d);
+        if (q + 1 < mine) {
+          e = s.list[start + q + 1];
+          const uint32_t idx = e & 0x7fffu;
+          niels_load(nl, idx == RLC_BASE_IDX ? base16 + TABLE_ENTRY_WORDS : pts + 32 * (size_t)idx);
+        }
+        fe_add(d, acc.Z, acc.Z);                     // 2u
+        fe_sub(ee, bb, a);                           // 3u
+        fe_sub(f, d, c);                             // 4u: first operand only
+        fe_add(gg, d, c);                            // 3u
+        fe_add(h, bb, a);                            // 2u
+        fe_mul(acc.X, f, ee);
+        fe_mul(acc.Y, h, gg);
+        fe_mul(acc.Z, f, gg);
+        fe_mul(acc.T, h, ee);
+      }
     }
     __syncthreads();
   }
@@ -395,27 +442,39 @@ k_rlc_bucket(size_t n, const int8_t* dig, const int8_t* bdig, const uint32_t* ni
     }
     __syncthreads();
   }
-  if (b == 0) {
-#pragma unroll 1
-    for (int k = 0; k < 8 * w_lo; k++) ge_dbl(acc, acc, k == 8 * w_lo - 1);  // the segment's weight 2^(8 w_lo)
+  if (b == 0) {                                  // the segment's weight 2^(8 w_lo) is applied by k_rlc_final
     uint32_t* o = segpts + (g * RLC_SEGS + seg) * 40;
 #pragma unroll
     for (int j = 0; j < 10; j++) { o[j] = acc.X.v[j]; o[10 + j] = acc.Y.v[j]; o[20 + j] = acc.Z.v[j]; o[30 + j] = acc.T.v[j]; }
   }
 }
 
-// R6: per group, the six segment points added up must be the neutral element
+// R6: per group, Horner over the window points (highest window first; the 16 windows of -R carry the
+// weights of the 16 lowest windows of -A): the total must be the neutral element.  One lane per group,
+// 248 dependent doublings: pure latency (0.5 ms), the price of any 253-bit multi-scalar multiplication.
+ED_DEV void seg_load(ge& p, const uint32_t* segpts, size_t g, int sgm) {
+  const uint32_t* o = segpts + (g * RLC_SEGS + sgm) * 40;
+#pragma unroll
+  for (int j = 0; j < 10; j++) { p.X.v[j] = o[j]; p.Y.v[j] = o[10 + j]; p.Z.v[j] = o[20 + j]; p.T.v[j] = o[30 + j]; }
+}
+
 __global__ void __launch_bounds__(64)
 k_rlc_final(size_t n, const uint32_t* segpts, const uint32_t* gflags, uint8_t* gok, uint32_t* stats) {
   const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
   const size_t groups = (n + RLC_G - 1) / RLC_G;
   if (g >= groups) return;
   ge acc, p;
-  for (int sgm = 0; sgm < RLC_SEGS; sgm++) {
-    const uint32_t* o = segpts + (g * RLC_SEGS + sgm) * 40;
-#pragma unroll
-    for (int j = 0; j < 10; j++) { p.X.v[j] = o[j]; p.Y.v[j] = o[10 + j]; p.Z.v[j] = o[20 + j]; p.T.v[j] = o[30 + j]; }
-    if (sgm == 0) acc = p; else ge_add_full(acc, acc, p);
+  seg_load(acc, segpts, g, 0);
+#pragma unroll 1
+  for (int sgm = 1; sgm < RLC_SEGS_A; sgm++) {
+#pragma unroll 1
+    for (int k = 0; k < 8 * RLC_SEG_WINDOWS; k++) ge_dbl(acc, acc, k == 8 * RLC_SEG_WINDOWS - 1);
+    seg_load(p, segpts, g, sgm);
+    ge_add_full(acc, acc, p);
+    if (sgm >= RLC_SEGS_A - RLC_SEGS_R) {
+      seg_load(p, segpts, g, RLC_SEGS_A + sgm - (RLC_SEGS_A - RLC_SEGS_R));
+      ge_add_full(acc, acc, p);
+    }
   }
   const bool ok = ge_is_neutral(acc) && gflags[g] == 0;
   gok[g] = (uint8_t)ok;
@@ -484,7 +543,7 @@ extern "C" hipError_t edk_verify_rlc(uint8_t* ok, uint32_t* stats, const edk_ver
   (void)hipEventRecord(ws->ev_exact, ws->side);
   hipLaunchKernelGGL(k_rlc_points, dim3(blocks), dim3(RLC_BLOCK), 0, stream, src, n, niels_a, niels_r, flags, gflags);
   (void)hipStreamWaitEvent(stream, ws->ev_exact, 0);
-  hipLaunchKernelGGL(k_rlc_scalars, dim3(blocks), dim3(RLC_BLOCK), 0, stream, n, ts, seed, flags, dig, bsum);
+  hipLaunchKernelGGL(k_rlc_scalars, dim3((unsigned)(groups * (RLC_G / RLC_BLOCK))), dim3(RLC_BLOCK), 0, stream, n, ts, seed, flags, dig, bsum);
   hipLaunchKernelGGL(k_rlc_group_scalar, dim3((unsigned)((groups + 63) / 64)), dim3(64), 0, stream, n, bsum, bdig);
   hipLaunchKernelGGL(k_rlc_bucket, dim3((unsigned)(groups * RLC_SEGS)), dim3(RLC_BUCKETS), 0, stream, n, dig, bdig,
                      niels_a, niels_r, base16, segpts);
