@@ -9,17 +9,21 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
 CMD="python3 $REPO/bench.py --steps 5 --warmup 1 --cpu-sample 4096"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/bench_stats.log 2>&1
+# the default command (verify + x25519 + sign in one process), then each op alone
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_all -- $CMD > $OUT/bench_stats_all.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD --op verify > $OUT/bench_stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_x25519 -- $CMD --op x25519 > $OUT/bench_stats_x25519.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_sign -- $CMD --op sign > $OUT/bench_stats_sign.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/bench_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD --op verify > $OUT/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD --op verify > $OUT/bench_write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_x25519 -- $CMD --op x25519 > $OUT/bench_fetch_x.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_x25519 -- $CMD --op x25519 > $OUT/bench_write_x.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_sign -- $CMD --op sign > $OUT/bench_fetch_s.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_sign -- $CMD --op sign > $OUT/bench_write_s.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT/bench_sq.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES --output-format csv -d $OUT/pmc_misc -- $CMD > $OUT/bench_misc.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- $CMD --op verify > $OUT/bench_sq.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES --output-format csv -d $OUT/pmc_misc -- $CMD --op verify > $OUT/bench_misc.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq_x25519 -- $CMD --op x25519 > $OUT/bench_sq_x.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq_sign -- $CMD --op sign > $OUT/bench_sq_s.log 2>&1
+# the opt-in batch verification (tools/rlc_rate.py): kernel stats
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_rlc -- python3 $REPO/tools/rlc_rate.py 5 > $OUT/bench_stats_rlc.log 2>&1
 python3 $REPO/tools/summarize_profile.py $TAG

@@ -18,7 +18,7 @@ dst = os.path.join(ROOT, "gpurun_out", "profiles_out")
 os.makedirs(dst, exist_ok=True)
 
 rows = []
-for sub in ("stats", "stats_x25519", "stats_sign"):
+for sub in ("stats_all", "stats", "stats_x25519", "stats_sign", "stats_rlc"):
     for f in glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv")):
         for r in csv.DictReader(open(f)):
             if r["Name"].startswith("ed::"):
