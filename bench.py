@@ -169,15 +169,21 @@ def cpu_baseline(op, w, gpu_out, sample):
             "per_core": sample / best / cores, "gpu_matches_cpu_on_sample": same}
 
 
-def gather_results(out, world):
-    """N > 1: all-gather the result bytes of every rank's shard (the only exchange of the path)."""
+def gather_results(out, world, everywhere=True):
+    """N > 1: the final result gather, the only exchange of the path.  Verdict bytes (1 B per item) are
+    all-gathered, so that every rank holds the whole vector; the 32- and 64-byte results of x25519 and sign are
+    gathered at rank 0 (everywhere=False), where a caller would collect them."""
     if world == 1:
         return out
     if dist.get_backend() == "gloo":                    # test hook (see main): stage through the host
         out = out.cpu()
-    full = torch.empty((world * out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
-    dist.all_gather_into_tensor(full, out)              # concatenated along dim 0: valid on nccl and gloo
-    return full.view((world,) + tuple(out.shape))
+    if everywhere:
+        full = torch.empty((world * out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
+        dist.all_gather_into_tensor(full, out)          # concatenated along dim 0: valid on nccl and gloo
+        return full.view((world,) + tuple(out.shape))
+    parts = [torch.empty_like(out) for _ in range(world)] if dist.get_rank() == 0 else None
+    dist.gather(out, parts, dst=0)
+    return torch.stack(parts) if parts is not None else None
 
 
 def timed_region(step, steps, world, sync, device):
@@ -223,7 +229,7 @@ def measure(op, w, n, steps, warmup, world, device):
         out = run_step(op, w)
         e1.record()
         marks.append((e0, e1))
-        gathered[0] = gather_results(out, world)        # the final result gather (RCCL over xGMI)
+        gathered[0] = gather_results(out, world, everywhere=(op == "verify"))   # the final result gather (RCCL over xGMI)
         return out
 
     for _ in range(warmup):

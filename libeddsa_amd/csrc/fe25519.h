@@ -147,11 +147,17 @@ ED_DEV void fe_fold_top(fe& h, const uint32_t r[10], uint64_t top) {
   ED_SCHED_FENCE();
 }
 
-// fld.c:209-244 (fld.c:447-497 in the 32-bit build) fld_mul.  f < 8u, g < 3.36u, h tight.
-ED_DEV void fe_mul(fe& h, const fe& f, const fe& g) {
-  uint32_t g19[10], f2[10], r[10];
+// 19 g, for a second operand that many multiplications share (the ladder's x1): computed once
+struct fe19 { uint32_t v[10]; };
+ED_DEV void fe_premul19(fe19& g19, const fe& g) {
+  g19.v[0] = 0;
 #pragma unroll
-  for (int j = 1; j < 10; j++) { ED_CHECK(g.v[j] <= 0xffffffffu / 19u); g19[j] = 19u * g.v[j]; }
+  for (int j = 1; j < 10; j++) { ED_CHECK(g.v[j] <= 0xffffffffu / 19u); g19.v[j] = 19u * g.v[j]; }
+}
+
+// fld.c:209-244 (fld.c:447-497 in the 32-bit build) fld_mul with 19 g supplied.  f < 8u, g < 3.36u, h tight.
+ED_DEV void fe_mul_pre(fe& h, const fe& f, const fe& g, const fe19& g19) {
+  uint32_t f2[10], r[10];
 #pragma unroll
   for (int i = 1; i < 10; i += 2) { ED_CHECK(f.v[i] <= 0x7fffffffu); f2[i] = 2u * f.v[i]; }
   uint64_t acc = 0;
@@ -162,12 +168,19 @@ ED_DEV void fe_mul(fe& h, const fe& f, const fe& g) {
       const int j = (k - i + 10) % 10;
       const bool wrap = i > k;
       const bool odd2 = (i & 1) && (j & 1);
-      acc = mad(odd2 ? f2[i] : f.v[i], wrap ? g19[j] : g.v[j], acc);
+      acc = mad(odd2 ? f2[i] : f.v[i], wrap ? g19.v[j] : g.v[j], acc);
     }
     r[k] = (uint32_t)acc & limb_mask(k);
     acc >>= limb_bits(k);
   }
   fe_fold_top(h, r, acc);
+}
+
+// fld.c:209-244 (fld.c:447-497 in the 32-bit build) fld_mul.  f < 8u, g < 3.36u, h tight.
+ED_DEV void fe_mul(fe& h, const fe& f, const fe& g) {
+  fe19 g19;
+  fe_premul19(g19, g);
+  fe_mul_pre(h, f, g, g19);
 }
 
 // fld.c:249-280 (fld.c:502-531) fld_sq.  f < 3.36u, h tight.

@@ -60,9 +60,16 @@ ED_DEV void x25519_ladder_lane(fe& x2, fe& z2, uint32_t s[8], const uint32_t pt[
   clamp(s);
   fe_frombytes(x1, pt);                          // bit 255 folded in as +19, not masked (fld.c:153)
   fe_set(x2, 1); fe_set(z2, 0); x3 = x1; fe_set(z3, 1);
+  fe19 x1_19;                                    // x1 is the second operand of one multiplication in every step
+  fe_premul19(x1_19, x1);
+#ifndef ED_HOST_CHECK
+#pragma unroll
+  for (int j = 1; j < 10; j++) asm volatile("" : "+v"(x1_19.v[j]));   // keep them: the compiler would recompute 19 x1 in every step
+#endif
   // bit 255 of the clamped scalar is 0 and the step for it maps (1:0),(x1:1) to itself
-  // projectively, so the ladder starts at bit 254.
-  shl256<1>(s);
+  // projectively, so the ladder starts at bit 254.  The scalar is consumed from the top, one word at a
+  // time: `cur` holds the current word, shifted left once per step.
+  uint32_t cur = s[7] << 1;
   // x25519.c:104-123 swaps (x2,z2) <-> (x3,z3) before and after every step.  The differential
   // addition is symmetric in the two points, so only the doubling has to know which slot holds
   // the point to double: with `swap` = (slots currently exchanged) ^ (this bit), the doubling's
@@ -72,8 +79,12 @@ ED_DEV void x25519_ladder_lane(fe& x2, fe& z2, uint32_t s[8], const uint32_t pt[
   uint32_t swap = 0;
 #pragma unroll 1
   for (int t = 254; t >= 3; t--) {
-    const uint32_t bit = s[7] >> 31;
-    shl256<1>(s);
+    const uint32_t bit = cur >> 31;
+    cur <<= 1;
+    if ((t & 31) == 0) {                         // word t / 32 is used up: fetch the next one (uniform, 7 times)
+      const int w = (t >> 5) - 1;
+      cur = w == 6 ? s[6] : w == 5 ? s[5] : w == 4 ? s[4] : w == 3 ? s[3] : w == 2 ? s[2] : w == 1 ? s[1] : s[0];
+    }
     swap ^= bit;
     fe a, aa, b, bb, e, c, d, da, cb, t1;
     fe_add(a, x2, z2);                           // 2u
@@ -92,7 +103,7 @@ ED_DEV void x25519_ladder_lane(fe& x2, fe& z2, uint32_t s[8], const uint32_t pt[
     fe_sq(x3, t1);
     fe_sub(t1, da, cb);                          // 3u
     fe_sq(t1, t1);
-    fe_mul(z3, t1, x1);
+    fe_mul_pre(z3, t1, x1, x1_19);
     fe_mul(x2, aa, bb);
     fe_mul121665(t1, e);                         // x25519.c:78 fld_scale(T2, T1, 121665)
     fe_add(t1, t1, aa);                          // 2u

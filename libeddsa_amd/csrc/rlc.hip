@@ -28,14 +28,15 @@
 // The multi-scalar multiplication is a bucket method laid out for the wavefront: one workgroup of 128
 // lanes per (group, byte-window); lane b owns bucket b+1 (signed 8-bit digits): the workgroup
 // counting-sorts the group's digits of that window in LDS (17 KB), each lane adds the points of its
-// bucket (mixed additions, ed_add_pc's 7 M, software-pipelined so that the next table entry arrives
-// during the second half of the current addition), and the weighted sum of the 128 buckets is two
-// log-step scans through LDS; k_rlc_final then runs Horner over the 48 window points of each group.
+// bucket (mixed additions, ed_add_pc's 7 M), and the weighted sum of the 128 buckets is two
+// log-step scans through LDS; k_rlc_final then runs Horner over the 48 window points of each group
+// (four lanes per point, quad_lanes.h: 248 dependent doublings are pure latency).
 // -A_i has 32 windows (z_i t_i mod l), -R_i 16 (z_i), B one entry per group and window: 48 mixed
 // additions per item instead of the per-item kernel's 252 doublings + 80 additions.  Algorithmic HBM
 // bytes: the same 129 per item as verify.
 #include "eddsa_kernels.h"
 #include "lanes.h"
+#include "quad_lanes.h"
 
 namespace ed {
 
@@ -71,7 +72,7 @@ __host__ inline rlc_layout rlc_carve(size_t cap) {
   L.bdig = o;    o += rlc_align(L.groups * 32);
   L.gflags = o;  o += rlc_align(L.groups * 4);
   L.gok = o;     o += rlc_align(L.groups);
-  L.seg = o;     o += rlc_align(L.groups * RLC_SEGS * 160);
+  L.seg = o;     o += rlc_align(L.groups * RLC_SEGS * 160);      // window points, cached form (40 words)
   L.tree = o;    o += rlc_align((cap / RLC_TREE_FAN + 2) * 32 * 2);
   L.seed = o;    o += 256;
   L.total = o;
@@ -381,41 +382,15 @@ k_rlc_bucket(size_t n, const int8_t* dig, const int8_t* bdig, const uint32_t* ni
     }
     if (bd != 0) s.list[atomicAdd(&s.cursor[bd < 0 ? -bd : bd], 1u)] = (uint16_t)(RLC_BASE_IDX | (bd < 0 ? 0x8000 : 0));
     __syncthreads();
-    // lane b adds the points of bucket b + 1.  Software-pipelined by hand: the three multiplications that
-    // consume the table entry come first, then the NEXT entry is fetched into the same registers and has
-    // the rest of the addition (four multiplications) to arrive.
-    {
-      ge_niels nl;
-      uint32_t e = 0;
-      if (mine) {
-        e = s.list[start];
-        const uint32_t idx = e & 0x7fffu;
-        niels_load(nl, idx == RLC_BASE_IDX ? base16 + TABLE_ENTRY_WORDS : pts + 32 * (size_t)idx);
-      }
+    // lane b adds the points of bucket b + 1 (fetching the next entry by hand during the second half of the
+    // current addition measured the same, 6.11 vs 6.15 ms per pass, and cost 6 spilled registers: not kept)
 #pragma unroll 1
-      for (uint32_t q = 0; q < mine; q++) {
-        fe a, bb, c, d, ee, f, gg, h;                // ge_add_niels (ge25519.h; ed.c:282-305 ed_add_pc) in two halves
-        ge_niels_cneg(nl, (e & 0x8000u) != 0);
-        fe_sub(a, acc.Y, acc.X);
-        fe_mul(a, a, nl.ymx);
-        fe_add(bb, acc.Y, acc.X);
-        fe_mul(bb, bb, nl.ypx);
-        fe_mul(c, acc.T, nl.t2d);
-        if (q + 1 < mine) {
-          e = s.list[start + q + 1];
-          const uint32_t idx = e & 0x7fffu;
-          niels_load(nl, idx == RLC_BASE_IDX ? base16 + TABLE_ENTRY_WORDS : pts + 32 * (size_t)idx);
-        }
-        fe_add(d, acc.Z, acc.Z);                     // 2u
-        fe_sub(ee, bb, a);                           // 3u
-        fe_sub(f, d, c);                             // 4u: first operand only
-        fe_add(gg, d, c);                            // 3u
-        fe_add(h, bb, a);                            // 2u
-        fe_mul(acc.X, f, ee);
-        fe_mul(acc.Y, h, gg);
-        fe_mul(acc.Z, f, gg);
-        fe_mul(acc.T, h, ee);
-      }
+    for (uint32_t q = start; q < start + mine; q++) {
+      const uint32_t e = s.list[q], idx = e & 0x7fffu;
+      ge_niels nl;
+      niels_load(nl, idx == RLC_BASE_IDX ? base16 + TABLE_ENTRY_WORDS : pts + 32 * (size_t)idx);
+      ge_niels_cneg(nl, (e & 0x8000u) != 0);
+      ge_add_niels(acc, acc, nl, true);
     }
     __syncthreads();
   }
@@ -442,41 +417,46 @@ k_rlc_bucket(size_t n, const int8_t* dig, const int8_t* bdig, const uint32_t* ni
     }
     __syncthreads();
   }
-  if (b == 0) {                                  // the segment's weight 2^(8 w_lo) is applied by k_rlc_final
-    uint32_t* o = segpts + (g * RLC_SEGS + seg) * 40;
-#pragma unroll
-    for (int j = 0; j < 10; j++) { o[j] = acc.X.v[j]; o[10 + j] = acc.Y.v[j]; o[20 + j] = acc.Z.v[j]; o[30 + j] = acc.T.v[j]; }
+  if (b == 0) {                                  // the window's weight 2^(8 w_lo) is applied by k_rlc_final
+    ge_cached c;                                 // stored in cached form (Y-X | Y+X | 2dT | 2Z): what quad_add_entry reads
+    ge_to_cached(c, acc);
+    cached_store(segpts + (g * RLC_SEGS + seg) * VERIFY_ENTRY_WORDS, 0, c);
   }
 }
 
 // R6: per group, Horner over the window points (highest window first; the 16 windows of -R carry the
-// weights of the 16 lowest windows of -A): the total must be the neutral element.  One lane per group,
-// 248 dependent doublings: pure latency (0.5 ms), the price of any 253-bit multi-scalar multiplication.
-ED_DEV void seg_load(ge& p, const uint32_t* segpts, size_t g, int sgm) {
-  const uint32_t* o = segpts + (g * RLC_SEGS + sgm) * 40;
-#pragma unroll
-  for (int j = 0; j < 10; j++) { p.X.v[j] = o[j]; p.Y.v[j] = o[10 + j]; p.Z.v[j] = o[20 + j]; p.T.v[j] = o[30 + j]; }
-}
-
-__global__ void __launch_bounds__(64)
+// weights of the 16 lowest windows of -A): the total must be the neutral element.  248 dependent
+// doublings per group: pure latency, the price of any 253-bit multi-scalar multiplication, so it runs in
+// the four-lanes-per-point form of quad_lanes.h (a doubling is one squaring and one multiplication
+// deep): 0.55 ms with one lane per group, 0.2 ms this way.
+__global__ void __launch_bounds__(256)
 k_rlc_final(size_t n, const uint32_t* segpts, const uint32_t* gflags, uint8_t* gok, uint32_t* stats) {
-  const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
+  const size_t g = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 2;            // quads are all-or-nothing
   const size_t groups = (n + RLC_G - 1) / RLC_G;
   if (g >= groups) return;
-  ge acc, p;
-  seg_load(acc, segpts, g, 0);
+  const int q = (int)(threadIdx.x & 3u);
+  const uint32_t* pts = segpts + g * RLC_SEGS * VERIFY_ENTRY_WORDS;
+  fe r;
+  fe_set(r, (uint32_t)(q & 1));                  // neutral element (0, 1, 0, 1) as (X, Y, T, Z)
 #pragma unroll 1
-  for (int sgm = 1; sgm < RLC_SEGS_A; sgm++) {
+  for (int sgm = 0; sgm < RLC_SEGS_A; sgm++) {
+    if (sgm != 0) {
 #pragma unroll 1
-    for (int k = 0; k < 8 * RLC_SEG_WINDOWS; k++) ge_dbl(acc, acc, k == 8 * RLC_SEG_WINDOWS - 1);
-    seg_load(p, segpts, g, sgm);
-    ge_add_full(acc, acc, p);
-    if (sgm >= RLC_SEGS_A - RLC_SEGS_R) {
-      seg_load(p, segpts, g, RLC_SEGS_A + sgm - (RLC_SEGS_A - RLC_SEGS_R));
-      ge_add_full(acc, acc, p);
+      for (int k = 0; k < 8 * RLC_SEG_WINDOWS; k++) quad_dbl(r, q);
     }
+    quad_add_entry(r, pts + sgm * VERIFY_ENTRY_WORDS, false, true, q);
+    if (sgm >= RLC_SEGS_A - RLC_SEGS_R)
+      quad_add_entry(r, pts + (RLC_SEGS_A + sgm - (RLC_SEGS_A - RLC_SEGS_R)) * VERIFY_ENTRY_WORDS, false, true, q);
   }
-  const bool ok = ge_is_neutral(acc) && gflags[g] == 0;
+  // neutral element: X = 0 and Y = Z (lane 0 holds X, lane 1 Y, lane 3 Z)
+  fe z, d;
+  fe_quad_perm<3, 3, 3, 3>(z, r);
+  fe_sub(d, r, z);                               // lane 1: Y - Z
+  const bool mine = q == 0 ? fe_iszero(r) : q == 1 ? fe_iszero(d) : true;
+  const int all = (int)mine & __shfl_xor((int)mine, 1) ;
+  const bool neutral = (all & __shfl_xor(all, 2)) != 0;
+  if (q != 0) return;
+  const bool ok = neutral && gflags[g] == 0;
   gok[g] = (uint8_t)ok;
   if (stats) {
     const uint32_t cnt = (uint32_t)(n - g * RLC_G < (size_t)RLC_G ? n - g * RLC_G : (size_t)RLC_G);
@@ -547,7 +527,7 @@ extern "C" hipError_t edk_verify_rlc(uint8_t* ok, uint32_t* stats, const edk_ver
   hipLaunchKernelGGL(k_rlc_group_scalar, dim3((unsigned)((groups + 63) / 64)), dim3(64), 0, stream, n, bsum, bdig);
   hipLaunchKernelGGL(k_rlc_bucket, dim3((unsigned)(groups * RLC_SEGS)), dim3(RLC_BUCKETS), 0, stream, n, dig, bdig,
                      niels_a, niels_r, base16, segpts);
-  hipLaunchKernelGGL(k_rlc_final, dim3((unsigned)((groups + 63) / 64)), dim3(64), 0, stream, n, segpts, gflags, gok, stats);
+  hipLaunchKernelGGL(k_rlc_final, dim3((unsigned)((4 * groups + 255) / 256)), dim3(256), 0, stream, n, segpts, gflags, gok, stats);
   hipLaunchKernelGGL(k_rlc_verdicts, dim3(blocks), dim3(RLC_BLOCK), 0, stream, n, gok, flags, ok);
   if ((e = hipGetLastError()) != hipSuccess) return e;
 
