@@ -1,0 +1,30 @@
+"""Constant-time evidence for the secret-scalar kernels (the discipline being claimed is the
+reference's scale16, lib/ed.c:346-391: no branch and no address depends on a secret digit): the hardware counters
+of k_x25519_base_point, k_genpub_point and k_sign_point - VALU / SALU / LDS / SMEM / VMEM instruction counts and
+LDS bank-conflict cycles - must be IDENTICAL whether the 2^16 secrets are all zero, all ones, random, or a
+different class in every lane.  Runs tools/ct_counters.sh (rocprofv3 --pmc passes, no tracing) as a child."""
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_point_kernels_counters_do_not_depend_on_the_secrets(engine, tmp_path):
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 is not installed on this box")
+    env = dict(os.environ, GRAFT_REPO_ROOT=ROOT)
+    r = subprocess.run([os.path.join(ROOT, "tools", "ct_counters.sh"), "pytest"], env=env, capture_output=True,
+                       text=True, timeout=900, cwd=ROOT)
+    out = os.path.join(ROOT, "gpurun_out", "profiles_out", "pytest_ct_counters.json")
+    assert r.returncode == 0 and os.path.exists(out), r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.load(open(out))
+    same = d["identical_across_secret_classes"]
+    assert set(same) == {"ed::k_x25519_base_point", "ed::k_genpub_point", "ed::k_sign_point"}, same
+    assert all(same.values()), d["counters"]
+    c = d["counters"]["random"]["ed::k_sign_point"]
+    assert c["SQ_INSTS_VALU"][0] > 1e6 and len(c["SQ_LDS_BANK_CONFLICT"]) == 1     # one value over all launches

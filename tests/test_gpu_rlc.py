@@ -45,6 +45,20 @@ def test_all_valid_groups_pass_by_combination(engine):
     assert bool(ok.all()) and st == (n, 0, 0, 4)
 
 
+def test_tiny_batches(engine):
+    """one item, a handful of items: a single partial group, a one-level hash tree"""
+    sig, pk, msg = _signed(engine, 5, 9)
+    for n in (1, 2, 5):
+        ok, st = engine.ed25519_verify_batch_rlc(sig[:n], pk[:n], msg[:n], msg_len=32, return_stats=True)
+        assert bool(ok.all()) and st == (n, 0, 0, 1)
+    bad = sig.copy(); bad[0, 33] ^= 1
+    ok, st = engine.ed25519_verify_batch_rlc(bad[:1], pk[:1], msg[:1], msg_len=32, return_stats=True)
+    assert ok.tolist() == [0] and st == (0, 1, 1, 0)
+    ok = engine.ed25519_verify_batch_rlc(bad, pk, msg, msg_len=32)
+    assert ok.tolist() == [0, 1, 1, 1, 1]
+    assert engine.ed25519_verify_batch_rlc(sig[:0], pk[:0], msg[:0], msg_len=32).shape == (0,)
+
+
 def test_a_failing_group_is_decided_per_item(engine, oracle):
     n = 4 * G
     sig, pk, msg = _signed(engine, n, 2)
