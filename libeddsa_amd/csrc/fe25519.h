@@ -184,15 +184,18 @@ ED_DEV void fe_mul(fe& h, const fe& f, const fe& g) {
 }
 
 // fld.c:249-280 (fld.c:502-531) fld_sq.  f < 3.36u, h tight.
+// Thirteen premultiplied operands serve the 55 products: 2 f_i for i < 8, 19 f_j for the even and
+// 38 f_j for the odd j >= 5.  A wrapped pair (i, j), i < j, i + j >= 10, carries the factor 2 * 19, times 2
+// again when both are odd: 2 f_i * 38 f_j (both odd), f_i * 38 f_j (i even, j odd: the 2 sits in the 38),
+// 2 f_i * 19 f_j (j even).
 ED_DEV void fe_sq(fe& h, const fe& f) {
-  uint32_t f2[10], f19[10], f38[10], r[10];
+  uint32_t f2[10], fw[10], r[10];
 #pragma unroll
-  for (int i = 0; i < 9; i++) { ED_CHECK(f.v[i] <= 0x7fffffffu); f2[i] = 2u * f.v[i]; }
+  for (int i = 0; i < 8; i++) { ED_CHECK(f.v[i] <= 0x7fffffffu); f2[i] = 2u * f.v[i]; }
 #pragma unroll
   for (int j = 5; j < 10; j++) {
     ED_CHECK(f.v[j] <= 0xffffffffu / ((j & 1) ? 38u : 19u));
-    f19[j] = 19u * f.v[j];
-    f38[j] = 2u * f19[j];
+    fw[j] = ((j & 1) ? 38u : 19u) * f.v[j];
   }
   uint64_t acc = 0;
 #pragma unroll
@@ -203,8 +206,14 @@ ED_DEV void fe_sq(fe& h, const fe& f) {
       if (i > j) continue;                       // each unordered pair once
       const bool wrap = i + j >= 10;             // i + j = k + 10
       const bool odd2 = (i & 1) && (j & 1);
-      const uint32_t a = (i != j) ? f2[i] : f.v[i];
-      const uint32_t b = wrap ? (odd2 ? f38[j] : f19[j]) : (odd2 ? f2[j] : f.v[j]);
+      uint32_t a, b;
+      if (wrap) {
+        b = fw[j];
+        a = (i == j || (!(i & 1) && (j & 1))) ? f.v[i] : f2[i];   // the diagonal, and even i with odd j: 38 f_j already holds the 2
+      } else {
+        a = (i != j) ? f2[i] : f.v[i];
+        b = odd2 ? f2[j] : f.v[j];
+      }
       acc = mad(a, b, acc);
     }
     r[k] = (uint32_t)acc & limb_mask(k);
