@@ -15,8 +15,13 @@ def dev(a):
 SIZES = [1, 2, 3, 63, 64, 65, 255, 256, 257, 511, 777, 1024, 2047, 4099, 16383, 16384, 16385, 20011, 33000]
 
 
+@pytest.fixture(scope="module")
+def device_set(engine):
+    return engine.init_devices()
+
+
 @pytest.mark.parametrize("case", range(24))
-def test_fuzz_against_the_oracle(engine, oracle, case):
+def test_fuzz_against_the_oracle(engine, oracle, device_set, case):
     rng = np.random.default_rng(1000 + case)
     n = int(SIZES[case % len(SIZES)]) if case < len(SIZES) else int(rng.integers(1, 9000))
     sk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
@@ -61,8 +66,42 @@ def test_fuzz_against_the_oracle(engine, oracle, case):
         got_h = engine.ed25519_verify_batch(sig, pk, msgs, msg_len=mlen)
         got_d = engine.ed25519_verify_batch(dev(sig), dev(pk), dev(msgs), msg_len=mlen).cpu().numpy()
     assert np.array_equal(got_h, want) and np.array_equal(got_d, want)
+    # the opt-in batch verification (random linear combination per group of 8192, per-item fallback) and the
+    # single-process multi-device form return the same verdict bytes
+    if ragged:
+        got_r = engine.ed25519_verify_batch_rlc(sig, pk, msgs, msg_off=off)
+        got_m = engine.ed25519_verify_batch_multi(sig, pk, msgs, msg_off=off)
+    else:
+        got_r = engine.ed25519_verify_batch_rlc(dev(sig), dev(pk), dev(msgs), msg_len=mlen).cpu().numpy()
+        got_m = engine.ed25519_verify_batch_multi(sig, pk, msgs, msg_len=mlen)
+    assert np.array_equal(got_r, want) and np.array_equal(got_m, want)
     # x25519 and x25519_base on the same random bytes
     assert np.array_equal(engine.x25519_batch(dev(sk), dev(pk)).cpu().numpy(), oracle.x25519_batch(sk, pk))
     m = min(n, 500)
     xb = np.stack([np.frombuffer(oracle.x25519_base(sk[i].tobytes()), np.uint8) for i in range(m)])
     assert np.array_equal(engine.x25519_base_batch(dev(sk)).cpu().numpy()[:m], xb)
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_fuzz_batch_verification_on_mostly_valid_traffic(engine, oracle, case):
+    """batches of several groups in which only a few items are bad (the regime batch verification is for): the
+    verdicts are the per-item ones, most groups are decided by the combination"""
+    rng = np.random.default_rng(5000 + case)
+    n = int(rng.integers(2 * 8192, 5 * 8192))
+    sk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    msgs = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    pk = engine.ed25519_genpub_batch(dev(sk))
+    sig = engine.ed25519_sign_batch(dev(sk), pk, dev(msgs)).cpu().numpy()
+    pk = pk.cpu().numpy()
+    nbad = int(rng.integers(0, 4))
+    for i in rng.integers(0, n, nbad):
+        which = int(rng.integers(0, 4))
+        if which == 0: sig[i, int(rng.integers(0, 32))] ^= 1 << int(rng.integers(0, 8))
+        elif which == 1: sig[i, 32 + int(rng.integers(0, 32))] ^= 1 << int(rng.integers(0, 8))
+        elif which == 2: pk[i] = rng.integers(0, 256, 32, dtype=np.uint8)
+        else: msgs[i, 0] ^= 1
+    want = oracle.verify_batch(sig, pk, msgs, 32)
+    got, st = engine.ed25519_verify_batch_rlc(dev(sig), dev(pk), dev(msgs), msg_len=32, return_stats=True)
+    assert np.array_equal(got.cpu().numpy(), want)
+    groups = (n + 8191) // 8192
+    assert st[2] + st[3] == groups and st[2] <= nbad and st[0] + st[1] == n
