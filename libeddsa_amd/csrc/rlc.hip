@@ -35,14 +35,13 @@
 // additions per item instead of the per-item kernel's 252 doublings + 80 additions.  Algorithmic HBM
 // bytes: the same 129 per item as verify.
 #include "eddsa_kernels.h"
-#include "lanes.h"
+#include "rlc_lanes.h"
 #include "quad_lanes.h"
 
 namespace ed {
 
 constexpr int RLC_G = 8192;                      // items per group
 constexpr int RLC_BUCKETS = 128;                 // |digit| in 1..128
-constexpr int RLC_WINDOWS_A = 32, RLC_WINDOWS_R = 16, RLC_WINDOWS = RLC_WINDOWS_A + RLC_WINDOWS_R;
 constexpr int RLC_SEG_WINDOWS = 1;               // windows per segment
 constexpr int RLC_SEGS_A = RLC_WINDOWS_A / RLC_SEG_WINDOWS, RLC_SEGS_R = RLC_WINDOWS_R / RLC_SEG_WINDOWS;
 constexpr int RLC_SEGS = RLC_SEGS_A + RLC_SEGS_R;   // window points per group: 32 for -A, 16 for -R
@@ -50,7 +49,6 @@ constexpr int RLC_BLOCK = 256;
 constexpr int RLC_TREE_FAN = 64;
 constexpr uint32_t RLC_BASE_IDX = RLC_G;         // list entry that stands for the base point B
 
-enum : uint8_t { RLC_R_VALID = 1, RLC_PER_ITEM = 2 };
 
 // workspace carving (bytes), capacity = a multiple of 2048 items
 struct rlc_layout {
@@ -97,24 +95,14 @@ __global__ void __launch_bounds__(RLC_BLOCK, 2)
 k_rlc_hash(edk_verify_src src, size_t n, uint32_t* ts, uint32_t* leaf) {
   const size_t i = (size_t)blockIdx.x * RLC_BLOCK + threadIdx.x;
   if (i >= n) return;
-  uint32_t rw[8], aw[8], sw[8], pre[16], dig[16], lf[16];
+  uint32_t rw[8], aw[8], sw[8], tw[8], lf[8];
   load_words8(rw, src.sigs + i * src.sig_stride);
   load_words8(aw, src.pubs + i * src.pub_stride);
+  load_words8(sw, src.sigs + i * src.sig_stride + 32);
   const uint8_t* m; size_t mlen;
   if (src.msg_off) { m = src.msgs + src.msg_off[i]; mlen = (size_t)(src.msg_off[i + 1] - src.msg_off[i]); }
   else { m = src.msgs + i * src.msg_stride; mlen = src.msg_len; }
-#pragma unroll
-  for (int k = 0; k < 8; k++) { pre[k] = rw[k]; pre[8 + k] = aw[k]; }
-  sha512_prefix_msg<16>(dig, pre, m, mlen);
-  // leaf = SHA-512(SHA-512(R || A || M) || S): commits to every byte of the item
-  sha512_prefix_msg<16>(lf, dig, src.sigs + i * src.sig_stride + 32, 32);
-  sc t, s;
-  uint32_t tw[8];
-  sc_from_words<16>(t, dig);
-  sc_to_words(tw, t);
-  load_words8(sw, src.sigs + i * src.sig_stride + 32);
-  sc_from_words<8>(s, sw);                       // not range-checked: sc.c:191-214
-  sc_to_words(sw, s);
+  rlc_hash_lane(tw, sw, lf, rw, aw, src.sigs + i * src.sig_stride + 32, m, mlen);
   uint4* o = reinterpret_cast<uint4*>(ts + 16 * i);
   o[0] = make_uint4(tw[0], tw[1], tw[2], tw[3]); o[1] = make_uint4(tw[4], tw[5], tw[6], tw[7]);
   o[2] = make_uint4(sw[0], sw[1], sw[2], sw[3]); o[3] = make_uint4(sw[4], sw[5], sw[6], sw[7]);
@@ -138,48 +126,17 @@ k_rlc_tree(const uint32_t* in, uint32_t* out, size_t count) {
 // ---------------------------------------------------------------------------------------------
 // R3: per item, -A and -R as affine niels points; the routing flags
 // ---------------------------------------------------------------------------------------------
-ED_DEV bool ge_is_neutral(const ge& p) {
-  fe d;
-  fe_sub(d, p.Y, p.Z);
-  return fe_iszero(p.X) && fe_iszero(d);
-}
-ED_DEV bool ge_small_order(const ge& p) {        // 8 p == neutral (p on the curve)
-  ge q;
-  ge_dbl(q, p, false); ge_dbl(q, q, false); ge_dbl(q, q, false);
-  return ge_is_neutral(q);
-}
-ED_DEV void niels_of_affine(ge_niels& n, const ge& p) {   // p.Z = 1: ed.c:436-442 ed_precompute
-  fe_sub(n.ymx, p.Y, p.X); fe_carry(n.ymx);
-  fe_add(n.ypx, p.Y, p.X); fe_carry(n.ypx);
-  fe_mul(n.t2d, p.T, fe_const_2d());
-}
-
 __global__ void __launch_bounds__(RLC_BLOCK, 2)
 k_rlc_points(edk_verify_src src, size_t n, uint32_t* niels_a, uint32_t* niels_r, uint8_t* flags, uint32_t* gflags) {
   const size_t i = (size_t)blockIdx.x * RLC_BLOCK + threadIdx.x;
   if (i >= n) return;
   uint32_t w[8];
-  uint8_t fl = 0;
-  ge p;
   ge_niels nl;
-  bool oncurve;
-  // -A: permissive decoding (ed.c:100-149), as the per-item path
   load_words8(w, src.pubs + i * src.pub_stride);
-  ge_frombytes(p, oncurve, w, true);
-  if (!oncurve || ge_small_order(p)) fl |= RLC_PER_ITEM;
-  niels_of_affine(nl, p);
+  uint8_t fl = rlc_decode_key_lane(nl, w);
   niels_store(niels_a + 32 * i, nl);
-  // -R: only the canonical encoding of a curve point can equal what ed_export writes (ed.c:155-169)
   load_words8(w, src.sigs + i * src.sig_stride);
-  const uint32_t sign = w[7] >> 31, top = w[7] & 0x7fffffffu;
-  const bool y_ge_p = top == 0x7fffffffu && (w[1] & w[2] & w[3] & w[4] & w[5] & w[6]) == 0xffffffffu && w[0] >= 0xffffffedu;
-  ge_frombytes(p, oncurve, w, true);
-  const bool valid = oncurve && !y_ge_p && !(sign != 0 && fe_iszero(p.X));
-  if (valid) {
-    fl |= RLC_R_VALID;
-    if (ge_small_order(p)) fl |= RLC_PER_ITEM;
-  }
-  niels_of_affine(nl, p);
+  fl |= rlc_decode_r_lane(nl, w);
   niels_store(niels_r + 32 * i, nl);
   flags[i] = fl;
   if (fl & RLC_PER_ITEM) atomicOr(gflags + i / RLC_G, 1u);
@@ -205,41 +162,19 @@ k_rlc_scalars(size_t n, const uint32_t* ts, const uint32_t* seed, const uint8_t*
     const size_t g = i / RLC_G, k = i % RLC_G;
     int8_t* d = dig + g * (size_t)RLC_WINDOWS * RLC_G + k;
     if (i < n && (flags[i] & RLC_R_VALID)) {
-      // z_i = 126 low bits of SHA-512(seed || i || "rlc"), made odd
-      uint32_t pre[16], h[16], zw[8], aw[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) pre[q] = seed[q];
-      pre[8] = (uint32_t)i; pre[9] = (uint32_t)((uint64_t)i >> 32); pre[10] = 0x00636c72u;
-#pragma unroll
-      for (int q = 11; q < 16; q++) pre[q] = 0;
-      sha512_prefix_msg<16>(h, pre, nullptr, 0);
-      zw[0] = h[0] | 1u; zw[1] = h[1]; zw[2] = h[2]; zw[3] = h[3] & 0x3fffffffu;
-      zw[4] = zw[5] = zw[6] = zw[7] = 0;
       const uint4* p = reinterpret_cast<const uint4*>(ts + 16 * i);
       const uint4 t0 = p[0], t1 = p[1], s0 = p[2], s1 = p[3];
       const uint32_t tw[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
       const uint32_t sw[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-      sc z, t, s, a;
-      sc_from_words<8>(z, zw);
-      sc_from_words<8>(t, tw);
-      sc_from_words<8>(s, sw);
-      sc_mul(a, z, t);
-      sc_to_words(aw, a);
-      sc_mul(s, z, s);
-      sc_to_words(zs, s);                        // zs[8] stays 0
-      // signed byte digits: byte of (x + 0x80...80) - 128, the recoding of ed.c:407-409 with 8-bit windows
-      words_add_pattern(aw, 0x80808080u);        // a < 2^253: no carry out of bit 255
-      {
-        uint64_t c = 0;                          // z < 2^126: no carry out of bit 127
+      uint32_t sd[8];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { c += (uint64_t)zw[q] + 0x80808080u; zw[q] = (uint32_t)c; c >>= 32; }
-      }
+      for (int q = 0; q < 8; q++) sd[q] = seed[q];
+      int8_t da[RLC_WINDOWS_A], dr[RLC_WINDOWS_R];
+      rlc_scalars_lane(da, dr, zs, sd, (uint64_t)i, tw, sw);
 #pragma unroll
-      for (int wd = 0; wd < RLC_WINDOWS_A; wd++)
-        d[(size_t)wd * RLC_G] = (int8_t)((int)((aw[wd >> 2] >> (8 * (wd & 3))) & 0xffu) - 128);
+      for (int wd = 0; wd < RLC_WINDOWS_A; wd++) d[(size_t)wd * RLC_G] = da[wd];
 #pragma unroll
-      for (int wd = 0; wd < RLC_WINDOWS_R; wd++)
-        d[(size_t)(RLC_WINDOWS_A + wd) * RLC_G] = (int8_t)((int)((zw[wd >> 2] >> (8 * (wd & 3))) & 0xffu) - 128);
+      for (int wd = 0; wd < RLC_WINDOWS_R; wd++) d[(size_t)(RLC_WINDOWS_A + wd) * RLC_G] = dr[wd];
     } else {                                     // rejected outright, or a slot past the end: contributes nothing
 #pragma unroll
       for (int wd = 0; wd < RLC_WINDOWS; wd++) d[(size_t)wd * RLC_G] = 0;
@@ -281,13 +216,10 @@ k_rlc_group_scalar(size_t n, const uint32_t* bsum, int8_t* bdig) {
 #pragma unroll
     for (int k = 0; k < 10; k++) { c += (uint64_t)acc[k] + (k < 9 ? bsum[10 * b + k] : 0u); acc[k] = (uint32_t)c; c >>= 32; }
   }
-  sc s;
-  uint32_t sw[8];
-  sc_from_words<16>(s, acc);
-  sc_to_words(sw, s);
-  words_add_pattern(sw, 0x80808080u);
+  int8_t dg[32];
+  rlc_group_scalar_lane(dg, acc);
 #pragma unroll
-  for (int wd = 0; wd < 32; wd++) bdig[32 * g + wd] = (int8_t)((int)((sw[wd >> 2] >> (8 * (wd & 3))) & 0xffu) - 128);
+  for (int wd = 0; wd < 32; wd++) bdig[32 * g + wd] = dg[wd];
 }
 
 // ---------------------------------------------------------------------------------------------

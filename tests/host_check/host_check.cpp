@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "lanes.h"
+#include "rlc_lanes.h"
 
 namespace ed {
 static std::atomic<long> g_violations{0};
@@ -224,6 +225,95 @@ void hc_scale_base(uint8_t out[32], const uint8_t scalar[32]) {           // sca
   rd(w, scalar); sc_from_words<8>(x, w); sc_to_words(xw, x);
   scale_base_lane(p, xw, tables().comb.data());
   ge_tobytes(o, p); wr(out, o);
+}
+
+
+// ---- batch verification (rlc_lanes.h): the per-lane steps of rlc.hip, and the whole combination of a small
+// batch evaluated the plain way (double-and-add over the signed byte digits) instead of by the workgroup's buckets
+
+// flags (RLC_R_VALID = 1, RLC_PER_ITEM = 2) of a key (is_r = 0) or an R (is_r = 1); out = the affine niels
+// entry of the NEGATED point as 3 x 32 canonical bytes (y-x | y+x | 2dxy)
+int hc_rlc_decode(uint8_t out[96], const uint8_t in[32], int is_r) {
+  uint32_t w[8];
+  rd(w, in);
+  ge_niels nl;
+  const uint8_t fl = is_r ? rlc_decode_r_lane(nl, w) : rlc_decode_key_lane(nl, w);
+  uint32_t o[8];
+  fe_tobytes(o, nl.ymx); wr(out, o);
+  fe_tobytes(o, nl.ypx); wr(out + 32, o);
+  fe_tobytes(o, nl.t2d); wr(out + 64, o);
+  return fl;
+}
+
+// digits of item i under `seed`: dig_a[32], dig_r[16], zs = z S mod l (32 bytes); t, s = reduced scalars
+void hc_rlc_scalars(int8_t dig_a[32], int8_t dig_r[16], uint8_t zs[32], const uint8_t seed[32], uint64_t i,
+                    const uint8_t t[32], const uint8_t s[32]) {
+  uint32_t sd[8], tw[8], sw[8], z9[9];
+  rd(sd, seed); rd(tw, t); rd(sw, s);
+  rlc_scalars_lane(dig_a, dig_r, z9, sd, i, tw, sw);
+  memcpy(zs, z9, 32);
+}
+
+// The whole check of rlc.hip for ONE group of n <= 64 items with fixed-length messages, every step taken from
+// rlc_lanes.h: leaves -> seed (one tree level), points and flags, coefficients and digits, then
+//   sum_w 256^w ( sum_i digA[i][w] (-A_i) + sum_i digR[i][w] (-R_i) + digB[w] B )
+// by Horner with plain additions.  Returns 1 if the total is the neutral element and no item is flagged for the
+// per-item path, 0 otherwise; valid_r[i] receives the RLC_R_VALID flag of item i.
+int hc_rlc_group(uint8_t* valid_r, const uint8_t* sigs, const uint8_t* pubs, const uint8_t* msgs, size_t mlen, int n) {
+  if (n < 1 || n > 64) return -1;
+  std::vector<uint32_t> tw(8 * n), sw(8 * n), leaves(8 * n);
+  std::vector<ge_niels> na(n), nr(n);
+  std::vector<uint8_t> fl(n);
+  for (int i = 0; i < n; i++) {
+    uint32_t rw[8], aw[8];
+    rd(rw, sigs + 64 * i); rd(aw, pubs + 32 * i); rd(&sw[8 * i], sigs + 64 * i + 32);
+    rlc_hash_lane(&tw[8 * i], &sw[8 * i], &leaves[8 * i], rw, aw, sigs + 64 * i + 32, msgs + mlen * i, mlen);
+    fl[i] = rlc_decode_key_lane(na[i], aw) | rlc_decode_r_lane(nr[i], rw);
+    valid_r[i] = fl[i] & RLC_R_VALID;
+  }
+  uint32_t seed16[16];
+  sha512_prefix_msg<0>(seed16, nullptr, reinterpret_cast<const uint8_t*>(leaves.data()), 32 * (size_t)n);   // k_rlc_tree, one level
+  std::vector<int8_t> da(32 * n), dr(16 * n);
+  uint32_t sum[16] = {0};
+  bool flagged = false;
+  for (int i = 0; i < n; i++) {
+    flagged = flagged || (fl[i] & RLC_PER_ITEM);
+    if (!(fl[i] & RLC_R_VALID)) { memset(&da[32 * i], 0, 32); memset(&dr[16 * i], 0, 16); continue; }
+    uint32_t zs[9];
+    rlc_scalars_lane(&da[32 * i], &dr[16 * i], zs, seed16, (uint64_t)i, &tw[8 * i], &sw[8 * i]);
+    uint64_t c = 0;
+    for (int k = 0; k < 10; k++) { c += (uint64_t)sum[k] + (k < 9 ? zs[k] : 0u); sum[k] = (uint32_t)c; c >>= 32; }
+  }
+  int8_t db[32];
+  rlc_group_scalar_lane(db, sum);
+  ge_niels nb;
+  niels_load(nb, tables().b16() + TABLE_ENTRY_WORDS);        // B
+  ge acc;
+  ge_neutral(acc);
+  auto add_digit = [&](const ge_niels& pt, int d) {          // acc += d * pt, |d| <= 128
+    if (d == 0) return;
+    ge_niels q = pt;
+    ge_niels_cneg(q, d < 0);
+    ge m;                                                    // m = |d| * pt by double-and-add
+    ge_neutral(m);
+    const int mag = d < 0 ? -d : d;
+    for (int bit = 7; bit >= 0; bit--) {
+      ge_dbl(m, m, true);
+      if ((mag >> bit) & 1) ge_add_niels(m, m, q, true);
+    }
+    ge_cached c;
+    ge_to_cached(c, m);
+    ge_add_cached(acc, acc, c, true);
+  };
+  for (int w = 31; w >= 0; w--) {
+    for (int k = 0; k < 8; k++) ge_dbl(acc, acc, true);
+    for (int i = 0; i < n; i++) {
+      add_digit(na[i], da[32 * i + w]);
+      if (w < 16) add_digit(nr[i], dr[16 * i + w]);
+    }
+    add_digit(nb, db[w]);
+  }
+  return (ge_is_neutral(acc) && !flagged) ? 1 : 0;
 }
 
 }  // extern "C"

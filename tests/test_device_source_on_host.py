@@ -220,3 +220,112 @@ def test_fuzz_field_and_scalars_with_hypothesis(hostcheck, oracle):
     mul()
     scalars()
     no_violations(hostcheck)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# batch verification (libeddsa_amd/csrc/rlc_lanes.h): the per-lane steps of rlc.hip on the host, bounds asserted
+# ---------------------------------------------------------------------------------------------------------
+P = 2**255 - 19
+L = 2**252 + 27742317777372353535851937790883648493
+D = (-121665 * pow(121666, P - 2, P)) % P
+SMALL_ORDER_Y = {1, P - 1, 0,
+                 int.from_bytes(bytes.fromhex("26e8958fc2b227b045c3f489f2ef98f0d5dfac05d3c63339b13802886d53fc05"), "little"),
+                 int.from_bytes(bytes.fromhex("c7176a703d4dd84fba3c0b760d10670f2a2053fa2c39ccc64ec7fd7792ac037a"), "little")}
+
+
+def _decode(enc):
+    """(on_curve, x, y) of ed_import's result (lib/ed.c:100-149), big-integer arithmetic"""
+    v = int.from_bytes(enc, "little")
+    sign, y = v >> 255, (v & (2**255 - 1)) % P
+    u, w = (y * y - 1) % P, (D * y * y + 1) % P
+    x2 = u * pow(w, P - 2, P) % P
+    x = pow(x2, (P + 3) // 8, P)
+    if (x * x - x2) % P:
+        x = x * pow(2, (P - 1) // 4, P) % P
+    on = (x * x - x2) % P == 0
+    if on and (x & 1) != sign:
+        x = (P - x) % P
+    return on, x, y
+
+
+def test_rlc_decoding_and_routing_flags(hostcheck, oracle):
+    import ctypes
+    rng = np.random.default_rng(21)
+    le = lambda x: int(x).to_bytes(32, "little")  # noqa: E731
+    encs = [le(1), le(P - 1), le(0), le(1 << 255), le(1 | 1 << 255), le(P), le(P + 1), le(P + 3), le((P - 1) | 1 << 255),
+            bytes.fromhex("26e8958fc2b227b045c3f489f2ef98f0d5dfac05d3c63339b13802886d53fc05"),
+            bytes.fromhex("c7176a703d4dd84fba3c0b760d10670f2a2053fa2c39ccc64ec7fd7792ac03fa")]
+    encs += [le(y) for y in range(2, 30)] + [le(2**255 - 1), le(2**256 - 1)]
+    encs += [oracle.genpub(bytes(rng.integers(0, 256, 32, dtype=np.uint8))) for _ in range(40)]
+    encs += [bytes(rng.integers(0, 256, 32, dtype=np.uint8)) for _ in range(40)]
+    out = ctypes.create_string_buffer(96)
+    seen = set()
+    for enc in encs:
+        v = int.from_bytes(enc, "little")
+        on, x, y = _decode(enc)
+        small = on and y in SMALL_ORDER_Y
+        # a key: flagged for the per-item path when it is no curve point or has small order
+        fl = hostcheck.hc_rlc_decode(out, enc, 0)
+        assert fl == (2 if (not on or small) else 0), enc.hex()
+        if on:                                          # the entry is the NEGATED point: (y + x, y - x, -2dxy)
+            nx = (P - x) % P
+            assert out.raw == le((y - nx) % P) + le((y + nx) % P) + le(2 * D * nx * y % P), enc.hex()
+        # an R: only the canonical encoding of a curve point survives
+        valid = on and (v & (2**255 - 1)) < P and not (x == 0 and v >> 255)
+        fl = hostcheck.hc_rlc_decode(out, enc, 1)
+        assert fl == ((1 if valid else 0) | (2 if valid and small else 0)), enc.hex()
+        seen.add((on, small, valid))
+    assert {(True, False, True), (True, True, True), (False, False, False), (True, True, False), (True, False, False)} <= seen
+    assert hostcheck.hc_violations() == 0, hostcheck.hc_first_violation()
+
+
+def test_rlc_coefficients_and_digits(hostcheck):
+    import ctypes
+    import hashlib
+    rng = np.random.default_rng(22)
+    da, dr = (ctypes.c_int8 * 32)(), (ctypes.c_int8 * 16)()
+    zs = ctypes.create_string_buffer(32)
+    for k in range(60):
+        seed = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+        i = int(rng.integers(0, 2**40)) if k % 2 else k
+        t = int.from_bytes(bytes(rng.integers(0, 256, 32, dtype=np.uint8)), "little") % L if k > 3 else (0, 1, L - 1, L - 2)[k]
+        s = int.from_bytes(bytes(rng.integers(0, 256, 32, dtype=np.uint8)), "little") % L if k > 3 else (L - 1, 0, 1, 7)[k]
+        hostcheck.hc_rlc_scalars(da, dr, zs, seed, ctypes.c_uint64(i), t.to_bytes(32, "little"), s.to_bytes(32, "little"))
+        h = hashlib.sha512(seed + i.to_bytes(8, "little") + b"rlc\0" + bytes(20)).digest()
+        z = (int.from_bytes(h[:16], "little") & (2**126 - 1)) | 1
+        assert all(-128 <= d <= 127 for d in list(da) + list(dr))
+        assert sum(d << (8 * j) for j, d in enumerate(dr)) == z
+        assert sum(d << (8 * j) for j, d in enumerate(da)) == z * t % L
+        assert int.from_bytes(zs.raw, "little") == z * s % L
+    assert hostcheck.hc_violations() == 0, hostcheck.hc_first_violation()
+
+
+def test_rlc_whole_group_by_double_and_add(hostcheck, oracle):
+    """the combination of rlc.hip for one small group, every step from rlc_lanes.h, evaluated without buckets:
+    neutral exactly when every item the combination represents is valid"""
+    import ctypes
+    rng = np.random.default_rng(23)
+    n, mlen = 24, 20
+    sk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    msg = rng.integers(0, 256, (n, mlen), dtype=np.uint8)
+    pk = oracle.genpub_batch(sk)
+    sig = oracle.sign_batch(sk, pk, msg, mlen)
+    valid = (ctypes.c_uint8 * n)()
+    P_ = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    run = lambda s, p, m: hostcheck.hc_rlc_group(valid, P_(np.ascontiguousarray(s)), P_(np.ascontiguousarray(p)),  # noqa: E731
+                                                 P_(np.ascontiguousarray(m)), ctypes.c_size_t(mlen), n)
+    assert run(sig, pk, msg) == 1 and all(valid)
+    s2 = sig.copy()                                             # S + l: reduced, not range-checked
+    s2[3, 32:] = np.frombuffer((int.from_bytes(sig[3, 32:].tobytes(), "little") + L).to_bytes(32, "little"), np.uint8)
+    assert run(s2, pk, msg) == 1
+    s2 = sig.copy(); s2[5, 40] ^= 1
+    assert run(s2, pk, msg) == 0                                # a wrong S
+    m2 = msg.copy(); m2[7, 0] ^= 1
+    assert run(sig, pk, m2) == 0                                # a wrong message
+    s2 = sig.copy(); s2[9, :32] = np.frombuffer((P + 1).to_bytes(32, "little"), np.uint8)
+    assert run(s2, pk, msg) == 1 and valid[9] == 0 and sum(valid) == n - 1    # non-canonical R: rejected at once, excluded
+    p2 = pk.copy(); p2[11] = np.frombuffer((P - 1).to_bytes(32, "little"), np.uint8)
+    assert run(sig, p2, msg) == 0                               # a key of order 2: flagged for the per-item path
+    p2 = pk.copy(); p2[11] = np.frombuffer((2).to_bytes(32, "little"), np.uint8)
+    assert run(sig, p2, msg) == 0                               # a key that is no curve point: flagged
+    assert hostcheck.hc_violations() == 0, hostcheck.hc_first_violation()
