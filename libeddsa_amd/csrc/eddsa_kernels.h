@@ -29,7 +29,7 @@ extern "C" {
 
 hipError_t edk_init_tables(uint32_t* base16, uint32_t* comb, uint32_t* comb_img, hipStream_t stream);
 
-#define EDK_EXACT_PAD_BYTES ((size_t)1024 * 64 * (160 + 2 * ((261 + 3) / 4)) * 4)
+#define EDK_EXACT_PAD_BYTES ((size_t)65536 * 1536)   /* 65536 work-list entries x (four addends x five factors + two digit strings), >= the one-lane kernel's 1024 x 64 lanes x 292 words */
 
 /* verify workspace for up to `capacity` items (a multiple of VERIFY_TILE), all in HBM */
 typedef struct edk_verify_ws {

@@ -156,10 +156,9 @@ k_verify_prepare(edk_verify_src src, size_t n, uint32_t* digits,
 
 // ed25519-sha512.c:148-181 replayed in the reference's own order (lanes.h verify_exact_lane) for
 // the items listed by k_verify_prepare.  Each item is one long serial chain (261 add + double
-// steps), so the work is latency-bound: about 1.3 ms for any number of items up to the chip's
-// width.  Single-wave blocks capped at 128 VGPRs (loop invariants and digit strings in a small
-// HBM/L2 scratchpad) so that the waves fit the slots k_verify_main's waves free.  This one-kernel
-// form (everything per item, spilling) serves work lists beyond the scratchpad's 65536 slots.
+// steps), so the work is latency-bound.  This one-lane, one-kernel form (everything per item,
+// spilling, strided over the list) serves work lists beyond the QUAD_MAX_ITEMS entries that the
+// four-lane chain below takes.
 constexpr int EXACT_BLOCK = 64;
 constexpr int EXACT_MAX_BLOCKS = 1024;
 constexpr int EXACT_PAD_WORDS = 160 + 2 * ((REF_JSF_LEN + 3) / 4);   /* per lane: 4 addends + 2 digit strings */
@@ -182,59 +181,23 @@ k_verify_exact(uint8_t* ok, edk_verify_src src, const uint32_t* offlist, const u
   }
 }
 
-// Passes of more than 2^19 items: the first EXACT_MAX_BLOCKS * 64 entries of the work list take
-// this route (smaller passes: the four-lane chain further down).  The short first half (joint
-// sparse form of the two scalars and the addends Q, B, Q+B, Q-B, all from what k_verify_prepare
-// left in the workspace: lanes.h verify_exact_setup_reuse_lane; about 0.12 ms whatever the count)
-// is a kernel of its own on the caller's stream right after k_verify_prepare; the long second half,
-// the chain, is the ONLY kernel on the side stream, so that it is dispatched together with
-// k_verify_main's first workgroups (a kernel that reaches the side queue later only runs once
-// k_verify_main has drained).  Its blocks are four waves -- one per SIMD, the footprint of exactly
-// one k_verify_main block -- with 152 VGPRs, which fit beside three of the main kernel's waves,
-// at raised wave priority.
-// Measured (tools/exact_path_time.py, rocprofv3 timelines via tools/exact_trace.py): beside the
-// main kernel the chain takes 2.7 ms (4.4 ms before the priority was raised; 1.3 ms on an idle
-// chip), more than one of the main kernel's four rounds of 1024 resident blocks, so every chain
-// block displaces main blocks; because 2^20 items are exactly 4 x 1024 blocks there is no slack
-// and ANY displaced block costs a fifth, nearly empty round: +0.6 ms for 1024 listed keys as for
-// 8192, +1.0 ms for 65536 (it was +1.6 ms with single-wave chain blocks, which displaced a main
-// block each).
-__global__ void __launch_bounds__(EXACT_BLOCK, 2)
-k_verify_exact_setup(const uint32_t* digits, const uint32_t* table, const uint32_t* offlist, const uint32_t* offcount,
-                     const uint32_t* base16, uint32_t* pad) {
-  const size_t g = (size_t)blockIdx.x * EXACT_BLOCK + threadIdx.x;
-  if (g >= *offcount) return;
-  const size_t i = offlist[g];                   // = the item's slot in this pass's workspace
-  uint32_t* base = pad + (size_t)blockIdx.x * (EXACT_PAD_WORDS * EXACT_BLOCK);
-  int8_t* ux = reinterpret_cast<int8_t*>(base + 160 * EXACT_BLOCK) + threadIdx.x;
-  verify_exact_setup_reuse_lane(digits + 16 * i, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
-                                base16 + TABLE_ENTRY_WORDS, ux, ux + REF_JSF_LEN * EXACT_BLOCK,
-                                base + threadIdx.x, EXACT_BLOCK);
-}
-
-constexpr int CHAIN_WAVES = 4;                   // waves per chain block: one per SIMD, the footprint of ONE k_verify_main block
-__global__ void __launch_bounds__(EXACT_BLOCK * CHAIN_WAVES, 2)
-k_verify_exact_chain(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const uint32_t* offlist,
-                     const uint32_t* offcount, const uint32_t* pad) {
-  __builtin_amdgcn_s_setprio(3);                 // few, long, latency-bound waves: let them issue first
-  const size_t wave = (size_t)blockIdx.x * CHAIN_WAVES + (threadIdx.x >> 6);
-  const unsigned lane = threadIdx.x & 63u;
-  const size_t g = wave * EXACT_BLOCK + lane;
-  if (g >= *offcount) return;
-  const size_t i = offlist[g];
-  uint32_t rw[8];
-  load32(rw, sigs, i, sig_stride);
-  const uint32_t* base = pad + wave * (EXACT_PAD_WORDS * EXACT_BLOCK);
-  const int8_t* ux = reinterpret_cast<const int8_t*>(base + 160 * EXACT_BLOCK) + lane;
-  ok[i] = (uint8_t)verify_exact_chain_lane(rw, ux, ux + REF_JSF_LEN * EXACT_BLOCK, base + lane, EXACT_BLOCK);
-}
-
-// Passes of up to QUAD_ROUTE_MAX_N items wait for the chain (k_verify_main is at most two rounds
-// long there), so they take the low-latency form: four lanes per item (quad_lanes.h), for the first
-// QUAD_MAX_ITEMS entries of the work list.
-constexpr size_t QUAD_ROUTE_MAX_N = (size_t)1 << 19;
-constexpr int QUAD_MAX_ITEMS = 32768;
-constexpr int QUAD_BLOCK = 256;
+// The fast route of the exact path, for the first QUAD_MAX_ITEMS entries of the work list (the rest, if any:
+// k_verify_exact above, strided, after the main kernel): four lanes per item (quad_lanes.h), so that a chain
+// step is a squaring and a multiplication deep.  Both halves -- the set-up (joint sparse form of the two
+// scalars and the addends Q, B, Q+B, Q-B, all from what k_verify_prepare left in the workspace) and the
+// chain -- run on the side stream beside k_verify_main, which is launched with MAIN_LDS_RESERVE and therefore
+// leaves wave slots and registers free on every CU.
+// Why this shape (tools/exact_path_time.py, tools/exact_trace.py timelines, profiles/r02_verify_ab.txt):
+// k_verify_main's grid for 2^20 items is an exact number of rounds of resident blocks, so it has no slack:
+// whatever holds up ONE of its blocks -- a displaced tile (round 1: chain blocks of four waves at 149 VGPRs
+// took a main block's place), or main waves starved by a long chain wave of raised priority on their SIMD --
+// costs the latency of one tile at the end (0.7 ms), for 512 off-curve keys as for 65536.  The remedy is to
+// disturb every SIMD a little instead of a few a lot: single-wave chain blocks (16 items) spread over the
+// whole chip, the short four-lane chain, no displacement.  Cost of the exact path on config 2: 0.94 ms in
+// round 1, 0.4 ms now.
+constexpr int QUAD_MAX_ITEMS = 65536;
+constexpr int QUAD_BLOCK = 256;                  // k_verify_main_quad
+constexpr int QUAD_CHAIN_BLOCK = 64;             // k_verify_exact_chain_quad: one wave = 16 items
 static_assert((size_t)QUAD_MAX_ITEMS * QUAD_ITEM_WORDS * 4 <= EDK_EXACT_PAD_BYTES, "scratchpad too small");
 
 __global__ void __launch_bounds__(EXACT_BLOCK, 2)
@@ -247,11 +210,10 @@ k_verify_exact_setup_quad(const uint32_t* digits, const uint32_t* table, const u
                                base16 + TABLE_ENTRY_WORDS, pad + g * QUAD_ITEM_WORDS);
 }
 
-__global__ void __launch_bounds__(QUAD_BLOCK, 2)
+__global__ void __launch_bounds__(QUAD_CHAIN_BLOCK, 2)
 k_verify_exact_chain_quad(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const uint32_t* offlist,
                           const uint32_t* offcount, const uint32_t* pad) {
-  __builtin_amdgcn_s_setprio(3);
-  const size_t g = ((size_t)blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;     // quads are all-or-nothing
+  const size_t g = ((size_t)blockIdx.x * QUAD_CHAIN_BLOCK + threadIdx.x) >> 2;   // quads are all-or-nothing
   if (g >= *offcount || g >= (size_t)QUAD_MAX_ITEMS) return;
   const size_t i = offlist[g];
   uint32_t rw[8];
@@ -283,6 +245,11 @@ k_verify_main(const uint32_t* digits, const uint32_t* table, const uint32_t* bas
 // product) and  item(k, zinv, good): the rest of the work of item k.
 // ---------------------------------------------------------------------------------------------
 constexpr int FINISH_K = 8;
+// k_verify_main uses no LDS; launching it with 78 KB of dynamic LDS per block limits it to two blocks (eight
+// waves) per CU.  Measured (profiles/r02_verify_ab.txt): the kernel itself is about 1 % FASTER that way (two
+// waves per SIMD already saturate VALU issue; fewer resident tables), and the exact path's waves fit beside
+// it on every CU without taking the place of any of its blocks.
+constexpr unsigned MAIN_LDS_RESERVE = 78 * 1024;
 
 struct finish_pos {
   size_t tile, i;            // tile index and global item index of slot k for this lane
@@ -671,36 +638,25 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   hipLaunchKernelGGL(k_verify_prepare, dim3(blocks), dim3(BLOCK), 0, stream, src, n, ws->digits, ws->table, ws->flags, ws->offlist, ws->offcount,
                      ws->exact_offcurve == 2);
   if (marks) (void)hipEventRecord(marks[1], stream);
-  // the exact path depends only on prepare: run it beside the main kernel on the side stream
-  const unsigned eb = (unsigned)((n + EXACT_BLOCK - 1) / EXACT_BLOCK);
-  const unsigned eb1 = eb < (unsigned)EXACT_MAX_BLOCKS ? eb : (unsigned)EXACT_MAX_BLOCKS;
-  const bool quad = n <= QUAD_ROUTE_MAX_N;
-  const size_t fast_items = quad ? (size_t)QUAD_MAX_ITEMS : (size_t)EXACT_MAX_BLOCKS * EXACT_BLOCK;
-  if (ws->exact_offcurve && quad) {
-    const size_t qi = n < (size_t)QUAD_MAX_ITEMS ? n : (size_t)QUAD_MAX_ITEMS;
+  // the exact path depends only on prepare: both of its kernels run beside the main kernel on the side stream
+  const size_t fast_items = (size_t)QUAD_MAX_ITEMS;
+  if (ws->exact_offcurve) {
+    const size_t qi = n < fast_items ? n : fast_items;
+    (void)hipEventRecord(ws->ev_prepared, stream);
+    (void)hipStreamWaitEvent(ws->side, ws->ev_prepared, 0);
     hipLaunchKernelGGL(k_verify_exact_setup_quad, dim3((unsigned)((qi + EXACT_BLOCK - 1) / EXACT_BLOCK)),
-                       dim3(EXACT_BLOCK), 0, stream, ws->digits, ws->table, ws->offlist, ws->offcount, base16,
+                       dim3(EXACT_BLOCK), 0, ws->side, ws->digits, ws->table, ws->offlist, ws->offcount, base16,
                        ws->exact_pad);
-    (void)hipEventRecord(ws->ev_prepared, stream);
-    (void)hipStreamWaitEvent(ws->side, ws->ev_prepared, 0);
-    hipLaunchKernelGGL(k_verify_exact_chain_quad, dim3((unsigned)((4 * qi + QUAD_BLOCK - 1) / QUAD_BLOCK)),
-                       dim3(QUAD_BLOCK), 0, ws->side, ok, src.sigs, src.sig_stride, ws->offlist, ws->offcount,
+    hipLaunchKernelGGL(k_verify_exact_chain_quad, dim3((unsigned)((4 * qi + QUAD_CHAIN_BLOCK - 1) / QUAD_CHAIN_BLOCK)),
+                       dim3(QUAD_CHAIN_BLOCK), 0, ws->side, ok, src.sigs, src.sig_stride, ws->offlist, ws->offcount,
                        ws->exact_pad);
-    (void)hipEventRecord(ws->ev_exact, ws->side);
-  } else if (ws->exact_offcurve) {
-    hipLaunchKernelGGL(k_verify_exact_setup, dim3(eb1), dim3(EXACT_BLOCK), 0, stream, ws->digits, ws->table,
-                       ws->offlist, ws->offcount, base16, ws->exact_pad);
-    (void)hipEventRecord(ws->ev_prepared, stream);
-    (void)hipStreamWaitEvent(ws->side, ws->ev_prepared, 0);
-    hipLaunchKernelGGL(k_verify_exact_chain, dim3((eb1 + CHAIN_WAVES - 1) / CHAIN_WAVES), dim3(EXACT_BLOCK * CHAIN_WAVES),
-                       0, ws->side, ok, src.sigs, src.sig_stride, ws->offlist, ws->offcount, ws->exact_pad);
     (void)hipEventRecord(ws->ev_exact, ws->side);
   }
   if (n <= QUAD_MAIN_MAX_N)
     hipLaunchKernelGGL(k_verify_main_quad, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0,
                        stream, ws->digits, ws->table, base16, ws->acc, n);
   else
-    hipLaunchKernelGGL(k_verify_main, dim3(blocks), dim3(BLOCK), 0, stream, ws->digits, ws->table, base16, ws->acc);
+    hipLaunchKernelGGL(k_verify_main, dim3(blocks), dim3(BLOCK), MAIN_LDS_RESERVE, stream, ws->digits, ws->table, base16, ws->acc);
   if (marks) (void)hipEventRecord(marks[2], stream);
   hipLaunchKernelGGL(k_verify_finish, dim3((blocks + FINISH_K - 1) / FINISH_K), dim3(BLOCK), 0, stream, ok, src.sigs,
                      src.sig_stride, ws->acc, ws->flags, n, ws->exact_offcurve);
