@@ -124,7 +124,7 @@ const char *eddsa_amd_strerror(int err)
 static void wipe_free(void *p, size_t bytes)
 {
     if (!p) return;
-    if (bytes) (void)hipMemset(p, 0, bytes);
+    if (bytes) { (void)hipMemset(p, 0, bytes); (void)hipDeviceSynchronize(); }
     (void)hipFree(p);
 }
 
@@ -162,8 +162,8 @@ static size_t round_capacity(size_t items)
     return (cap + 8 * VERIFY_TILE - 1) / (8 * VERIFY_TILE) * (8 * VERIFY_TILE);   /* whole finish blocks */
 }
 
-/* caller holds e->lk */
-static int fws_reserve(struct vslot *v, size_t items)
+/* caller holds e->lk; st = the stream the pass is about to use */
+static int fws_reserve(struct vslot *v, size_t items, hipStream_t st)
 {
     int rc = 0;
     const size_t cap = round_capacity(items);
@@ -172,8 +172,10 @@ static int fws_reserve(struct vslot *v, size_t items)
     fws_release(v);
     TRY(hipMalloc((void **)&v->fws.acc, cap * ACC_WORDS * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&v->fws.aux, cap * 16 * sizeof(uint32_t)));
-    TRY(hipMemset(v->fws.acc, 0, cap * ACC_WORDS * sizeof(uint32_t)));    /* recycled memory: start clean */
-    TRY(hipMemset(v->fws.aux, 0, cap * 16 * sizeof(uint32_t)));
+    /* recycled memory: start clean.  On the pass's own stream: a hipMemset on the null stream is not ordered
+     * with the kernels of a non-blocking stream and could land after their first stores */
+    TRY(hipMemsetAsync(v->fws.acc, 0, cap * ACC_WORDS * sizeof(uint32_t), st));
+    TRY(hipMemsetAsync(v->fws.aux, 0, cap * 16 * sizeof(uint32_t), st));
     v->fws.capacity = cap;
 out:
     if (rc) fws_release(v);
@@ -512,7 +514,7 @@ static int fixed_on(struct engine *e, size_t n, fixed_step step, const void *ctx
     if (n == 0) return 0;
     pthread_mutex_lock(&e->lk);
     struct vslot *v = ws_pick(e, st);
-    rc = fws_reserve(v, n < CHUNK_MAX ? n : CHUNK_MAX);
+    rc = fws_reserve(v, n < CHUNK_MAX ? n : CHUNK_MAX, st);
     if (rc) goto unlock;
     TRY(hipStreamWaitEvent(st, v->free, 0));
     for (size_t done = 0; done < n; done += CHUNK_MAX)
