@@ -102,8 +102,7 @@ ED_DEV void ge_dbl(ge& r, const ge& p, bool need_t) {
   fe_carry(h);                                  // tight, so e fits the g-operand bound
   fe_sub(e, s, h);                              // 3u
   fe_sub(g, yy, xx);                            // 3u
-  fe_sub(f, xx, yy);
-  fe_add(f, f, zz2);                            // 5u: first operand only
+  fe_sub4(f, zz2, g);                           // xx - yy + 2zz = 2zz - g, < 6u: first operand only
   // second operands are e (X, T) and g (Y, Z): their 19x premultiplies are computed once each
   fe_mul(r.X, f, e);
   fe_mul(r.Y, h, g);

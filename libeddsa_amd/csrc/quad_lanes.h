@@ -244,8 +244,7 @@ ED_DEV void quad_dbl(fe& r, int q) {
   fe_carry(h);                                   // tight, so e fits the second-operand bound
   fe_sub(e, ss, h);                              // 3u
   fe_sub(g, yy, xx);                             // 3u
-  fe_sub(f, xx, yy);
-  fe_add(f, f, zz);                              // 5u: first operand only
+  fe_sub4(f, zz, g);                             // xx - yy + 2zz = 2zz - g, < 6u: first operand only
   fe x = h, y = g;
   fe_cmov(x, f, q == 0 || q == 3);               // (X, Y, T, Z) = (f e, h g, h e, f g)
   fe_cmov(y, e, q == 0 || q == 2);
