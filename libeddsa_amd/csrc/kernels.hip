@@ -213,6 +213,7 @@ k_verify_exact_setup_quad(const uint32_t* digits, const uint32_t* table, const u
 __global__ void __launch_bounds__(QUAD_CHAIN_BLOCK, 2)
 k_verify_exact_chain_quad(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const uint32_t* offlist,
                           const uint32_t* offcount, const uint32_t* pad) {
+  __builtin_amdgcn_s_setprio(3);                 // small passes wait for the chain: 1-3 % there; no difference beside a full k_verify_main
   const size_t g = ((size_t)blockIdx.x * QUAD_CHAIN_BLOCK + threadIdx.x) >> 2;   // quads are all-or-nothing
   if (g >= *offcount || g >= (size_t)QUAD_MAX_ITEMS) return;
   const size_t i = offlist[g];
