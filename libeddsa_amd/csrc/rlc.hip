@@ -228,19 +228,22 @@ k_rlc_group_scalar(size_t n, const uint32_t* bsum, int8_t* bdig) {
 struct rlc_lds {
   uint32_t hist[RLC_BUCKETS + 4];
   uint32_t cursor[RLC_BUCKETS + 4];
+  uint32_t first[RLC_BUCKETS + 4];               // where each bucket's run starts in the sorted list
+  uint32_t perm[RLC_BUCKETS];                    // rank by size -> bucket: lane l serves bucket perm[l]
   union {
     uint16_t list[RLC_G + 2];                    // entry = item index in the group (or RLC_BASE_IDX) | sign << 15
     uint32_t pts[RLC_BUCKETS * 40];              // exchange area of the final scans (after the last window)
   };
 };
 
-ED_DEV void lds_put(uint32_t* pts, const ge& p) {
+ED_DEV void lds_put_at(uint32_t* pts, const ge& p, int slot) {
 #pragma unroll
   for (int j = 0; j < 10; j++) {
-    pts[j * RLC_BUCKETS + threadIdx.x] = p.X.v[j];        pts[(10 + j) * RLC_BUCKETS + threadIdx.x] = p.Y.v[j];
-    pts[(20 + j) * RLC_BUCKETS + threadIdx.x] = p.Z.v[j]; pts[(30 + j) * RLC_BUCKETS + threadIdx.x] = p.T.v[j];
+    pts[j * RLC_BUCKETS + slot] = p.X.v[j];        pts[(10 + j) * RLC_BUCKETS + slot] = p.Y.v[j];
+    pts[(20 + j) * RLC_BUCKETS + slot] = p.Z.v[j]; pts[(30 + j) * RLC_BUCKETS + slot] = p.T.v[j];
   }
 }
+ED_DEV void lds_put(uint32_t* pts, const ge& p) { lds_put_at(pts, p, (int)threadIdx.x); }
 ED_DEV void lds_get(ge& p, const uint32_t* pts, int lane) {
 #pragma unroll
   for (int j = 0; j < 10; j++) {
@@ -296,10 +299,16 @@ k_rlc_bucket(size_t n, const int8_t* dig, const int8_t* bdig, const uint32_t* ni
     }
     if (bd != 0) atomicAdd(&s.hist[bd < 0 ? -bd : bd], 1u);
     __syncthreads();
-    uint32_t start = 0;
-    for (int q = 1; q <= b; q++) start += s.hist[q];
-    const uint32_t mine = s.hist[b + 1];
+    uint32_t start = 0, rank = 0;
+    const uint32_t own = s.hist[b + 1];
+    for (int q = 1; q <= RLC_BUCKETS; q++) {     // prefix sum, and this bucket's rank by size (fullest first)
+      const uint32_t c = s.hist[q];
+      if (q <= b) start += c;
+      rank += (c > own || (c == own && q < b + 1)) ? 1u : 0u;
+    }
     s.cursor[b + 1] = start;
+    s.first[b + 1] = start;
+    s.perm[rank] = (uint32_t)b;
     __syncthreads();
 #pragma unroll 1
     for (int j = 0; j < 4; j++) {
@@ -314,10 +323,15 @@ k_rlc_bucket(size_t n, const int8_t* dig, const int8_t* bdig, const uint32_t* ni
     }
     if (bd != 0) s.list[atomicAdd(&s.cursor[bd < 0 ? -bd : bd], 1u)] = (uint16_t)(RLC_BASE_IDX | (bd < 0 ? 0x8000 : 0));
     __syncthreads();
-    // lane b adds the points of bucket b + 1 (fetching the next entry by hand during the second half of the
-    // current addition measured the same, 6.11 vs 6.15 ms per pass, and cost 6 spilled registers: not kept)
+    // Lane l adds the points of the bucket whose size has rank l: the 64 fullest buckets of the window go to
+    // wave 0, the 64 emptiest to wave 1.  A wave takes as long as its fullest lane (a bucket holds Poisson(64)
+    // points), so in bucket order both waves paid for a near-maximal bucket (~86 additions each); sorted, the
+    // second wave stops at the median (~64).  (Fetching the next entry by hand during the second half of the
+    // current addition measured the same and cost 6 spilled registers: not kept.)
+    const int mb = (int)s.perm[b];
+    const uint32_t lo = s.first[mb + 1], cnt = s.hist[mb + 1];
 #pragma unroll 1
-    for (uint32_t q = start; q < start + mine; q++) {
+    for (uint32_t q = lo; q < lo + cnt; q++) {
       const uint32_t e = s.list[q], idx = e & 0x7fffu;
       ge_niels nl;
       niels_load(nl, idx == RLC_BASE_IDX ? base16 + TABLE_ENTRY_WORDS : pts + 32 * (size_t)idx);
@@ -325,7 +339,12 @@ k_rlc_bucket(size_t n, const int8_t* dig, const int8_t* bdig, const uint32_t* ni
       ge_add_niels(acc, acc, nl, true);
     }
     __syncthreads();
+    lds_put_at(s.pts, acc, mb);                  // back to bucket order for the weighted sum
+    __syncthreads();
+    lds_get(acc, s.pts, b);
+    __syncthreads();
   }
+  static_assert(RLC_SEG_WINDOWS == 1, "the size-ranked lane assignment is per window");
   // sum over buckets of (b + 1) * acc_b = sum over b of the suffix sums T_b = acc_b + acc_(b+1) + ...
 #pragma unroll 1
   for (int stride = 1; stride < RLC_BUCKETS; stride <<= 1) {                 // inclusive suffix scan
