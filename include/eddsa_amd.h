@@ -139,7 +139,7 @@ EDDSA_AMD_DECL int ed25519_verify_records(uint8_t *ok, const uint8_t *records, s
                                           size_t msg_len, size_t n);
 /* OPT-IN batch verification by random linear combination: the reference's own TODO
  * (lib/ed25519-sha512.c:13-14, "batch verification"); same arguments and verdict bytes as
- * ed25519_verify_batch, about 2.5x its rate on batches whose signatures are (nearly) all valid.
+ * ed25519_verify_batch, about twice its rate on batches whose signatures are (nearly) all valid.
  * Groups of 8192 items are checked as  (sum z_i S_i) B - sum (z_i t_i) A_i - sum z_i R_i = 0  with
  * 126-bit odd coefficients z_i derived from a SHA-512 tree over the whole batch; a group that fails, or
  * that contains a key that is no curve point or a key / R of small order, is decided item by item by the
