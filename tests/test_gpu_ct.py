@@ -27,6 +27,8 @@ def test_point_kernels_counters_do_not_depend_on_the_secrets(engine, tmp_path):
     if r.returncode != 0 or not os.path.exists(out):        # the profiler could not run here: nothing to compare
         pytest.skip("rocprofv3 --pmc did not produce counters on this box: " + (r.stdout + r.stderr)[-300:])
     d = json.load(open(out))
+    if not all(d["counters"].get(c) for c in ("zero", "ones", "random", "mixed")):
+        pytest.skip("rocprofv3 collected no counters for some class on this box")
     same = d["identical_across_secret_classes"]
     assert set(same) == {"ed::k_x25519_base_point", "ed::k_genpub_point", "ed::k_sign_point"}, same
     assert all(same.values()), d["counters"]
