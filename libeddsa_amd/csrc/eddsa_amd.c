@@ -14,8 +14,8 @@
  * own duration and restores the caller's.
  *
  * Locks, always taken in this order:  g_table (rwlock: read for the duration of every call, write
- * to create / destroy engines)  ->  engine.pipe_lk (host staging pipeline)  ->  engine.lk (workspace
- * pool, profiling marks).
+ * to create / destroy engines)  ->  g_rccl_lk (the multi-device device-pointer call)  ->  engine.pipe_lk
+ * (host staging pipeline)  ->  engine.lk (workspace pool, profiling marks).
  */
 #define _POSIX_C_SOURCE 200809L
 #define __HIP_PLATFORM_AMD__ 1
@@ -99,6 +99,7 @@ struct multi {
     const char *(*GetErrorString)(int);
 };
 static struct multi g_multi;
+static pthread_mutex_t g_rccl_lk = PTHREAD_MUTEX_INITIALIZER;   /* one grouped RCCL call at a time (taken after g_table) */
 #define NCCL_UINT8 1                   /* ncclUint8, rccl.h */
 
 #define TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = -(int)e_; goto out; } } while (0)
@@ -1188,12 +1189,15 @@ int x25519_batch_multi(uint8_t *out, const uint8_t *scalars, const uint8_t *poin
 int ed25519_verify_batch_multi_dev(uint8_t *const ok_full[], const uint8_t *const sigs[], const uint8_t *const pubs[],
                                    const uint8_t *const msgs[], size_t msg_len, size_t n_total, void *const streams[])
 {
-    int rc = 0, saved = -1, g, r, even = 1;
+    int rc = 0, saved = -1, g, r, even = 1, locked = 0;
     pthread_rwlock_rdlock(&g_table);
     g = g_multi.n;
     if (g == 0) { rc = -(int)hipErrorNotInitialized; goto unlock; }
     if (n_total == 0) goto unlock;
     (void)hipGetDevice(&saved);
+    /* concurrent callers must not interleave their launches or their grouped RCCL calls on the shared communicators */
+    pthread_mutex_lock(&g_rccl_lk);
+    locked = 1;
     for (int d = 0; d < g && !rc; d++) {
         size_t lo, hi;
         eddsa_amd_shard_bounds(n_total, d, g, &lo, &hi);
@@ -1224,6 +1228,7 @@ int ed25519_verify_batch_multi_dev(uint8_t *const ok_full[], const uint8_t *cons
     r = g_multi.GroupEnd();
     if (r && !rc) rc = ERR_RCCL_BASE - r;
 out:
+    if (locked) pthread_mutex_unlock(&g_rccl_lk);
     if (saved >= 0) (void)hipSetDevice(saved);
 unlock:
     pthread_rwlock_unlock(&g_table);
