@@ -97,8 +97,8 @@ EDDSA_AMD_DECL int ed25519_verify_batch_multi_dev(uint8_t *const ok_full[], cons
                                                   size_t msg_len, size_t n_total, void *const streams[]);
 /* human-readable text for a negative return value */
 EDDSA_AMD_DECL const char *eddsa_amd_strerror(int err);
-/* copy the device's generated tables out for inspection: base16 = 32769 entries k*B; comb = 416
- * entries comb[i][k] = (k+1)*1024^i*B, i < 26, k < 16 (the reference's ed_lookup[i][k], lib/ed.c:41-43,
+/* copy the device's generated tables out for inspection: base16 = 32769 entries k*B; comb = 704
+ * entries comb[i][k] = (k+1)*4096^i*B, i < 22, k < 32 (the reference's ed_lookup[i][k], lib/ed.c:41-43,
  * is (k+1)*256^i*B: the same comb with 4-bit windows; row 0 coincides for k < 8); each entry 32
  * words: 10 radix-2^25.5 limbs of y-x, y+x, 2dxy, then 2 words of padding. */
 EDDSA_AMD_DECL int eddsa_amd_dump_tables(uint32_t *base16_words, uint32_t *comb_words);

@@ -7,15 +7,15 @@
 
 #ifndef TABLE_BASE16_ENTRIES      /* also defined, identically, by lanes.h for the device side */
 #define TABLE_BASE16_ENTRIES 32769 /* k*B, k = 0..32768 */
-#define COMB_W 5                  /* signed window width of the fixed-base comb (the reference's is 4, ed.c:397-430) */
+#define COMB_W 6                  /* signed window width of the fixed-base comb (the reference's is 4, ed.c:397-430) */
 #define COMB_HALF (1 << (COMB_W - 1))          /* digits d in [-COMB_HALF, COMB_HALF - 1] */
-#define COMB_DIGITS (COMB_W == 4 ? 64 : 52)    /* digits of x + offset: 64 x 4 bits, or 52 x 5 bits (260 bits) */
+#define COMB_DIGITS (COMB_W == 4 ? 64 : COMB_W == 5 ? 52 : 44)   /* digits of x + offset: 64 x 4, 52 x 5 or 44 x 6 bits */
 #define COMB_ROWS (COMB_DIGITS / 2)            /* even digits and odd digits share a row */
 #define TABLE_COMB_ENTRIES (COMB_ROWS * COMB_HALF) /* comb[i][k] = (k+1) * 2^(2*COMB_W*i) * B, k < COMB_HALF */
 #define TABLE_ENTRY_WORDS 32      /* 3 x 10 limbs + 2 padding words */
 #define VERIFY_TABLE_ENTRIES 9    /* 0..8 times -A, cached form */
 #define VERIFY_ENTRY_WORDS 40     /* ymx | ypx | t2d | z2 */
-#define COMB_IMG_ENTRIES (2 * COMB_HALF) /* LDS image of a comb row: entry d + COMB_HALF = d * 2^(2*COMB_W*i) * B */
+#define COMB_IMG_ENTRIES (COMB_HALF + 1) /* LDS image of a comb row: entry m = m * 2^(2*COMB_W*i) * B, m = 0..COMB_HALF */
 #define COMB_IMG_ENTRY_WORDS 36
 #define COMB_IMG_WORDS (COMB_ROWS * COMB_IMG_ENTRIES * COMB_IMG_ENTRY_WORDS)
 #endif

@@ -20,13 +20,13 @@
 #include "sha512.h"
 
 #define TABLE_BASE16_ENTRIES 32769 /* k*B, k = 0..32768: 16-bit signed windows of S (4 MiB, L2/MALL) */
-#define COMB_W 5                  /* signed window width of the fixed-base comb (the reference's is 4, ed.c:397-430) */
+#define COMB_W 6                  /* signed window width of the fixed-base comb (the reference's is 4, ed.c:397-430) */
 #define COMB_HALF (1 << (COMB_W - 1))          /* digits d in [-COMB_HALF, COMB_HALF - 1] */
-#define COMB_DIGITS (COMB_W == 4 ? 64 : 52)    /* digits of x + offset: 64 x 4 bits, or 52 x 5 bits (260 bits) */
+#define COMB_DIGITS (COMB_W == 4 ? 64 : COMB_W == 5 ? 52 : 44)   /* digits of x + offset: 64 x 4, 52 x 5 or 44 x 6 bits */
 #define COMB_ROWS (COMB_DIGITS / 2)            /* even digits and odd digits share a row */
 #define TABLE_COMB_ENTRIES (COMB_ROWS * COMB_HALF) /* comb[i][k] = (k+1) * 2^(2*COMB_W*i) * B, k < COMB_HALF */
 #define TABLE_ENTRY_WORDS 32      /* 3 x 10 limbs + 2 padding words */
-#define COMB_IMG_ENTRIES (2 * COMB_HALF) /* LDS image of a comb row: entry d + COMB_HALF = d * 2^(2*COMB_W*i) * B */
+#define COMB_IMG_ENTRIES (COMB_HALF + 1) /* LDS image of a comb row: entry m = m * 2^(2*COMB_W*i) * B, m = 0..COMB_HALF */
 #define COMB_IMG_ENTRY_WORDS 36   /* 30 limbs + 6 padding words: entries start 4 banks apart */
 #define COMB_IMG_WORDS (COMB_ROWS * COMB_IMG_ENTRIES * COMB_IMG_ENTRY_WORDS)
 #define VERIFY_TABLE_ENTRIES 9    /* 0..8 times -A, cached form */
@@ -149,7 +149,7 @@ ED_DEV void x25519_lane(uint32_t out[8], uint32_t s[8], const uint32_t pt[8]) {
 // ---------------------------------------------------------------------------------------------
 // Entry = 32 words: y-x | y+x | 2dxy (10 canonical limbs each) + 2 words of padding.
 //   base16[k], k = 0..32768 : k * B                (16-bit signed windows of S in verify)
-//   comb[i][k], i < 32, k < 8 : (k+1) * 256^i * B  (ed.c:41-43 ed_lookup, sign/genpub/x25519_base)
+//   comb[i][k], i < COMB_ROWS, k < COMB_HALF : (k+1) * 2^(2 COMB_W i) * B  (ed.c:41-43 ed_lookup has 32 rows of 8: w = 4)
 
 ED_DEV void niels_store(uint32_t* dst, const ge_niels& n) {
 #pragma unroll
@@ -627,30 +627,29 @@ ED_DEV bool verify_exact_lane(const uint32_t rw[8], const uint32_t sraw[8], cons
 // COMB_HALF at every digit position, then subtract it from every digit); even digits accumulate
 // in R0, odd digits in R1, both from row i = j / 2 of the table comb[i][k] = (k+1) * 2^(2 w i) * B;
 // then R1 <- 2^w R1 and out = R0 + R1.  The reference has w = 4 (64 digits, 32 rows of 8); here
-// w = 5: 52 digits, 26 rows of 16, i.e. 52 mixed additions instead of 64 for one more doubling.
-// x * B is the same group element either way and only its affine encoding leaves the kernels (the
-// addition law of ed.c:282-305 is complete on this curve), so the bytes are the reference's.
+// w = 6: 44 digits, 22 rows of 32, i.e. 44 mixed additions instead of 64 for two more doublings
+// (round 1 had w = 5, 52 additions).  x * B is the same group element either way and only its affine
+// encoding leaves the kernels (the addition law of ed.c:282-305 is complete on this curve), so the bytes
+// are the reference's.
 // The scalar is secret here, so the lookup keeps the reference's constant-time discipline
 // (ed.c:359-390): no memory address and no branch depends on the digit.  On the device the table
-// is staged in LDS as 2 * COMB_HALF ready-made entries per row, d * 2^(2 w i) * B for every digit
-// value d (sign and the neutral element already applied, `comb_image_entry_lane`: 26 x 32 x 144
-// bytes = 117 KiB, one 512-lane block per CU); lane L of every wave reads entry L mod 32 -- an
-// address that depends on the lane number only -- and each lane then takes the entry it needs
-// from lane (d + COMB_HALF) of its own wave with ds_bpermute_b32, the cross-lane shuffle of the
-// LDS crossbar (30 per lookup, on the LDS pipe, beside the VALU work of the previous addition).
+// is staged in LDS as COMB_HALF + 1 entries per row, m * 2^(2 w i) * B for m = 0 (the neutral element)
+// .. COMB_HALF (`comb_image_entry_lane`: 22 x 33 x 144 bytes = 102 KiB, one 512-lane block per CU);
+// lane L of every wave reads entry min(L, COMB_HALF) -- an address that depends on the lane number
+// only -- and each lane then takes the entry it needs from lane |d| of its own wave with
+// ds_bpermute_b32, the cross-lane shuffle of the LDS crossbar (30 per lookup, on the LDS pipe, beside
+// the VALU work of the previous addition), and applies the digit's sign in registers (ed.c:383-389:
+// swap y-x with y+x, negate 2dxy; 40 selects).  With w = 5 the image held both signs (2 x 16 entries per
+// row) and needed no selects; with w = 6 both signs would not fit the CU's 160 KiB of LDS, and 8 fewer
+// additions are worth more than 44 x 40 selects (sign 400 -> 43x M/s).
 // The first version scanned all eight entries of a w = 4 row with v_cndmask: 240 selects + 40 for
 // the conditional negation per lookup, 15 % of the kernel's instructions.
 
-// entry s = d + COMB_HALF of the image of comb row `row` (comb = the table in its global layout)
-ED_DEV void comb_image_entry_lane(uint32_t* dst, const uint32_t* comb, int row, int s) {
-  const int d = s - COMB_HALF, mag = d < 0 ? -d : d;
+// entry m of the image of comb row `row` (comb = the table in its global layout): m * 2^(2 w row) * B
+ED_DEV void comb_image_entry_lane(uint32_t* dst, const uint32_t* comb, int row, int m) {
   ge_niels e;
   fe_set(e.ymx, 1); fe_set(e.ypx, 1); fe_set(e.t2d, 0);        // ed.c:73 pced_zero
-  if (mag != 0) niels_load(e, comb + TABLE_ENTRY_WORDS * (COMB_HALF * row + mag - 1));
-  if (d < 0) {                                                  // ed.c:383-389: swap diff/sum, negate prod
-    ge_niels_cneg(e, true);
-    fe_carry(e.t2d);
-  }
+  if (m != 0) niels_load(e, comb + TABLE_ENTRY_WORDS * (COMB_HALF * row + m - 1));
 #pragma unroll
   for (int j = 0; j < 10; j++) { dst[j] = e.ymx.v[j]; dst[10 + j] = e.ypx.v[j]; dst[20 + j] = e.t2d.v[j]; }
 #pragma unroll
@@ -663,32 +662,35 @@ ED_DEV void comb_select(ge_niels& e, const uint32_t* table, int row, uint32_t di
   const int d = (int)digit - COMB_HALF, mag = d < 0 ? -d : d;
   fe_set(e.ymx, 1); fe_set(e.ypx, 1); fe_set(e.t2d, 0);
   if (mag != 0) niels_load(e, table + TABLE_ENTRY_WORDS * (COMB_HALF * row + mag - 1));
-  if (d < 0) { ge_niels_cneg(e, true); fe_carry(e.t2d); }
+  ge_niels_cneg(e, d < 0);                                      // ed.c:383-389: swap diff/sum, negate prod
 }
 #else
 // device: `table` is the LDS image [COMB_ROWS][COMB_IMG_ENTRIES][COMB_IMG_ENTRY_WORDS]; every lane
 // of the wave must be active (the point kernels give idle lanes a real item for that reason)
 ED_DEV void comb_select(ge_niels& e, const uint32_t* table, int row, uint32_t digit) {
+  const int lane = (int)(threadIdx.x & 63u);
   const word4* p = reinterpret_cast<const word4*>(
-      table + COMB_IMG_ENTRY_WORDS * (COMB_IMG_ENTRIES * row + (int)(threadIdx.x & (COMB_IMG_ENTRIES - 1))));
+      table + COMB_IMG_ENTRY_WORDS * (COMB_IMG_ENTRIES * row + (lane < COMB_HALF ? lane : COMB_HALF)));
   uint32_t w[32];
 #pragma unroll
   for (int q = 0; q < 8; q++) {
     const word4 v = p[q];
     w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
   }
-  const int src = (int)(digit << 2);                            // byte address of the source lane's slot
+  const int d = (int)digit - COMB_HALF, mag = d < 0 ? -d : d;
+  const int src = mag << 2;                                     // byte address of the source lane's slot
 #pragma unroll
   for (int j = 0; j < 30; j++) w[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)w[j]);
 #pragma unroll
   for (int j = 0; j < 10; j++) { e.ymx.v[j] = w[j]; e.ypx.v[j] = w[10 + j]; e.t2d.v[j] = w[20 + j]; }
+  ge_niels_cneg(e, d < 0);                                      // the sign, in registers: no branch, no address
 }
 #endif
 
 // out = x * B for a reduced scalar (x < 2^253) given as eight little-endian words; comb = the LDS
 // image on the device, the table in its global layout in the host build (see comb_select)
 ED_DEV void scale_base_lane(ge& out, const uint32_t xw[8], const uint32_t* comb) {
-  // y = x + sum_j COMB_HALF * 2^(w j): nine words (w = 5: 260 bits)
+  // y = x + sum_j COMB_HALF * 2^(w j): nine words (w = 6: 264 bits)
   uint32_t y[9];
   {
     uint64_t c = 0;

@@ -157,9 +157,9 @@ def test_exact_chain_for_off_curve_points(hostcheck, oracle, golden):
 
 
 def test_tables_match_the_reference_points(hostcheck, oracle, golden):
-    """comb[i][k] = (k+1) * 1024^i * B (row 0 = the first row of the reference's lib/ed_lookup64.h)
+    """comb[i][k] = (k+1) * 4096^i * B (row 0 = the first row of the reference's lib/ed_lookup64.h)
     and base16[k] = k * B, every comb entry and a sample of base16 against the oracle's k * B"""
-    base16 = np.zeros((32769, 32), np.uint32); comb = np.zeros((416, 32), np.uint32)
+    base16 = np.zeros((32769, 32), np.uint32); comb = np.zeros((704, 32), np.uint32)
     hostcheck.hc_tables(base16.ctypes.data_as(ctypes.c_void_p), comb.ctypes.data_as(ctypes.c_void_p))
     pos = [0, 26, 51, 77, 102, 128, 153, 179, 204, 230]
     val = lambda limbs: sum(int(v) << s for v, s in zip(limbs, pos))  # noqa: E731
@@ -175,8 +175,8 @@ def test_tables_match_the_reference_points(hostcheck, oracle, golden):
     for k in range(8):
         assert enc(comb[k]) == pts[32 * k:32 * k + 32], k
     out = ctypes.create_string_buffer(32)
-    for e in range(416):
-        oracle.lib.orc_ed_scale_base(out, int((e % 16 + 1) * 1024 ** (e // 16) % ell).to_bytes(32, "little"))
+    for e in range(704):
+        oracle.lib.orc_ed_scale_base(out, int((e % 32 + 1) * 4096 ** (e // 32) % ell).to_bytes(32, "little"))
         assert enc(comb[e]) == out.raw, e
     for k in list(range(1, 32769, 331)) + [32767, 32768]:
         oracle.lib.orc_ed_scale_base(out, int(k).to_bytes(32, "little"))

@@ -89,10 +89,10 @@ def test_layer_kats_through_the_abi(engine, golden):
 
 
 def test_device_tables_equal_the_reference_table(engine, oracle, golden):
-    """the tables generated on the device: comb[i][k] = (k+1) * 1024^i * B (row 0 = the first row of the
+    """the tables generated on the device: comb[i][k] = (k+1) * 4096^i * B (row 0 = the first row of the
     reference's lib/ed_lookup64.h, every entry against the oracle's k * B) and base16[k] = k * B"""
     import ctypes
-    base16 = np.zeros((32769, 32), np.uint32); comb = np.zeros((416, 32), np.uint32)
+    base16 = np.zeros((32769, 32), np.uint32); comb = np.zeros((704, 32), np.uint32)
     rc = engine.library().eddsa_amd_dump_tables(base16.ctypes.data_as(ctypes.c_void_p), comb.ctypes.data_as(ctypes.c_void_p))
     assert rc == 0
     pos = [0, 26, 51, 77, 102, 128, 153, 179, 204, 230]
@@ -111,8 +111,8 @@ def test_device_tables_equal_the_reference_table(engine, oracle, golden):
     pts = golden("comb_points.bin")
     ell = 2**252 + 27742317777372353535851937790883648493
     out = ctypes.create_string_buffer(32)
-    for e in range(416):
-        oracle.lib.orc_ed_scale_base(out, int((e % 16 + 1) * 1024 ** (e // 16) % ell).to_bytes(32, "little"))
+    for e in range(704):
+        oracle.lib.orc_ed_scale_base(out, int((e % 32 + 1) * 4096 ** (e // 32) % ell).to_bytes(32, "little"))
         assert enc(comb[e]) == out.raw, e
     for k in range(1, 9):                                  # base16[k] = k*B = comb row 0 = the reference's row 0
         assert enc(comb[k - 1]) == pts[32 * (k - 1):32 * k]
