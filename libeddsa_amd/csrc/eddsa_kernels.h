@@ -15,7 +15,7 @@
 #define TABLE_ENTRY_WORDS 32      /* 3 x 10 limbs + 2 padding words */
 #define VERIFY_TABLE_ENTRIES 9    /* 0..8 times -A, cached form */
 #define VERIFY_ENTRY_WORDS 40     /* ymx | ypx | t2d | z2 */
-#define COMB_IMG_ENTRIES (COMB_HALF + 1) /* LDS image of a comb row: entry m = m * 2^(2*COMB_W*i) * B, m = 0..COMB_HALF */
+#define COMB_IMG_ENTRIES COMB_HALF       /* LDS image of a comb row: entry m - 1 = m * 2^(2*COMB_W*i) * B, m = 1..COMB_HALF */
 #define COMB_IMG_ENTRY_WORDS 36
 #define COMB_IMG_WORDS (COMB_ROWS * COMB_IMG_ENTRIES * COMB_IMG_ENTRY_WORDS)
 #endif

@@ -424,7 +424,7 @@ k_x25519_finish(uint8_t* out, uint32_t* acc, size_t n) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// fixed-base kernels: the image of the comb (22 rows x 33 entries m * 4096^i * B, m = 0..32, 102 KiB of the CU's
+// fixed-base kernels: the image of the comb (22 rows x 32 entries m * 4096^i * B, m = 1..32, 99 KiB of the CU's
 // 160 KiB LDS; one 512-lane block per CU, two waves per SIMD) is staged by every block of a
 // "point" kernel; the matching "finish" kernel encodes (and, for sign, hashes and computes S)
 // ---------------------------------------------------------------------------------------------

@@ -26,7 +26,7 @@
 #define COMB_ROWS (COMB_DIGITS / 2)            /* even digits and odd digits share a row */
 #define TABLE_COMB_ENTRIES (COMB_ROWS * COMB_HALF) /* comb[i][k] = (k+1) * 2^(2*COMB_W*i) * B, k < COMB_HALF */
 #define TABLE_ENTRY_WORDS 32      /* 3 x 10 limbs + 2 padding words */
-#define COMB_IMG_ENTRIES (COMB_HALF + 1) /* LDS image of a comb row: entry m = m * 2^(2*COMB_W*i) * B, m = 0..COMB_HALF */
+#define COMB_IMG_ENTRIES COMB_HALF       /* LDS image of a comb row: entry m - 1 = m * 2^(2*COMB_W*i) * B, m = 1..COMB_HALF */
 #define COMB_IMG_ENTRY_WORDS 36   /* 30 limbs + 6 padding words: entries start 4 banks apart */
 #define COMB_IMG_WORDS (COMB_ROWS * COMB_IMG_ENTRIES * COMB_IMG_ENTRY_WORDS)
 #define VERIFY_TABLE_ENTRIES 9    /* 0..8 times -A, cached form */
@@ -633,23 +633,25 @@ ED_DEV bool verify_exact_lane(const uint32_t rw[8], const uint32_t sraw[8], cons
 // are the reference's.
 // The scalar is secret here, so the lookup keeps the reference's constant-time discipline
 // (ed.c:359-390): no memory address and no branch depends on the digit.  On the device the table
-// is staged in LDS as COMB_HALF + 1 entries per row, m * 2^(2 w i) * B for m = 0 (the neutral element)
-// .. COMB_HALF (`comb_image_entry_lane`: 22 x 33 x 144 bytes = 102 KiB, one 512-lane block per CU);
-// lane L of every wave reads entry min(L, COMB_HALF) -- an address that depends on the lane number
-// only -- and each lane then takes the entry it needs from lane |d| of its own wave with
-// ds_bpermute_b32, the cross-lane shuffle of the LDS crossbar (30 per lookup, on the LDS pipe, beside
-// the VALU work of the previous addition), and applies the digit's sign in registers (ed.c:383-389:
-// swap y-x with y+x, negate 2dxy; 40 selects).  With w = 5 the image held both signs (2 x 16 entries per
-// row) and needed no selects; with w = 6 both signs would not fit the CU's 160 KiB of LDS, and 8 fewer
-// additions are worth more than 44 x 40 selects (sign 400 -> 43x M/s).
+// is staged in LDS as COMB_HALF entries per row, m * 2^(2 w i) * B for m = 1 .. COMB_HALF
+// (`comb_image_entry_lane`: 22 x 32 x 144 bytes = 99 KiB, one 512-lane block per CU);
+// lane L of every wave reads entry L mod 32 -- an address that depends on the lane number only -- and
+// each lane then takes the entry it needs from lane |d| - 1 of its own wave with ds_bpermute_b32, the
+// cross-lane shuffle of the LDS crossbar (30 per lookup, on the LDS pipe, beside the VALU work of the
+// previous addition), replaces it by the neutral element when d = 0 and applies the digit's sign, both
+// with selects in registers (ed.c:383-389: swap y-x with y+x, negate 2dxy).  Only lanes 0..31 are ever
+// sources: the shuffle's crossbar has 32 banks for this purpose, and a 33rd source lane (an entry for
+// m = 0 in lane 32) measurably collided with lane 0 whenever digits 0 and -32 met in one wave
+// (SQ_LDS_BANK_CONFLICT 45 k for constant secrets, 430 k for random ones: tests/test_gpu_ct.py caught it).
+// With w = 5 the image held both signs (2 x 16 entries per row) and needed no selects; with w = 6 both
+// signs would not fit the CU's 160 KiB of LDS, and 8 fewer additions are worth more than 44 x 70 selects.
 // The first version scanned all eight entries of a w = 4 row with v_cndmask: 240 selects + 40 for
 // the conditional negation per lookup, 15 % of the kernel's instructions.
 
-// entry m of the image of comb row `row` (comb = the table in its global layout): m * 2^(2 w row) * B
-ED_DEV void comb_image_entry_lane(uint32_t* dst, const uint32_t* comb, int row, int m) {
+// entry m - 1 of the image of comb row `row` (comb = the table in its global layout): m * 2^(2 w row) * B
+ED_DEV void comb_image_entry_lane(uint32_t* dst, const uint32_t* comb, int row, int m1) {
   ge_niels e;
-  fe_set(e.ymx, 1); fe_set(e.ypx, 1); fe_set(e.t2d, 0);        // ed.c:73 pced_zero
-  if (m != 0) niels_load(e, comb + TABLE_ENTRY_WORDS * (COMB_HALF * row + m - 1));
+  niels_load(e, comb + TABLE_ENTRY_WORDS * (COMB_HALF * row + m1));
 #pragma unroll
   for (int j = 0; j < 10; j++) { dst[j] = e.ymx.v[j]; dst[10 + j] = e.ypx.v[j]; dst[20 + j] = e.t2d.v[j]; }
 #pragma unroll
@@ -668,9 +670,8 @@ ED_DEV void comb_select(ge_niels& e, const uint32_t* table, int row, uint32_t di
 // device: `table` is the LDS image [COMB_ROWS][COMB_IMG_ENTRIES][COMB_IMG_ENTRY_WORDS]; every lane
 // of the wave must be active (the point kernels give idle lanes a real item for that reason)
 ED_DEV void comb_select(ge_niels& e, const uint32_t* table, int row, uint32_t digit) {
-  const int lane = (int)(threadIdx.x & 63u);
   const word4* p = reinterpret_cast<const word4*>(
-      table + COMB_IMG_ENTRY_WORDS * (COMB_IMG_ENTRIES * row + (lane < COMB_HALF ? lane : COMB_HALF)));
+      table + COMB_IMG_ENTRY_WORDS * (COMB_IMG_ENTRIES * row + (int)(threadIdx.x & (COMB_IMG_ENTRIES - 1))));
   uint32_t w[32];
 #pragma unroll
   for (int q = 0; q < 8; q++) {
@@ -678,9 +679,13 @@ ED_DEV void comb_select(ge_niels& e, const uint32_t* table, int row, uint32_t di
     w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
   }
   const int d = (int)digit - COMB_HALF, mag = d < 0 ? -d : d;
-  const int src = mag << 2;                                     // byte address of the source lane's slot
+  const int src = ((mag - 1) & (COMB_IMG_ENTRIES - 1)) << 2;    // byte address of the source lane's slot (lanes 0..31 only)
+  const bool none = mag == 0;
 #pragma unroll
-  for (int j = 0; j < 30; j++) w[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)w[j]);
+  for (int j = 0; j < 30; j++) {
+    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)w[j]);
+    w[j] = none ? ((j == 0 || j == 10) ? 1u : 0u) : v;          // d = 0: the neutral element (1, 1, 0), ed.c:73 pced_zero
+  }
 #pragma unroll
   for (int j = 0; j < 10; j++) { e.ymx.v[j] = w[j]; e.ypx.v[j] = w[10 + j]; e.t2d.v[j] = w[20 + j]; }
   ge_niels_cneg(e, d < 0);                                      // the sign, in registers: no branch, no address
