@@ -13,7 +13,8 @@ One "step" = one pass of the hot path over the whole synthetic batch, inputs alr
           verdict bytes.  Total work fixed: "strong".  --log2n overrides the per-GPU size
           (then "weak").
 After the verify region the same process times config 3 (2^20 x25519 per GPU) and config 5 (2^20
-signs per GPU) with the same step count and reports them under "secondary" (--op all, the default).
+signs per GPU) with the same step count and reports them under "secondary" (--op all, the default),
+together with the opt-in batch verification on the config's items before corruption.
 
 `--gpus N` without a torch.distributed environment spawns the N ranks itself (a child
 `python -m torch.distributed.run`, started before this process touches the GPU) and relays rank 0's line.
@@ -79,8 +80,9 @@ def make_workload(op, n, first, device, seed=None, config=None):
     pk = ed.ed25519_genpub_batch(d_sk)
     sig = ed.ed25519_sign_batch(d_sk, pk, up(msg)).cpu().numpy()
     pk = pk.cpu().numpy()
+    valid = (up(sig.copy()), up(pk.copy()), up(msg.copy()))   # the same items before corruption: the batch-verification line
     expect = workload.corrupt_for_verify(sig, pk, msg, seed=seed, config=config, first=first)
-    return {"sigs": up(sig), "pubs": up(pk), "msgs": up(msg), "expect": up(expect)}
+    return {"sigs": up(sig), "pubs": up(pk), "msgs": up(msg), "expect": up(expect), "valid": valid}
 
 
 def pmc_profile():
@@ -148,7 +150,7 @@ def cpu_baseline(op, w, gpu_out, sample):
         lib, kind = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so")), "port"
         fn = {"verify": lib.orc_ed25519_verify_batch, "x25519": lib.orc_x25519_batch, "sign": lib.orc_ed25519_sign_batch}[op]
     P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
-    host = {k: v[:sample].cpu().numpy().copy() for k, v in w.items() if k != "expect"}
+    host = {k: v[:sample].cpu().numpy().copy() for k, v in w.items() if k not in ("expect", "valid")}
     if op == "verify":
         out = np.zeros(sample, np.uint8)
         args = (P(out), P(host["sigs"]), P(host["pubs"]), P(host["msgs"]), ctypes.c_size_t(32), ctypes.c_size_t(sample), cores)
@@ -377,10 +379,33 @@ def main():
         "outputs_correct": correct, "verdicts": pinned,
         "roofline": roofline_of(main_op, n, k_ms, phases, ms_per_step, passes), "cpu_baseline": base,
     }
+    secondary = {}
+    if args.op == "all" and main_op == "verify":
+        # SURVEY 8(f)-3, opt-in: the same items BEFORE corruption through ed25519_verify_batch_rlc (groups of 8192
+        # checked by one random linear combination; a group that fails falls back to the per-item kernels)
+        m = min(n, 1 << 20)
+        vs, vp, vm = w["valid"][0][:m], w["valid"][1][:m], w["valid"][2][:m]
+        for _ in range(max(1, args.warmup)):
+            ed.ed25519_verify_batch_rlc(vs, vp, vm, msg_len=32)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            okr, st = ed.ed25519_verify_batch_rlc(vs, vp, vm, msg_len=32, return_stats=True)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        good = all_ranks_agree(bool(okr.all()) and st[0] == m and st[1] == 0, world, device)
+        correct = correct and good
+        secondary["verify_rlc_all_valid"] = {
+            "metric": "ed25519 verifies/sec, opt-in batch verification, the config's items before corruption (all valid)",
+            "value": world * m * args.steps / el, "unit": UNIT["verify"], "ms_per_step": el / args.steps * 1e3,
+            "items_per_gpu": m, "stats": st, "outputs_correct": good,
+            "note": "not the headline: verdicts equal the per-item path's, see include/eddsa_amd.h for the caveat; "
+                    "time of this rank (no gather)"}
     del w, out, full
 
     if args.op == "all":                                # the rest of BASELINE's metric, same process, same step count
-        secondary = {}
         for op in ("x25519", "sign"):
             w2 = make_workload(op, n2, rank * n2, device)
             torch.cuda.synchronize()

@@ -94,6 +94,8 @@ def test_bench_default_line_carries_the_whole_metric(engine, golden):
         s = d["secondary"][op]
         assert s["metric"] == metric and s["value"] > 0 and s["outputs_correct"] is True
         assert 0 < s["roofline"]["frac"] < 1.5 and s["cpu_baseline"]["gpu_matches_cpu_on_sample"]
+    v = d["secondary"]["verify_rlc_all_valid"]
+    assert v["outputs_correct"] is True and v["stats"][0] == 1 << 20 and v["value"] > d["value"]
     r = d["roofline"]
     assert 0 < r["whole_pass"]["frac"] <= r["frac"] * 1.2 and "source" in r["valu_busy"] and "source" in r["traffic"]
 
