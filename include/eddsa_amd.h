@@ -111,6 +111,7 @@ EDDSA_AMD_DECL int eddsa_amd_dump_tables(uint32_t *base16_words, uint32_t *comb_
  * reference's order of operations (JSF/Shamir chain, lib/ed.c:455-507) and the windowed kernel's
  * result is ignored -- same verdicts, latency-bound, meant for self-checks. */
 EDDSA_AMD_DECL void eddsa_amd_set_offcurve_mode(int exact);
+EDDSA_AMD_DECL void eddsa_amd_set_rlc_min_items(size_t items);   /* see ed25519_verify_batch_rlc */
 
 /* measurement aid: when on, HIP events are recorded on the launch stream around the three kernels
  * of every verify pass (up to 256 passes); eddsa_amd_verify_phase_ms() waits for them and returns
@@ -150,7 +151,10 @@ EDDSA_AMD_DECL int ed25519_verify_records(uint8_t *ok, const uint8_t *records, s
  * cofactorless check rejects one of them.  That is why this is never the default.
  * stats (4 words, may be NULL) receives: items decided by the combination, items decided per item,
  * groups sent to the per-item kernels, groups decided by the combination.
- * The device-pointer form synchronises `stream` once per pass (it reads the group verdicts). */
+ * The device-pointer form synchronises `stream` once per pass (it reads the group verdicts).
+ * The combination has about 2 ms of latency of its own (hash tree over the batch, one serial Horner per
+ * group), so it pays from about 3 x 2^17 items (x1.6 at 2^19, x2.0 from 2^20): calls with fewer items than
+ * eddsa_amd_set_rlc_min_items (default 3 x 2^17 = 393216; 0 = always combine) go straight to the per-item kernels. */
 EDDSA_AMD_DECL int ed25519_verify_batch_rlc(uint8_t *ok, uint32_t stats[4], const uint8_t *sigs,
                                             const uint8_t *pubs, const uint8_t *msgs,
                                             const uint64_t *msg_off, size_t msg_len, size_t n);

@@ -38,6 +38,7 @@ from .api import (  # noqa: F401
     sk_ed25519_to_x25519,
     set_offcurve_mode,
     set_profiling,
+    set_rlc_min_items,
     shutdown,
     sk_ed25519_to_x25519_batch,
     verify_phase_ms,

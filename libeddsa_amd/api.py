@@ -81,6 +81,12 @@ def set_offcurve_mode(exact=True):
     library().eddsa_amd_set_offcurve_mode(2 if exact == 2 else int(bool(exact)))
 
 
+def set_rlc_min_items(items):
+    """ed25519_verify_batch_rlc calls with fewer items go straight to the per-item kernels (default 3 x 2^17,
+    the measured break-even; 0 = always try the combination)"""
+    library().eddsa_amd_set_rlc_min_items(_c_size(int(items)))
+
+
 def set_profiling(on):
     library().eddsa_amd_set_profiling(int(bool(on)))
 

@@ -82,6 +82,7 @@ static struct engine *g_eng[MAX_DEVICES];
 static int g_default = -1;            /* device of the host-pointer entry points; -1: the caller's current device at first use */
 static int g_offcurve_mode = 1;       /* eddsa_amd_set_offcurve_mode: 0 reject, 1 exact (default), 2 all exact */
 static int g_profiling;               /* record marks around the three verify kernels */
+static size_t g_rlc_min_items = (size_t)3 << 17;   /* eddsa_amd_set_rlc_min_items: smaller calls go to the per-item kernels */
 
 /* the device set of the *_multi entry points (eddsa_amd_init_devices) */
 typedef struct ncclComm *ncclComm_t;  /* as in rccl.h; the library is dlopen()ed on first use (it is 570 MB) */
@@ -428,6 +429,15 @@ void eddsa_amd_set_offcurve_mode(int exact)
     pthread_rwlock_unlock(&g_table);
 }
 
+/* ed25519_verify_batch_rlc[_dev] calls of fewer than `items` items use the per-item kernels (default 3 x 2^17:
+ * the measured break-even; 0 = always try the combination) */
+void eddsa_amd_set_rlc_min_items(size_t items)
+{
+    pthread_rwlock_wrlock(&g_table);
+    g_rlc_min_items = items;
+    pthread_rwlock_unlock(&g_table);
+}
+
 /* per-kernel timing of the verify pass, for bench.py's roofline line: HIP events recorded on the
  * launch stream around k_verify_prepare / k_verify_main / k_verify_finish of every chunk */
 void eddsa_amd_set_profiling(int on)
@@ -589,6 +599,13 @@ static int rlc_on(struct engine *e, uint8_t *ok, uint32_t *stats, const edk_veri
 {
     int rc = 0;
     if (n == 0) return 0;
+    if (n < g_rlc_min_items) {
+        /* the combination has about 2 ms of latency of its own (hash tree, one serial Horner per group): below
+         * ~3 x 2^17 items the per-item kernels are faster (tools/rlc_sizes.py), so such calls go straight to them */
+        rc = verify_on(e, ok, all, n, st);
+        if (!rc) { hipError_t er = edk_rlc_note_per_item(stats, n, st); if (er != hipSuccess) rc = -(int)er; }
+        return rc;
+    }
     pthread_mutex_lock(&e->lk);
     struct vslot *v = ws_pick(e, st);
     rc = ws_reserve(v, n < CHUNK_MAX ? n : CHUNK_MAX);

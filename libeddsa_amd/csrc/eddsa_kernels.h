@@ -75,6 +75,7 @@ typedef struct edk_rlc_ws {
 } edk_rlc_ws;
 #define EDK_RLC_HOST_BYTES 4096
 size_t edk_rlc_ws_bytes(size_t capacity);
+hipError_t edk_rlc_note_per_item(uint32_t* stats, size_t n, hipStream_t stream);
 hipError_t edk_verify_rlc(uint8_t* ok, uint32_t* stats, const edk_verify_src* src, size_t n, const uint32_t* base16,
                           const edk_verify_ws* ws, const edk_rlc_ws* rws, hipStream_t stream);
 

@@ -429,6 +429,20 @@ k_rlc_verdicts(size_t n, const uint8_t* gok, const uint8_t* flags, uint8_t* ok) 
 
 using namespace ed;
 
+namespace ed {
+__global__ void k_rlc_note_per_item(uint32_t* stats, uint32_t items, uint32_t groups) {
+  atomicAdd(stats + 1, items);
+  atomicAdd(stats + 2, groups);
+}
+}  // namespace ed
+
+// a pass that the caller routes to the per-item kernels without trying the combination: only the statistics
+extern "C" hipError_t edk_rlc_note_per_item(uint32_t* stats, size_t n, hipStream_t stream) {
+  if (stats && n) hipLaunchKernelGGL(ed::k_rlc_note_per_item, dim3(1), dim3(1), 0, stream, stats, (uint32_t)n,
+                                     (uint32_t)((n + ed::RLC_G - 1) / ed::RLC_G));
+  return hipGetLastError();
+}
+
 extern "C" size_t edk_rlc_ws_bytes(size_t capacity) { return capacity ? rlc_carve(capacity).total : 0; }
 
 extern "C" hipError_t edk_verify_rlc(uint8_t* ok, uint32_t* stats, const edk_verify_src* srcp, size_t n,

@@ -20,6 +20,14 @@ def device_set(engine):
     return engine.init_devices()
 
 
+@pytest.fixture(autouse=True)
+def always_combine(engine):
+    """small batches through the combination itself (by default calls below 3 x 2^17 items use the per-item kernels)"""
+    engine.set_rlc_min_items(0)
+    yield
+    engine.set_rlc_min_items(3 << 17)
+
+
 @pytest.mark.parametrize("case", range(24))
 def test_fuzz_against_the_oracle(engine, oracle, device_set, case):
     rng = np.random.default_rng(1000 + case)

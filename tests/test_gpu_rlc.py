@@ -21,6 +21,15 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+@pytest.fixture(autouse=True)
+def always_combine(engine):
+    """these tests drive the combination itself with small batches: switch off the routing of calls below 3 x 2^17
+    items to the per-item kernels (test_small_calls_go_to_the_per_item_kernels checks the default)"""
+    engine.set_rlc_min_items(0)
+    yield
+    engine.set_rlc_min_items(3 << 17)
+
+
 def _signed(engine, n, seed, mlen=32):
     rng = np.random.default_rng(seed)
     sk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
@@ -43,6 +52,21 @@ def test_all_valid_groups_pass_by_combination(engine):
         s2[i, 32:] = np.frombuffer((int.from_bytes(sig[i, 32:].tobytes(), "little") + k * L).to_bytes(32, "little"), np.uint8)
     ok, st = engine.ed25519_verify_batch_rlc(dev(s2), dev(pk), dev(msg), msg_len=32, return_stats=True)
     assert bool(ok.all()) and st == (n, 0, 0, 4)
+
+
+def test_small_calls_go_to_the_per_item_kernels(engine):
+    """default routing: below 3 x 2^17 items the combination's own latency (hash tree, Horner) costs more than it
+    saves, so the call uses the per-item kernels; from 3 x 2^17 on it combines"""
+    engine.set_rlc_min_items(3 << 17)
+    sig, pk, msg = _signed(engine, 400000, 11)
+    n = 3 * G
+    ok, st = engine.ed25519_verify_batch_rlc(dev(sig[:n]), dev(pk[:n]), dev(msg[:n]), msg_len=32, return_stats=True)
+    assert bool(ok.all()) and st == (0, n, 3, 0)
+    ok, st = engine.ed25519_verify_batch_rlc(sig[:n], pk[:n], msg[:n], msg_len=32, return_stats=True)      # host-pointer pipeline
+    assert bool(ok.all()) and st == (0, n, 3, 0)
+    n = 400000
+    ok, st = engine.ed25519_verify_batch_rlc(dev(sig), dev(pk), dev(msg), msg_len=32, return_stats=True)
+    assert bool(ok.all()) and st == (n, 0, 0, 49)
 
 
 def test_tiny_batches(engine):
