@@ -395,7 +395,8 @@ def main():
             okr, st = ed.ed25519_verify_batch_rlc(vs, vp, vm, msg_len=32, return_stats=True)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        good = all_ranks_agree(bool(okr.all()) and st[0] == m and st[1] == 0, world, device)
+        # (calls below the library's break-even size skip the combination: then st[1] == m)
+        good = all_ranks_agree(bool(okr.all()) and st[0] + st[1] == m and (st[0] == m or m < (3 << 17)), world, device)
         correct = correct and good
         secondary["verify_rlc_all_valid"] = {
             "metric": "ed25519 verifies/sec, opt-in batch verification, the config's items before corruption (all valid)",
