@@ -95,6 +95,24 @@ k_x25519_ladder(uint32_t* accout, const uint8_t* scalars, const uint8_t* points,
   for (int j = 0; j < 10; j++) { o[j * BLOCK] = x2.v[j]; o[(20 + j) * BLOCK] = z2.v[j]; }
 }
 
+// small passes: four lanes per item (quad_lanes.h: x25519_ladder_quad); writes the same workspace slots
+constexpr size_t X25519_QUAD_MAX_N = (size_t)1 << 13;
+__global__ void __launch_bounds__(BLOCK, 2)
+k_x25519_ladder_quad(uint32_t* accout, const uint8_t* scalars, const uint8_t* points, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 2;          // quads are all-or-nothing
+  if (i >= n) return;
+  const int q = (int)(threadIdx.x & 3u);
+  uint32_t s[8], pt[8];
+  load32(s, scalars, i, 32);
+  load32(pt, points, i, 32);
+  fe r;
+  x25519_ladder_quad(r, s, pt, q);
+  if (q > 1) return;                             // lane 0: x2 -> the X slot, lane 1: z2 -> the Z slot
+  uint32_t* o = accout + (i / BLOCK) * (ACC_WORDS * BLOCK) + (i % BLOCK) + (q == 0 ? 0 : 20) * BLOCK;
+#pragma unroll
+  for (int j = 0; j < 10; j++) o[j * BLOCK] = r.v[j];
+}
+
 __global__ void __launch_bounds__(64) k_init_tables(uint32_t* base16, uint32_t* comb) {
   const int id = blockIdx.x * 64 + threadIdx.x;
   if (id >= TABLE_BASE16_ENTRIES + TABLE_COMB_ENTRIES) return;
@@ -624,7 +642,11 @@ hipError_t edk_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* point
                       const edk_fixed_ws* ws, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   const unsigned blocks = (unsigned)((n + BLOCK - 1) / BLOCK);
-  hipLaunchKernelGGL(k_x25519_ladder, dim3(blocks), dim3(BLOCK), 0, stream, ws->acc, scalars, points, n);
+  if (n <= X25519_QUAD_MAX_N)
+    hipLaunchKernelGGL(k_x25519_ladder_quad, dim3((unsigned)((4 * n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, ws->acc,
+                       scalars, points, n);
+  else
+    hipLaunchKernelGGL(k_x25519_ladder, dim3(blocks), dim3(BLOCK), 0, stream, ws->acc, scalars, points, n);
   hipLaunchKernelGGL(k_x25519_finish, dim3((blocks + FINISH_K - 1) / FINISH_K), dim3(BLOCK), 0, stream, out, ws->acc, n);
   return hipGetLastError();
 }

@@ -289,4 +289,73 @@ ED_DEV void verify_main_quad(fe& r, const uint32_t* digits, const uint32_t* tab,
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// X25519 with four lanes per item, for SMALL passes (lanes.h: x25519_ladder_lane is the one-lane form):
+// a ladder step is nine multiplications / squarings deep with one lane; with the quad holding
+// (x2, z2, x3, z3) it is three deep:
+//   stage 0   (x3 - z3)(x2 + z2) | (x3 + z3)(x2 - z2) | P^2 | Q^2      P, Q = sum and difference of the point to double
+//   stage 1   (da + cb)^2        | (da - cb)^2        | aa bb | 121665 (aa - bb)
+//   stage 2         -            | e (121665 e + aa)  |   -   | (da - cb)^2 x1
+// Same field expressions as x25519.c:60-94 (montgomery) and the same swap logic as the one-lane form, so the
+// same (x2 : z2); about 740 dependent instructions per step instead of 1260.  Leaves x2 in lane 0 and z2 in
+// lane 1 of the quad.
+// ---------------------------------------------------------------------------------------------
+ED_DEV void x25519_ladder_quad(fe& r, uint32_t s[8], const uint32_t pt[8], int q) {
+  fe x1, k121665;
+  clamp(s);
+  fe_frombytes(x1, pt);                          // bit 255 folded in as +19, not masked (fld.c:153)
+  fe_set(k121665, 121665);
+  r = x1;                                        // (x2, z2, x3, z3) = (1, 0, x1, 1)
+  { fe one, zero; fe_set(one, 1); fe_set(zero, 0); fe_cmov(r, one, q == 0 || q == 3); fe_cmov(r, zero, q == 1); }
+  uint32_t cur = s[7] << 1;                      // bit 255 of the clamped scalar is 0: start at bit 254
+  uint32_t swap = 0;
+#pragma unroll 1
+  for (int t = 254; t >= 0; t--) {
+    const uint32_t bit = cur >> 31;
+    cur <<= 1;
+    if ((t & 31) == 0 && t != 0) {
+      const int w = (t >> 5) - 1;
+      cur = w == 6 ? s[6] : w == 5 ? s[5] : w == 4 ? s[4] : w == 3 ? s[3] : w == 2 ? s[2] : w == 1 ? s[1] : s[0];
+    }
+    swap ^= bit;
+    fe x2, z2, x3, z3, a, b, c, d, u, v, m1;
+    fe_quad_perm<0, 0, 0, 0>(x2, r); fe_quad_perm<1, 1, 1, 1>(z2, r);
+    fe_quad_perm<2, 2, 2, 2>(x3, r); fe_quad_perm<3, 3, 3, 3>(z3, r);
+    fe_add(a, x2, z2);                           // 2u
+    fe_sub(b, x2, z2);                           // 3u
+    fe_add(c, x3, z3);                           // 2u
+    fe_sub(d, x3, z3);                           // 3u
+    // stage 0: lane 0: d * a, lane 1: c * b, lane 2: P * P, lane 3: Q * Q  (the point to double: slot 3 when exchanged)
+    u = d; v = a;
+    fe_cmov(u, c, q == 1); fe_cmov(v, b, q == 1);
+    { fe p2 = a, q2 = b; fe_cmov(p2, c, swap != 0); fe_cmov(q2, d, swap != 0);
+      fe_cmov(u, p2, q == 2); fe_cmov(v, p2, q == 2); fe_cmov(u, q2, q == 3); fe_cmov(v, q2, q == 3); }
+    swap = bit;
+    fe_mul(m1, u, v);                            // (da, cb, aa, bb)
+    fe da, cb, aa, bb, e, m2;
+    fe_quad_perm<0, 0, 0, 0>(da, m1); fe_quad_perm<1, 1, 1, 1>(cb, m1);
+    fe_quad_perm<2, 2, 2, 2>(aa, m1); fe_quad_perm<3, 3, 3, 3>(bb, m1);
+    fe_sub(e, aa, bb);                           // 3u
+    // stage 1: lane 0: (da + cb)^2, lane 1: (da - cb)^2, lane 2: aa * bb, lane 3: e * 121665
+    fe_add(u, da, cb);                           // 2u
+    v = u;
+    { fe t1; fe_sub(t1, da, cb); fe_cmov(u, t1, q == 1); fe_cmov(v, t1, q == 1); }       // 3u
+    fe_cmov(u, aa, q == 2); fe_cmov(v, bb, q == 2);
+    fe_cmov(u, e, q == 3); fe_cmov(v, k121665, q == 3);
+    fe_mul(m2, u, v);                            // (x3', (da - cb)^2, x2', 121665 e)
+    // stage 2: lane 1: e * (121665 e + aa), lane 3: (da - cb)^2 * x1; lanes 0 and 2 idle (they compute lane 1's product too)
+    fe w, tsq, m3;
+    fe_add(w, m2, aa);                           // lane 3: 121665 e + aa, 2u
+    fe_quad_perm<3, 3, 3, 3>(w, w);
+    fe_quad_perm<1, 1, 1, 1>(tsq, m2);
+    u = e; v = w;
+    fe_cmov(u, tsq, q == 3); fe_cmov(v, x1, q == 3);
+    fe_mul(m3, u, v);                            // lane 1: z2', lane 3: z3'
+    // (x2', z2', x3', z3') = (m2 of lane 2, m3, m2 of lane 0, m3)
+    fe_quad_perm<2, 1, 0, 3>(r, m2);
+    fe_cmov(r, m3, (q & 1) != 0);
+  }
+}
+
 }  // namespace ed
