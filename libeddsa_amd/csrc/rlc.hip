@@ -26,14 +26,16 @@
 // never passes.
 //
 // The multi-scalar multiplication is a bucket method laid out for the wavefront: one workgroup of 128
-// lanes per (group, byte-window); lane b owns bucket b+1 (signed 8-bit digits): the workgroup
-// counting-sorts the group's digits of that window in LDS (17 KB), each lane adds the points of its
-// bucket (mixed additions, ed_add_pc's 7 M), and the weighted sum of the 128 buckets is two
-// log-step scans through LDS; k_rlc_final then runs Horner over the 48 window points of each group
-// (four lanes per point, quad_lanes.h: 248 dependent doublings are pure latency).
+// lanes per (group, byte-window), 128 buckets for the signed 8-bit digits: the workgroup counting-sorts
+// the group's digits of that window in LDS (17 KB), hands the buckets to its lanes by size rank (the 64
+// fullest to wave 0: a wave takes as long as its fullest lane), each lane adds the points of its bucket
+// (mixed additions, ed_add_pc's 7 M), and the weighted sum of the 128 buckets is two log-step scans
+// through LDS; k_rlc_final then runs Horner over the 48 window points of each group (four lanes per
+// point, quad_lanes.h: 248 dependent doublings are pure latency).
 // -A_i has 32 windows (z_i t_i mod l), -R_i 16 (z_i), B one entry per group and window: 48 mixed
 // additions per item instead of the per-item kernel's 252 doublings + 80 additions.  Algorithmic HBM
-// bytes: the same 129 per item as verify.
+// bytes: the same 129 per item as verify.  The per-lane arithmetic (decoding and routing flags,
+// coefficients, digit recoding) is in rlc_lanes.h, which the host-check build also compiles.
 #include "eddsa_kernels.h"
 #include "rlc_lanes.h"
 #include "quad_lanes.h"
@@ -42,7 +44,7 @@ namespace ed {
 
 constexpr int RLC_G = 8192;                      // items per group
 constexpr int RLC_BUCKETS = 128;                 // |digit| in 1..128
-constexpr int RLC_SEG_WINDOWS = 1;               // windows per segment
+constexpr int RLC_SEG_WINDOWS = 1;               // windows per workgroup (2 and 4, with the doublings in between, measured slower)
 constexpr int RLC_SEGS_A = RLC_WINDOWS_A / RLC_SEG_WINDOWS, RLC_SEGS_R = RLC_WINDOWS_R / RLC_SEG_WINDOWS;
 constexpr int RLC_SEGS = RLC_SEGS_A + RLC_SEGS_R;   // window points per group: 32 for -A, 16 for -R
 constexpr int RLC_BLOCK = 256;
