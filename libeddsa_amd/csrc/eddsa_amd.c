@@ -837,22 +837,25 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
                 if ((rc = pipe_grow(&p->d_msgs[s], &p->msgs_cap[s], need))) goto out;
             }
         }
-        if (ragged) TRY(hipMemcpyAsync(p->d_off, j->msg_off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, p->up));
+        /* a call of one chunk has nothing to overlap: everything in order on the kernels' stream, one sync */
+        const int single = nchunks == 1;
+        hipStream_t up = single ? p->exec : p->up, down = single ? p->exec : p->down;
+        if (ragged) TRY(hipMemcpyAsync(p->d_off, j->msg_off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, up));
         for (size_t k = 0; k < nchunks; k++) {
             const int s = (int)(k & 1);
             const size_t lo = k * chunk, m = n - lo < chunk ? n - lo : chunk;
             /* upload chunk k into slot s once the kernels of chunk k-2 have consumed it */
-            if (k >= 2) TRY(hipStreamWaitEvent(p->up, p->exec_done[s], 0));
+            if (k >= 2) TRY(hipStreamWaitEvent(up, p->exec_done[s], 0));
             for (int i = 0; i < j->n_in; i++)
-                TRY(hipMemcpyAsync(p->d_in[s][i], j->in[i] + lo * j->in_w[i], m * j->in_w[i], hipMemcpyHostToDevice, p->up));
+                TRY(hipMemcpyAsync(p->d_in[s][i], j->in[i] + lo * j->in_w[i], m * j->in_w[i], hipMemcpyHostToDevice, up));
             if (j->has_msgs) {
                 const size_t bytes = ragged ? (size_t)j->msg_off[n] : m * j->msg_len;
                 const uint8_t *src = ragged ? j->msgs : j->msgs + lo * j->msg_len;
-                if (bytes) TRY(hipMemcpyAsync(p->d_msgs[s], src, bytes, hipMemcpyHostToDevice, p->up));
+                if (bytes) TRY(hipMemcpyAsync(p->d_msgs[s], src, bytes, hipMemcpyHostToDevice, up));
             }
-            TRY(hipEventRecord(p->in_ready[s], p->up));
+            if (!single) TRY(hipEventRecord(p->in_ready[s], up));
             /* kernels of chunk k */
-            TRY(hipStreamWaitEvent(p->exec, p->in_ready[s], 0));
+            if (!single) TRY(hipStreamWaitEvent(p->exec, p->in_ready[s], 0));
             {
                 struct hjob jj = *j;
                 jj.stats = d_stats;
@@ -861,29 +864,29 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
                             j->msg_len, m, p->exec);
             }
             if (rc) goto out;
-            TRY(hipEventRecord(p->exec_done[s], p->exec));
+            if (!single) TRY(hipEventRecord(p->exec_done[s], p->exec));
             /* download chunk k-1 (its kernels were launched one iteration ago) */
             if (k >= 1) {
                 const size_t plo = (k - 1) * chunk;
-                TRY(hipStreamWaitEvent(p->down, p->exec_done[s ^ 1], 0));
+                TRY(hipStreamWaitEvent(down, p->exec_done[s ^ 1], 0));
                 TRY(hipMemcpyAsync(j->out + plo * j->out_w, (uint8_t *)p->d_out + plo * j->out_w, chunk * j->out_w,
-                                   hipMemcpyDeviceToHost, p->down));
+                                   hipMemcpyDeviceToHost, down));
             }
         }
         {
             const size_t plo = (nchunks - 1) * chunk;
-            TRY(hipStreamWaitEvent(p->down, p->exec_done[(nchunks - 1) & 1], 0));
+            if (!single) TRY(hipStreamWaitEvent(down, p->exec_done[(nchunks - 1) & 1], 0));
             TRY(hipMemcpyAsync(j->out + plo * j->out_w, (uint8_t *)p->d_out + plo * j->out_w, (n - plo) * j->out_w,
-                               hipMemcpyDeviceToHost, p->down));
-            if (j->stats) TRY(hipMemcpyAsync(j->stats, d_stats, 16, hipMemcpyDeviceToHost, p->down));
+                               hipMemcpyDeviceToHost, down));
+            if (j->stats) TRY(hipMemcpyAsync(j->stats, d_stats, 16, hipMemcpyDeviceToHost, down));
         }
         /* secrets do not outlive the call in the staging buffers */
         if (j->wipe & WIPE_IN0)
             for (int s = 0; s < nslots; s++) TRY(hipMemsetAsync(p->d_in[s][0], 0, chunk * j->in_w[0], p->exec));
-        TRY(hipStreamSynchronize(p->down));
+        if (!single) TRY(hipStreamSynchronize(down));
         if (j->wipe & WIPE_OUT) TRY(hipMemsetAsync(p->d_out, 0, n * j->out_w, p->exec));
         TRY(hipStreamSynchronize(p->exec));
-        TRY(hipStreamSynchronize(p->up));
+        if (!single) TRY(hipStreamSynchronize(up));
     }
 out:
     if (rc && p->ready) { (void)hipStreamSynchronize(p->up); (void)hipStreamSynchronize(p->exec); (void)hipStreamSynchronize(p->down); }
