@@ -39,6 +39,7 @@ from .api import (  # noqa: F401
     set_offcurve_mode,
     set_profiling,
     set_rlc_min_items,
+    set_verify_algo,
     shutdown,
     sk_ed25519_to_x25519_batch,
     verify_phase_ms,

@@ -81,6 +81,12 @@ def set_offcurve_mode(exact=True):
     library().eddsa_amd_set_offcurve_mode(2 if exact == 2 else int(bool(exact)))
 
 
+def set_verify_algo(algo=0):
+    """0 (default): half-length scalars for verify passes above 2^14 items, full-length windows below; 1: always
+    full-length; 2: always half-length.  Same verdicts; a measurement and test aid."""
+    library().eddsa_amd_set_verify_algo(int(algo))
+
+
 def set_rlc_min_items(items):
     """ed25519_verify_batch_rlc calls with fewer items go straight to the per-item kernels (default 3 x 2^17,
     the measured break-even; 0 = always try the combination)"""

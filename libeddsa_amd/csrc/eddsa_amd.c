@@ -80,6 +80,7 @@ struct engine {
 static pthread_rwlock_t g_table = PTHREAD_RWLOCK_INITIALIZER;
 static struct engine *g_eng[MAX_DEVICES];
 static int g_default = -1;            /* device of the host-pointer entry points; -1: the caller's current device at first use */
+static int g_verify_algo = 0;         /* eddsa_amd_set_verify_algo: 0 by pass size (default), 1 full-length windows, 2 half-length scalars */
 static int g_offcurve_mode = 1;       /* eddsa_amd_set_offcurve_mode: 0 reject, 1 exact (default), 2 all exact */
 static int g_profiling;               /* record marks around the three verify kernels */
 static size_t g_rlc_min_items = (size_t)3 << 17;   /* eddsa_amd_set_rlc_min_items: smaller calls go to the per-item kernels */
@@ -136,11 +137,14 @@ static void ws_release(struct vslot *v)
     if (v->ws.table) (void)hipFree(v->ws.table);
     if (v->ws.acc) (void)hipFree(v->ws.acc);
     if (v->ws.flags) (void)hipFree(v->ws.flags);
+    if (v->ws.hdigits) (void)hipFree(v->ws.hdigits);
+    if (v->ws.rtable) (void)hipFree(v->ws.rtable);
     if (v->ws.offlist) (void)hipFree(v->ws.offlist);
     if (v->ws.offcount) (void)hipFree(v->ws.offcount);
     if (v->ws.exact_pad) (void)hipFree(v->ws.exact_pad);
     v->ws.capacity = 0;
     v->ws.digits = v->ws.table = v->ws.acc = v->ws.offlist = v->ws.offcount = v->ws.exact_pad = NULL;
+    v->ws.hdigits = v->ws.rtable = NULL;
     v->ws.flags = NULL;
 }
 
@@ -196,6 +200,8 @@ static int ws_reserve(struct vslot *v, size_t items)
     TRY(hipMalloc((void **)&v->ws.digits, cap * 16 * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&v->ws.table, cap / VERIFY_TILE * (size_t)VERIFY_TABLE_WORDS_PER_TILE * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&v->ws.acc, cap * ACC_WORDS * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&v->ws.hdigits, cap * EDK_HALF_DIGIT_WORDS * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&v->ws.rtable, cap / VERIFY_TILE * (size_t)VERIFY_TABLE_WORDS_PER_TILE * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&v->ws.flags, cap));
     TRY(hipMalloc((void **)&v->ws.offlist, cap * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&v->ws.offcount, 256));
@@ -284,7 +290,7 @@ static int engine_create(int device)
     TRY(hipSetDevice(device));
     TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { rc = ERR_NOT_GFX950; goto out; }
-    TRY(hipMalloc((void **)&e->base16, (size_t)TABLE_BASE16_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&e->base16, (size_t)2 * TABLE_BASE16_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&e->comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&e->comb_img, COMB_IMG_WORDS * sizeof(uint32_t)));
     for (int i = 0; i < VERIFY_SLOTS; i++) {
@@ -422,6 +428,16 @@ out:
  * SHA-512(R || A || M), i.e. on a fixed point of a random function, and saves the ~1 ms the exact
  * pass costs whenever a batch contains such keys.  ALL (2): every item takes the reference-order
  * path and the windowed evaluation's result is ignored -- slow (latency-bound), for self-checks. */
+/* Which evaluation ed25519_verify* uses (same verdicts; a measurement and test aid).  0 (default): half-length
+ * scalars (csrc/halve.h) for passes of more than 2^14 items, full-length windows with four lanes per item below;
+ * 1: full-length windows always; 2: half-length scalars always. */
+void eddsa_amd_set_verify_algo(int algo)
+{
+    pthread_rwlock_wrlock(&g_table);
+    g_verify_algo = algo == 1 || algo == 2 ? algo : 0;
+    pthread_rwlock_unlock(&g_table);
+}
+
 void eddsa_amd_set_offcurve_mode(int exact)
 {
     pthread_rwlock_wrlock(&g_table);
@@ -496,6 +512,7 @@ static int verify_on(struct engine *e, uint8_t *ok, const edk_verify_src *all, s
     rc = ws_reserve(v, n < CHUNK_MAX ? n : CHUNK_MAX);
     if (rc) goto unlock;
     v->ws.exact_offcurve = g_offcurve_mode;
+    v->ws.algo = g_offcurve_mode ? g_verify_algo : 1;   /* the reject mode has no exact path for the items the pair search gives up on */
     /* the slot may have served another stream: order this pass behind its previous one */
     TRY(hipStreamWaitEvent(st, v->free, 0));
     for (size_t done = 0; done < n; done += CHUNK_MAX) {
@@ -612,6 +629,7 @@ static int rlc_on(struct engine *e, uint8_t *ok, uint32_t *stats, const edk_veri
     if (!rc) rc = rws_reserve(v, n < CHUNK_MAX ? n : CHUNK_MAX);
     if (rc) goto unlock;
     v->ws.exact_offcurve = g_offcurve_mode ? g_offcurve_mode : 1;
+    v->ws.algo = g_verify_algo;
     TRY(hipStreamWaitEvent(st, v->free, 0));
     for (size_t done = 0; done < n; done += CHUNK_MAX) {
         size_t m = n - done < CHUNK_MAX ? n - done : CHUNK_MAX;

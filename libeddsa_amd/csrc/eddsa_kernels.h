@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 #ifndef TABLE_BASE16_ENTRIES      /* also defined, identically, by lanes.h for the device side */
-#define TABLE_BASE16_ENTRIES 32769 /* k*B, k = 0..32768 */
+#define TABLE_BASE16_ENTRIES 32769 /* k*B, k = 0..32768; the table holds twice that: k*2^128*B follows */
 #define COMB_W 6                  /* signed window width of the fixed-base comb (the reference's is 4, ed.c:397-430) */
 #define COMB_HALF (1 << (COMB_W - 1))          /* digits d in [-COMB_HALF, COMB_HALF - 1] */
 #define COMB_DIGITS (COMB_W == 4 ? 64 : COMB_W == 5 ? 52 : 44)   /* digits of x + offset: 64 x 4, 52 x 5 or 44 x 6 bits */
@@ -21,6 +21,7 @@
 #endif
 #define VERIFY_TABLE_WORDS_PER_TILE (VERIFY_TABLE_ENTRIES * 40 * 256)
 #define VERIFY_TILE 256            /* items per tile = threads per block */
+#define EDK_HALF_DIGIT_WORDS 20     /* = HALF_DIGIT_WORDS of lanes.h */
 #define ACC_WORDS 40               /* point workspace per item: X, Y, Z and one slot for the finish kernels' prefix products */
 
 #ifdef __cplusplus
@@ -37,12 +38,15 @@ typedef struct edk_verify_ws {
   uint32_t* digits;   /* capacity * 16 words */
   uint32_t* table;    /* capacity / 256 tiles * VERIFY_TABLE_WORDS_PER_TILE words */
   uint32_t* acc;      /* capacity * ACC_WORDS words */
+  uint32_t* hdigits;  /* capacity * EDK_HALF_DIGIT_WORDS words: the half-length scalars (kernels.hip k_verify_halve) */
+  uint32_t* rtable;   /* like table: 0..8 times -R' */
   uint8_t* flags;     /* capacity bytes */
   uint32_t* offlist;  /* capacity words: items whose key is off the curve */
   uint32_t* offcount; /* 1 word */
   uint32_t* exact_pad;/* EDK_EXACT_PAD_BYTES: per-lane scratchpad of k_verify_exact */
   hipStream_t side;   /* the exact path runs here, beside the main kernel */
   hipEvent_t ev_prepared, ev_exact;
+  int algo;           /* 0: half-length scalars for passes above 2^14 items, full-length windows below; 1: always full-length; 2: always half-length */
   int exact_offcurve; /* 1: replay the reference's chain for off-curve keys (default); 0: reject them; 2: replay for every item */
 } edk_verify_ws;
 

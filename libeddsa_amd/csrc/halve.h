@@ -1,0 +1,161 @@
+// halve.h - half-length scalars for Ed25519 verification, one item per lane.
+//
+// The reference checks  encode(S*B - t*A) == R-bytes  (ed25519-sha512.c:166-180), which costs 252 doublings
+// per item because t is a 253-bit scalar on a variable base.  For an item whose A and R both decode to curve
+// points (R strictly: lanes.h verify_half_point_lane) that check is the group equation Q := S*B - t*A - R' = 0,
+// and for any integer u coprime to the group order 8l it is equivalent to u*Q = 0:
+//     (u S mod l)*B  -  v*A  -  u*R'  =  0        with  v = u t  (mod 8 l)
+// (B has order l; A and R' have orders dividing 8l, so v*A = u*t*A also when A has a torsion component).
+// The extended Euclidean algorithm on (8l, t), stopped half way, gives such a pair with |u|, v < 2^134
+// (Antipa, Brown, Gallant, Lambert, Struik, Vanstone: "Accelerated verification of ECDSA signatures", SAC 2005,
+// there mod the prime group order; mod 8l and with u odd here so that the equivalence is exact for every input
+// on the curve, which is what bit-exactness with the reference's cofactorless check needs).  The evaluation is
+// then 132 doublings and three half-length scalars.  Items for which no suitable pair turns up in the two
+// candidates examined, or whose expansion has a quotient of 31 bits or more before that (together about 1 in
+// 10^4 random t), are handed to the exact path like off-curve keys.
+//
+// Public data only (verification): control flow and timing depend on t.
+#pragma once
+#include "sc25519.h"
+
+namespace ed {
+
+constexpr int HALF_WINDOWS = 34;                 // 4-bit signed windows of v and |u|: values < 2^134
+constexpr int HALF_BITS = 134;
+constexpr int HALF_RETRY_MIN_BITS = 122;         // an even u is retried one step later only if r >= 2^122: |u'| <= 8l / r < 2^134
+
+// 8 l, little-endian words
+ED_DEV constexpr uint32_t halve_N(int i) {
+  constexpr uint32_t N[8] = {0xe7ae9f68u, 0xc09318d2u, 0x17bce6b2u, 0xa6f7cef5u, 0x00000000u, 0x00000000u, 0x00000000u, 0x80000000u};
+  return N[i];
+}
+
+ED_DEV double halve_to_double(const uint32_t w[8]) {
+  double d = (double)w[7];
+#pragma unroll
+  for (int k = 6; k >= 0; k--) d = __builtin_fma(d, 4294967296.0, (double)w[k]);
+  return d;                                      // relative error < 2^-50
+}
+
+// a < b as 256-bit numbers
+ED_DEV bool halve_less(const uint32_t a[8], const uint32_t b[8]) {
+  int64_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) { c += (int64_t)a[k] - (int64_t)b[k]; c >>= 32; }
+  return c != 0;
+}
+
+// a < 2^bits
+ED_DEV bool halve_below(const uint32_t a[8], int bits) {
+  uint32_t hi = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (32 * k >= bits) hi |= a[k];
+    else if (32 * (k + 1) > bits) hi |= a[k] >> (bits - 32 * k);
+  }
+  return hi == 0;
+}
+
+// One half-step of the Euclidean algorithm: (ra, ua) -= q * (rb, ub) with q = an underestimate (>= 1) of
+// floor(ra / rb), for lanes with `active` set (which have ra >= rb > 0); q = 0 otherwise.  ua, ub: 160-bit
+// two's complement.  Returns true, and changes nothing, when the quotient does not fit 31 bits (one step in
+// 2^31: the caller gives the item up).
+ED_DEV bool halve_reduce(uint32_t ra[8], uint32_t ua[5], const uint32_t rb[8], const uint32_t ub[5], bool active) {
+  const double a = halve_to_double(ra);
+  double b = halve_to_double(rb);
+  b = active ? b : 1.0;
+  double qd = __builtin_floor((a / b) * (1.0 - 0x1p-40));   // never above the true quotient
+  const bool big = active && !(qd < 2147483647.0);
+  qd = qd < 2147483647.0 ? qd : 0.0;
+  uint32_t q = (uint32_t)qd;
+  q = q < 1u ? 1u : q;
+  q = active && !big ? q : 0u;
+  uint64_t carry = 0;
+  int64_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    carry += (uint64_t)q * rb[k];
+    c += (int64_t)ra[k] - (int64_t)(uint32_t)carry;
+    ra[k] = (uint32_t)c;
+    c >>= 32;
+    carry >>= 32;
+  }
+  ED_CHECK(c == 0 && carry == 0);                // q <= floor(ra / rb): no borrow out
+  carry = 0;
+  c = 0;
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    carry += (uint64_t)q * ub[k];
+    c += (int64_t)ua[k] - (int64_t)(uint32_t)carry;
+    ua[k] = (uint32_t)c;
+    c >>= 32;
+    carry >>= 32;
+  }
+  return big;
+}
+
+// |u| < 2^134 for a 160-bit two's complement u; mag = |u|, neg = u < 0
+ED_DEV bool halve_magnitude(uint32_t mag[5], bool& neg, const uint32_t u[5]) {
+  neg = (u[4] >> 31) != 0;
+  int64_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    c += neg ? -(int64_t)u[k] : (int64_t)u[k];
+    mag[k] = (uint32_t)c;
+    c >>= 32;
+  }
+  return (mag[4] >> (HALF_BITS - 128)) == 0;
+}
+
+// t (< l, eight words) -> v (five words, 0 <= v < 2^134), |u| (five words, < 2^134, u odd), uneg = (u < 0)
+// with v = u t (mod 8 l).  Returns false when the item has to take the exact path instead.
+ED_DEV bool halve_scalar_lane(uint32_t vw[5], uint32_t uw[5], bool& uneg, const uint32_t tw[8]) {
+  uint32_t r0[8], r1[8], u0[5], u1[5];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { r0[k] = halve_N(k); r1[k] = tw[k]; }
+#pragma unroll
+  for (int k = 0; k < 5; k++) { u0[k] = 0; u1[k] = 0; }
+  u1[0] = 1;
+  // the candidate is the smaller remainder with its cofactor; which = 1: (r1, u1), 0: (r0, u0)
+  bool done = false, good = false, tried = false;
+  int which = 1;
+  // examine the candidate a completed step has produced (lanes with `fresh` set)
+  auto examine = [&](const uint32_t r[8], const uint32_t u[5], bool fresh, int idx) {
+    if (!fresh || done) return;
+    if (!halve_below(r, HALF_BITS)) return;
+    if (u[0] & 1u) {
+      uint32_t m[5]; bool ng;
+      good = halve_magnitude(m, ng, u);
+      done = true; which = idx;
+    } else if (tried || halve_below(r, HALF_RETRY_MIN_BITS)) {
+      done = true; good = false; which = idx;
+    } else {
+      tried = true;
+    }
+  };
+  examine(r1, u1, true, 1);
+  for (int it = 0; it < 160; it++) {
+    if (done) break;
+    {                                            // r0 by r1
+      const bool act = !done && !halve_less(r0, r1);
+      if (halve_reduce(r0, u0, r1, u1, act)) { done = true; good = false; }
+      examine(r0, u0, act && halve_less(r0, r1), 0);
+    }
+    {                                            // r1 by r0
+      const bool act = !done && !halve_less(r1, r0);
+      if (halve_reduce(r1, u1, r0, u0, act)) { done = true; good = false; }
+      examine(r1, u1, act && halve_less(r1, r0), 1);
+    }
+  }
+  good = good && done;
+  uint32_t usel[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    vw[k] = which ? r1[k] : r0[k];
+    usel[k] = which ? u1[k] : u0[k];
+  }
+  halve_magnitude(uw, uneg, usel);
+  return good;
+}
+
+}  // namespace ed

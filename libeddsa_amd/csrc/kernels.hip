@@ -115,11 +115,13 @@ k_x25519_ladder_quad(uint32_t* accout, const uint8_t* scalars, const uint8_t* po
 
 __global__ void __launch_bounds__(64) k_init_tables(uint32_t* base16, uint32_t* comb) {
   const int id = blockIdx.x * 64 + threadIdx.x;
-  if (id >= TABLE_BASE16_ENTRIES + TABLE_COMB_ENTRIES) return;
+  if (id >= 2 * TABLE_BASE16_ENTRIES + TABLE_COMB_ENTRIES) return;
   if (id < TABLE_BASE16_ENTRIES) {
     table_entry_lane(base16 + (size_t)TABLE_ENTRY_WORDS * id, (uint32_t)id, 0);
+  } else if (id < 2 * TABLE_BASE16_ENTRIES) {     // k * 2^128 * B: the high half of s' in the half-length verification
+    table_entry_lane(base16 + (size_t)TABLE_ENTRY_WORDS * id, (uint32_t)(id - TABLE_BASE16_ENTRIES), 128);
   } else {
-    const int c = id - TABLE_BASE16_ENTRIES;      // comb[i][k], c = COMB_HALF i + k
+    const int c = id - 2 * TABLE_BASE16_ENTRIES;  // comb[i][k], c = COMB_HALF i + k
     table_entry_lane(comb + TABLE_ENTRY_WORDS * c, (uint32_t)(c % COMB_HALF) + 1, 2u * COMB_W * (uint32_t)(c / COMB_HALF));
   }
 }
@@ -252,6 +254,56 @@ k_verify_main(const uint32_t* digits, const uint32_t* table, const uint32_t* bas
   for (int j = 0; j < 10; j++) {
     o[j * BLOCK] = acc.X.v[j]; o[(10 + j) * BLOCK] = acc.Y.v[j]; o[(20 + j) * BLOCK] = acc.Z.v[j];
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Half-length verification (halve.h), the route of passes above QUAD_MAIN_MAX_N items:
+//   k_verify_prepare    as above
+//   k_verify_halve      (u, v) with v = u t mod 8l from t; s' = |u| S; decompress R strictly, table of 0..8 * -R'
+//   k_verify_main_half  132 doublings + 68 + 16 additions, neutral-element test, verdict byte
+// No finish kernel: "is the neutral element" needs no inversion.  Items the pair search gives up on join the
+// off-curve keys on the exact path's work list (so the list is complete only after k_verify_halve).
+// Workspace beside the one above: hdigits [item][HALF_DIGIT_WORDS], rtable [item][entry 9][word 40];
+// flags bit 0: this path owns the verdict, bit 2: R is a canonical encoding of a curve point.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK, 2)
+k_verify_halve(const uint8_t* sigs, size_t sig_stride, size_t n, const uint32_t* digits, uint32_t* hdigits,
+               uint32_t* rtable, uint8_t* flags, uint32_t* offlist, uint32_t* offcount) {
+  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const size_t item = i < n ? i : n - 1;
+  const uint8_t fl = flags[i];
+  uint32_t tdig[8], sdig[8], hd[HALF_DIGIT_WORDS];
+  {
+    const uint4* d = reinterpret_cast<const uint4*>(digits + 16 * i);
+    const uint4 a = d[0], b = d[1], c = d[2], e = d[3];
+    tdig[0] = a.x; tdig[1] = a.y; tdig[2] = a.z; tdig[3] = a.w; tdig[4] = b.x; tdig[5] = b.y; tdig[6] = b.z; tdig[7] = b.w;
+    sdig[0] = c.x; sdig[1] = c.y; sdig[2] = c.z; sdig[3] = c.w; sdig[4] = e.x; sdig[5] = e.y; sdig[6] = e.z; sdig[7] = e.w;
+  }
+  const bool found = verify_half_scalars_lane(hd, tdig, sdig);
+  uint4* o = reinterpret_cast<uint4*>(hdigits + HALF_DIGIT_WORDS * i);
+#pragma unroll
+  for (int q = 0; q < HALF_DIGIT_WORDS / 4; q++) o[q] = make_uint4(hd[4 * q], hd[4 * q + 1], hd[4 * q + 2], hd[4 * q + 3]);
+  uint32_t rw[8];
+  load32(rw, sigs, item, sig_stride);
+  const bool rvalid = verify_half_point_lane(rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), rw);
+  const bool mine = (fl & 1) != 0 && found;
+  flags[i] = (uint8_t)((mine ? 1 : 0) | (rvalid ? 4 : 0));
+  if ((fl & 1) != 0 && !found && i < n) offlist[atomicAdd(offcount, 1u)] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(BLOCK, 2)
+k_verify_main_half(uint8_t* ok, const uint32_t* hdigits, const uint32_t* table, const uint32_t* rtable,
+                   const uint32_t* base16, const uint8_t* flags, size_t n, int exact_offcurve) {
+  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;   // < workspace capacity
+  const bool neutral = verify_half_main_lane(hdigits + HALF_DIGIT_WORDS * i, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
+                                             rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16);
+  if (i >= n) return;
+  const uint8_t fl = flags[i];
+  if ((fl & 1) == 0) {                           // the exact path owns this verdict (or, in reject mode, nobody does)
+    if (!exact_offcurve) ok[i] = 0;
+    return;
+  }
+  ok[i] = (uint8_t)(neutral && (fl & 4) != 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -632,7 +684,7 @@ using namespace ed;
 extern "C" {
 
 hipError_t edk_init_tables(uint32_t* base16, uint32_t* comb, uint32_t* comb_img, hipStream_t stream) {
-  const int total = TABLE_BASE16_ENTRIES + TABLE_COMB_ENTRIES;
+  const int total = 2 * TABLE_BASE16_ENTRIES + TABLE_COMB_ENTRIES;
   hipLaunchKernelGGL(k_init_tables, dim3((total + 63) / 64), dim3(64), 0, stream, base16, comb);
   hipLaunchKernelGGL(k_init_comb_image, dim3((COMB_ROWS * COMB_IMG_ENTRIES + 63) / 64), dim3(64), 0, stream, comb_img, comb);
   return hipGetLastError();
@@ -660,8 +712,13 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   if (marks) (void)hipEventRecord(marks[0], stream);
   hipLaunchKernelGGL(k_verify_prepare, dim3(blocks), dim3(BLOCK), 0, stream, src, n, ws->digits, ws->table, ws->flags, ws->offlist, ws->offcount,
                      ws->exact_offcurve == 2);
+  // algo 0: half-length scalars above QUAD_MAIN_MAX_N items, full-length windows below; 1 / 2 force one of them
+  const bool half = ws->algo == 2 || (ws->algo == 0 && n > QUAD_MAIN_MAX_N);
+  if (half)
+    hipLaunchKernelGGL(k_verify_halve, dim3(blocks), dim3(BLOCK), 0, stream, src.sigs, src.sig_stride, n, ws->digits, ws->hdigits,
+                       ws->rtable, ws->flags, ws->offlist, ws->offcount);
   if (marks) (void)hipEventRecord(marks[1], stream);
-  // the exact path depends only on prepare: both of its kernels run beside the main kernel on the side stream
+  // the exact path depends only on what came before: both of its kernels run beside the main kernel on the side stream
   const size_t fast_items = (size_t)QUAD_MAX_ITEMS;
   if (ws->exact_offcurve) {
     const size_t qi = n < fast_items ? n : fast_items;
@@ -675,15 +732,21 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
                        ws->exact_pad);
     (void)hipEventRecord(ws->ev_exact, ws->side);
   }
-  if (n <= QUAD_MAIN_MAX_N)
-    hipLaunchKernelGGL(k_verify_main_quad, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0,
-                       stream, ws->digits, ws->table, base16, ws->acc, n);
-  else
-    hipLaunchKernelGGL(k_verify_main, dim3(blocks), dim3(BLOCK), MAIN_LDS_RESERVE, stream, ws->digits, ws->table, base16, ws->acc);
-  if (marks) (void)hipEventRecord(marks[2], stream);
-  hipLaunchKernelGGL(k_verify_finish, dim3((blocks + FINISH_K - 1) / FINISH_K), dim3(BLOCK), 0, stream, ok, src.sigs,
-                     src.sig_stride, ws->acc, ws->flags, n, ws->exact_offcurve);
-  if (marks) (void)hipEventRecord(marks[3], stream);
+  if (half) {
+    hipLaunchKernelGGL(k_verify_main_half, dim3(blocks), dim3(BLOCK), MAIN_LDS_RESERVE, stream, ok, ws->hdigits, ws->table,
+                       ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
+    if (marks) { (void)hipEventRecord(marks[2], stream); (void)hipEventRecord(marks[3], stream); }
+  } else {
+    if (n <= QUAD_MAIN_MAX_N)
+      hipLaunchKernelGGL(k_verify_main_quad, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0,
+                         stream, ws->digits, ws->table, base16, ws->acc, n);
+    else
+      hipLaunchKernelGGL(k_verify_main, dim3(blocks), dim3(BLOCK), MAIN_LDS_RESERVE, stream, ws->digits, ws->table, base16, ws->acc);
+    if (marks) (void)hipEventRecord(marks[2], stream);
+    hipLaunchKernelGGL(k_verify_finish, dim3((blocks + FINISH_K - 1) / FINISH_K), dim3(BLOCK), 0, stream, ok, src.sigs,
+                       src.sig_stride, ws->acc, ws->flags, n, ws->exact_offcurve);
+    if (marks) (void)hipEventRecord(marks[3], stream);
+  }
   if (ws->exact_offcurve) {
     (void)hipStreamWaitEvent(stream, ws->ev_exact, 0);   // complete when both paths are
     if (n > fast_items)   // possibly more listed keys than the fast route takes: the rest, strided, one kernel

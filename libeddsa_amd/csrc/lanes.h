@@ -18,6 +18,7 @@
 #include "ge25519.h"
 #include "sc25519.h"
 #include "sha512.h"
+#include "halve.h"
 
 #define TABLE_BASE16_ENTRIES 32769 /* k*B, k = 0..32768: 16-bit signed windows of S (4 MiB, L2/MALL) */
 #define COMB_W 6                  /* signed window width of the fixed-base comb (the reference's is 4, ed.c:397-430) */
@@ -246,12 +247,10 @@ ED_DEV void verify_s_lane(uint32_t sw[8]) {
   sc_to_words(sw, s);
   words_add_pattern(sw, 0x80008000u);
 }
-// -A and its multiples 0..8 in cached form at tab; returns whether A is on the curve
-ED_DEV bool verify_table_lane(uint32_t* tab, const uint32_t aw[8]) {
-  bool oncurve;
-  ge a, p, q;
+// a and its multiples 0..8 in cached form at tab
+ED_DEV void verify_table_point_lane(uint32_t* tab, const ge& a) {
+  ge p, q;
   ge_cached c1, c;
-  ge_frombytes(a, oncurve, aw, true);
   ge_neutral(p);
   ge_to_cached(c, p);  cached_store(tab, 0, c);
   ge_to_cached(c1, a); cached_store(tab, 1, c1);
@@ -269,6 +268,13 @@ ED_DEV bool verify_table_lane(uint32_t* tab, const uint32_t aw[8]) {
   ge_to_cached(c, q);  cached_store(tab, 5, c);
   ge_dbl(p, p, true);                            // 8
   ge_to_cached(c, p);  cached_store(tab, 8, c);
+}
+// -A and its multiples 0..8 in cached form at tab; returns whether A is on the curve
+ED_DEV bool verify_table_lane(uint32_t* tab, const uint32_t aw[8]) {
+  bool oncurve;
+  ge a;
+  ge_frombytes(a, oncurve, aw, true);
+  verify_table_point_lane(tab, a);
   return oncurve;
 }
 
@@ -324,6 +330,133 @@ ED_DEV bool verify_encode_lane(const fe& X, const fe& Y, const fe& zinv, const u
 #pragma unroll
   for (int q = 0; q < 8; q++) diff |= cw[q] ^ rw[q];
   return diff == 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ed25519 verify with half-length scalars (halve.h): the same verdicts from 132 doublings.
+//     acc = 16*acc + sigma*d_i*(-A) + e_i*(-R')  [+ f_j*B + g_j*(2^128 B) when i = 4j, j < 8]
+// over 34 four-bit windows, d = digits of v, e = digits of |u|, sigma = sign of u, f / g = the 16-bit digits
+// of the low / high half of s' = |u| S mod l; accept iff the result is the neutral element and R was a
+// canonical encoding.  hd (HALF_DIGIT_WORDS per item): v + 0x88.. [0,5) | |u| + 0x88.. [5,10) |
+// s' + 0x8000.. [10,18) | bit 0 of [18]: u < 0.
+// ---------------------------------------------------------------------------------------------
+#define HALF_DIGIT_WORDS 20
+
+// 160-bit add of the 34-nibble pattern 0x88..8
+ED_DEV void half_add_pattern(uint32_t w[5]) {
+  uint64_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    c += (uint64_t)w[k] + (k < 4 ? 0x88888888u : 0x00000088u);
+    w[k] = (uint32_t)c;
+    c >>= 32;
+  }
+}
+
+// tdig / sdig: the digit words k_verify_prepare wrote (t + 0x88.., S mod l + 0x8000..).  Returns false when the
+// item has to take the exact path.
+ED_DEV bool verify_half_scalars_lane(uint32_t hd[HALF_DIGIT_WORDS], const uint32_t tdig[8], const uint32_t sdig[8]) {
+  uint32_t tw[8], sw[8], vw[5], uw[5], u8[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { tw[k] = tdig[k]; sw[k] = sdig[k]; }
+  words_sub_pattern(tw, 0x88888888u);
+  words_sub_pattern(sw, 0x80008000u);
+  bool uneg;
+  const bool good = halve_scalar_lane(vw, uw, uneg, tw);
+#pragma unroll
+  for (int k = 0; k < 8; k++) u8[k] = k < 5 ? uw[k] : 0;
+  sc s, u, su;
+  sc_from_words<8>(s, sw);
+  sc_from_words<8>(u, u8);
+  sc_mul(su, s, u);                              // |u| S mod l
+  sc_to_words(sw, su);
+  words_add_pattern(sw, 0x80008000u);
+  half_add_pattern(vw);
+  half_add_pattern(uw);
+#pragma unroll
+  for (int k = 0; k < 5; k++) { hd[k] = vw[k]; hd[5 + k] = uw[k]; }
+#pragma unroll
+  for (int k = 0; k < 8; k++) hd[10 + k] = sw[k];
+  hd[18] = uneg ? 1u : 0u;
+  hd[19] = 0;
+  return good;
+}
+
+// Table of 0..8 times -R' at tab, R' the point R encodes.  Returns whether R is what ed_export can produce
+// (ed.c:155-169: y < p, a curve point, and not x = 0 with the sign bit set): only then can the reference's byte
+// comparison (ed25519-sha512.c:176-180) succeed, and then it is the comparison of the points.
+ED_DEV bool verify_half_point_lane(uint32_t* tab, const uint32_t rw[8]) {
+  bool oncurve;
+  ge r;
+  ge_frombytes(r, oncurve, rw, true);
+  bool top = (rw[7] & 0x7fffffffu) == 0x7fffffffu && rw[0] >= 0xffffffedu;
+#pragma unroll
+  for (int k = 1; k < 7; k++) top = top && rw[k] == 0xffffffffu;
+  const bool zero_x_signed = (rw[7] >> 31) != 0 && fe_iszero(r.X);
+  verify_table_point_lane(tab, r);
+  return oncurve && !top && !zero_x_signed;
+}
+
+// a table entry as loaded (ten 16-byte words), so that the loads can be issued a window ahead of their use
+struct cached_raw { word4 q[10]; };
+ED_DEV void cached_load_raw(cached_raw& r, const uint32_t* tab, uint32_t entry) {
+  const word4* p = reinterpret_cast<const word4*>(tab + entry * VERIFY_ENTRY_WORDS);
+#pragma unroll
+  for (int q = 0; q < 10; q++) r.q[q] = p[q];
+}
+ED_DEV void cached_from_raw(ge_cached& c, const cached_raw& r) {
+  uint32_t w[40];
+#pragma unroll
+  for (int q = 0; q < 10; q++) { w[4 * q] = r.q[q].x; w[4 * q + 1] = r.q[q].y; w[4 * q + 2] = r.q[q].z; w[4 * q + 3] = r.q[q].w; }
+#pragma unroll
+  for (int j = 0; j < 10; j++) { c.ymx.v[j] = w[j]; c.ypx.v[j] = w[10 + j]; c.t2d.v[j] = w[20 + j]; c.z2.v[j] = w[30 + j]; }
+}
+
+// returns whether the combination is the neutral element.  The two per-item table entries of a window are
+// requested before the window's four doublings and consumed after them (the kernel runs two waves per SIMD, which
+// is not enough to hide a miss to HBM per addition otherwise).
+ED_DEV bool verify_half_main_lane(const uint32_t* hd, const uint32_t* tab_a, const uint32_t* tab_r, const uint32_t* base16) {
+  ge acc;
+  ge_neutral(acc);
+  const bool uneg = (hd[18] & 1u) != 0;
+#pragma unroll 1
+  for (int w = HALF_WINDOWS - 1; w >= 0; w--) {
+    const int dv = (int)((hd[w >> 3] >> (4 * (w & 7))) & 15u) - 8;
+    const int du = (int)((hd[5 + (w >> 3)] >> (4 * (w & 7))) & 15u) - 8;
+    cached_raw ra, rr;
+    cached_load_raw(ra, tab_a, (uint32_t)(dv < 0 ? -dv : dv));
+    cached_load_raw(rr, tab_r, (uint32_t)(du < 0 ? -du : du));
+    const bool base_here = (w & 3) == 0 && w < 32;
+    if (w != HALF_WINDOWS - 1) {
+#pragma unroll 1
+      for (int k = 0; k < 4; k++) ge_dbl(acc, acc, k == 3);
+    }
+    {
+      ge_cached c;
+      cached_from_raw(c, ra);
+      ge_cached_cneg(c, (dv < 0) != uneg);       // sigma * d * (-A)
+      ge_add_cached(acc, acc, c, true);
+      cached_from_raw(c, rr);
+      ge_cached_cneg(c, du < 0);                 // e * (-R')
+      ge_add_cached(acc, acc, c, base_here);
+    }
+    if (base_here) {
+      const int j = w >> 2;                      // digit j of s' sits at bit 16 j, digit 8 + j at bit 128 + 16 j
+#pragma unroll 1
+      for (int h = 0; h < 2; h++) {
+        const int jj = j + 8 * h;
+        const int dig = (int)((hd[10 + (jj >> 1)] >> (16 * (jj & 1))) & 0xffffu) - 32768;
+        const uint32_t mag = (uint32_t)(dig < 0 ? -dig : dig);
+        ge_niels nb;
+        niels_load(nb, base16 + TABLE_ENTRY_WORDS * ((size_t)mag + (h ? (size_t)TABLE_BASE16_ENTRIES : 0)));
+        ge_niels_cneg(nb, dig < 0);
+        ge_add_niels(acc, acc, nb, h == 0);
+      }
+    }
+  }
+  fe d;
+  fe_sub(d, acc.Y, acc.Z);
+  return fe_iszero(acc.X) && fe_iszero(d) && !fe_iszero(acc.Z);
 }
 
 // ---------------------------------------------------------------------------------------------

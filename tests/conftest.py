@@ -136,7 +136,7 @@ def hostcheck():
     d = os.path.join(ROOT, "tests", "host_check")
     lib = os.path.join(d, "libhostcheck.so")
     srcs = [os.path.join(d, "host_check.cpp")] + [os.path.join(ROOT, "libeddsa_amd", "csrc", f)
-                                                   for f in ("lanes.h", "rlc_lanes.h", "fe25519.h", "ge25519.h", "sc25519.h", "sha512.h")]
+                                                   for f in ("lanes.h", "halve.h", "rlc_lanes.h", "fe25519.h", "ge25519.h", "sc25519.h", "sha512.h")]
     if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DED_HOST_CHECK", "-Wno-unknown-pragmas",
                                "-I" + os.path.join(ROOT, "libeddsa_amd", "csrc"), srcs[0], "-o", lib])

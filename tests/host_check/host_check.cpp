@@ -34,8 +34,11 @@ struct Tables {
   // 16-byte aligned view of the base table (entries are read with 16-byte loads)
   uint32_t* b16() { return reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(base16.data()) + 15) & ~(uintptr_t)15); }
   std::vector<uint32_t> base16, comb;
-  Tables() : base16((size_t)TABLE_BASE16_ENTRIES * TABLE_ENTRY_WORDS + 32), comb(TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS) {
+  Tables() : base16((size_t)2 * TABLE_BASE16_ENTRIES * TABLE_ENTRY_WORDS + 32), comb(TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS) {
     for (int k = 0; k < TABLE_BASE16_ENTRIES; k++) table_entry_lane(b16() + (size_t)TABLE_ENTRY_WORDS * k, (uint32_t)k, 0);
+    // the second half, k * 2^128 * B (verify_half_main_lane): each entry by doubling the one before the shift
+    for (int k = 0; k < TABLE_BASE16_ENTRIES; k++)
+      table_entry_lane(b16() + (size_t)TABLE_ENTRY_WORDS * (TABLE_BASE16_ENTRIES + k), (uint32_t)k, 128);
     for (int c = 0; c < TABLE_COMB_ENTRIES; c++)
       table_entry_lane(&comb[TABLE_ENTRY_WORDS * c], (uint32_t)(c % COMB_HALF) + 1, 2u * COMB_W * (uint32_t)(c / COMB_HALF));
   }
@@ -75,6 +78,30 @@ int hc_verify(const uint8_t sig[64], const uint8_t pub[32], const uint8_t* msg, 
   fe zinv;
   fe_inv(zinv, acc.Z);
   return verify_encode_lane(acc.X, acc.Y, zinv, rw) ? 1 : 0;
+}
+
+// the half-length path (halve.h; k_verify_prepare + k_verify_halve + k_verify_main_half) for one item:
+// 0 / 1 = its verdict, 2 = the item is handed to the exact path (key off the curve, or no short pair)
+int hc_verify_half(const uint8_t sig[64], const uint8_t pub[32], const uint8_t* msg, size_t len) {
+  alignas(16) uint32_t tab[VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS], rtab[VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS];
+  uint32_t rw[8], sw[8], aw[8], tw[8], hd[HALF_DIGIT_WORDS];
+  rd(rw, sig); rd(sw, sig + 32); rd(aw, pub);
+  const bool oncurve = verify_prepare_lane(tw, sw, tab, rw, aw, msg, len);
+  const bool shortpair = verify_half_scalars_lane(hd, tw, sw);
+  const bool rvalid = verify_half_point_lane(rtab, rw);
+  if (!oncurve || !shortpair) return 2;
+  return verify_half_main_lane(hd, tab, rtab, tables().b16()) && rvalid ? 1 : 0;
+}
+
+// halve_scalar_lane: v (20 bytes), |u| (20 bytes), sign of u; returns whether a pair was found
+int hc_halve(uint8_t v[20], uint8_t u[20], int* uneg, const uint8_t t[32]) {
+  uint32_t tw[8], vw[5], uw[5];
+  rd(tw, t);
+  bool ng;
+  const bool good = halve_scalar_lane(vw, uw, ng, tw);
+  memcpy(v, vw, 20); memcpy(u, uw, 20);
+  *uneg = ng ? 1 : 0;
+  return good ? 1 : 0;
 }
 
 // the exact (reference-order) path, as k_verify_exact runs it for off-curve keys

@@ -329,3 +329,84 @@ def test_rlc_whole_group_by_double_and_add(hostcheck, oracle):
     p2 = pk.copy(); p2[11] = np.frombuffer((2).to_bytes(32, "little"), np.uint8)
     assert run(sig, p2, msg) == 0                               # a key that is no curve point: flagged
     assert hostcheck.hc_violations() == 0, hostcheck.hc_first_violation()
+
+
+# ---------------------------------------------------------------------------------------------
+# half-length verification (libeddsa_amd/csrc/halve.h)
+# ---------------------------------------------------------------------------------------------
+N8L = 8 * L
+
+
+def halve_model(t, th=134, retry_min=122):
+    """the rule of halve_scalar_lane on Python integers: (found, u, v)"""
+    r0, u0, r1, u1, tried = N8L, 0, t, 1, False
+    while True:
+        if r1 < (1 << th):
+            if u1 & 1:
+                return abs(u1) < (1 << th), u1, r1
+            if tried or r1 < (1 << retry_min):
+                return False, u1, r1
+            tried = True
+        q = r0 // r1
+        if q >= 1 << 31:
+            return False, u1, r1
+        r0, r1, u0, u1 = r1, r0 - q * r1, u1, u0 - q * u1
+
+
+def test_halved_scalar_pairs(hostcheck):
+    """v = u t (mod 8 l), u odd, both below 2^134, and the same pair as Euclid's algorithm on integers gives -
+    for random t, tiny and huge t, and t whose continued fraction has a giant quotient right at the half-way
+    point (those are the ones handed to the exact path)"""
+    rng = np.random.default_rng(77)
+    ts = [0, 1, 2, 3, 5, 8, L - 1, L - 2, L // 2, L // 3, (1 << 134) - 1, 1 << 134, (1 << 134) + 1, (1 << 127) + 12345]
+    ts += [N8L // k % L for k in (3, 5, 7, 9, 1000003, (1 << 61) - 1, (1 << 100) + 277, (1 << 125) + 1, (1 << 126) + 3, (1 << 128) + 51)]
+    ts += [((1 << 127) * k + 1) % L for k in (2, 6, 10)]
+    ts += [int.from_bytes(bytes(rng.integers(0, 256, 32, dtype=np.uint8)), "little") % L for _ in range(3000)]
+    found = 0
+    for t in ts:
+        v, u, neg = ctypes.create_string_buffer(20), ctypes.create_string_buffer(20), ctypes.c_int(0)
+        good = hostcheck.hc_halve(v, u, ctypes.byref(neg), le(t))
+        want, mu, mv = halve_model(t)
+        assert bool(good) == want, hex(t)
+        if good:
+            found += 1
+            ui = int.from_bytes(u.raw, "little") * (-1 if neg.value else 1)
+            vi = int.from_bytes(v.raw, "little")
+            assert (ui, vi) == (mu, mv), hex(t)
+            assert ui & 1 and abs(ui) < 1 << 134 and 0 <= vi < 1 << 134 and (ui * t - vi) % N8L == 0
+    assert found >= len(ts) - 12
+    no_violations(hostcheck)
+
+
+def test_verify_half_length_edges_and_torsion(hostcheck, golden):
+    """the half-length path on the reference-pinned edge cases and on the mixed-order keys / commitments of
+    verify_torsion.json (where u t A != (u t mod l) A, and a plain mod-l split would accept or reject wrongly):
+    same verdict as the reference whenever the path keeps the item (it hands off-curve keys to the exact path)"""
+    kept = 0
+    for c in golden("verify_edges.json") + golden("verify_torsion.json"):
+        msg = H(c["msg"])
+        got = hostcheck.hc_verify_half(H(c["sig"]), H(c["pub"]), msg, SZ(len(msg)))
+        if got == 2:
+            assert hostcheck.hc_verify_exact(H(c["sig"]), H(c["pub"]), msg, SZ(len(msg))) == int(c["accept"]), c["name"]
+        else:
+            kept += 1
+            assert got == int(c["accept"]), c["name"]
+    assert kept > 350
+    no_violations(hostcheck)
+
+
+def test_verify_half_length_random_against_oracle(hostcheck, oracle):
+    rng = np.random.default_rng(23)
+    rb = lambda n: bytes(rng.integers(0, 256, n, dtype=np.uint8))  # noqa: E731
+    for i in range(120):
+        sk, msg = rb(32), rb(int(rng.integers(0, 150)))
+        pk = oracle.genpub(sk)
+        sig = oracle.sign(sk, pk, msg)
+        flip = bytearray(sig); flip[int(rng.integers(0, 64))] ^= 1 << int(rng.integers(0, 8))
+        cases = [(sig, pk), (rb(64), pk), (bytes(flip), pk), (sig[:32] + le((int.from_bytes(sig[32:], "little") + L) % 2**256), pk),
+                 (sig, rb(32)), (sig[:31] + bytes([sig[31] ^ 0x80]) + sig[32:], pk), (le(P + 1) + sig[32:], pk)]
+        for s, p_ in cases:
+            got = hostcheck.hc_verify_half(s, p_, msg, SZ(len(msg)))
+            want = int(oracle.verify(s, p_, msg))
+            assert got == want or (got == 2 and hostcheck.hc_verify_exact(s, p_, msg, SZ(len(msg))) == want)
+    no_violations(hostcheck)

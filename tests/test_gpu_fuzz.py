@@ -74,6 +74,15 @@ def test_fuzz_against_the_oracle(engine, oracle, device_set, case):
         got_h = engine.ed25519_verify_batch(sig, pk, msgs, msg_len=mlen)
         got_d = engine.ed25519_verify_batch(dev(sig), dev(pk), dev(msgs), msg_len=mlen).cpu().numpy()
     assert np.array_equal(got_h, want) and np.array_equal(got_d, want)
+    # both evaluations (full-length windows, half-length scalars) whatever the pass size
+    for algo in (1, 2):
+        engine.set_verify_algo(algo)
+        try:
+            got_a = (engine.ed25519_verify_batch(sig, pk, msgs, msg_off=off) if ragged else
+                     engine.ed25519_verify_batch(dev(sig), dev(pk), dev(msgs), msg_len=mlen).cpu().numpy())
+        finally:
+            engine.set_verify_algo(0)
+        assert np.array_equal(got_a, want), algo
     # the opt-in batch verification (random linear combination per group of 8192, per-item fallback) and the
     # single-process multi-device form return the same verdict bytes
     if ragged:

@@ -1,0 +1,106 @@
+"""GPU tests of the half-length verification (libeddsa_amd/csrc/halve.h: u (S B - t A - R) = 0 with half-length
+u, v = u t mod 8l; k_verify_halve + k_verify_main_half), the default route of verify passes above 2^14 items: the
+same verdict bytes as the reference, as the full-length kernels and as the oracle, on the reference-pinned edge
+cases, on mixed-order keys and commitments, and on seeded batches large enough to contain items the pair search
+hands to the exact path (about 1 in 10^4)."""
+import numpy as np
+import pytest
+
+import workload  # tools/ is on sys.path (conftest)
+
+pytestmark = pytest.mark.gpu
+H = bytes.fromhex
+
+
+def arr(rows):
+    return np.frombuffer(b"".join(rows), np.uint8).reshape(len(rows), -1).copy()
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(autouse=True)
+def restore(engine):
+    yield
+    engine.set_verify_algo(0)
+    engine.set_offcurve_mode(True)
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+def test_edge_and_torsion_vectors_on_either_evaluation(engine, golden, algo):
+    """verify_edges.json (S + k l, non-canonical / small-order / off-curve A, non-canonical R, flipped bits) and
+    verify_torsion.json (A = a B + T, R = r B + T' for all 64 pairs of points of order dividing 8: accepted
+    exactly when t T + T' = 0, which a pair (u, v) with v = u t mod l only - not mod 8l - would get wrong)"""
+    engine.set_verify_algo(algo)
+    cases = golden("verify_edges.json") + golden("verify_torsion.json")
+    msgs = [H(c["msg"]) for c in cases]
+    off = np.zeros(len(msgs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(m) for m in msgs])
+    blob = np.frombuffer(b"".join(msgs), np.uint8).copy()
+    sig, pub = arr([H(c["sig"]) for c in cases]), arr([H(c["pub"]) for c in cases])
+    want = np.array([c["accept"] for c in cases], np.uint8)
+    got = engine.ed25519_verify_batch(sig, pub, blob, msg_off=off)
+    bad = [cases[i]["name"] for i in np.nonzero(got != want)[0]]
+    assert not bad, bad
+    got = engine.ed25519_verify_batch(dev(sig), dev(pub), dev(blob), msg_off=dev(off.astype(np.int64))).cpu().numpy()
+    assert np.array_equal(got, want)
+    tors = np.array([c["accept"] for c in golden("verify_torsion.json")])
+    assert 20 <= tors.sum() <= 40 and len(tors) == 192
+
+
+def test_half_full_and_oracle_agree_on_a_large_seeded_batch(engine, oracle):
+    """2^17 + 333 items of the config-2 recipe (1/16 corrupted, edge vectors spliced in, some off-curve keys; about
+    a dozen items whose t has no short pair): default route (half-length), forced full-length, forced half-length
+    and the oracle return the same bytes"""
+    n = (1 << 17) + 333
+    sk, msg = workload.sign_inputs(n, seed=9, config=2)
+    pk = engine.ed25519_genpub_batch(sk)
+    sig = engine.ed25519_sign_batch(sk, pk, msg)
+    expect = workload.corrupt_for_verify(sig, pk, msg, seed=9, config=2)
+    want = oracle.verify_batch(sig, pk, msg, msg.shape[1])
+    assert np.array_equal(want, expect)
+    d = dev(sig), dev(pk), dev(msg)
+    for algo in (0, 2, 1):
+        engine.set_verify_algo(algo)
+        got = engine.ed25519_verify_batch(*d, msg_len=msg.shape[1]).cpu().numpy()
+        assert np.array_equal(got, want), (algo, np.nonzero(got != want)[0][:10])
+    engine.set_verify_algo(0)
+    assert np.array_equal(engine.ed25519_verify_batch(sig, pk, msg, msg_len=msg.shape[1]), want)      # host path, chunked
+
+
+@pytest.mark.parametrize("n", [1, 2, 255, 257, 4099])
+def test_forced_half_length_on_small_and_ragged_passes(engine, oracle, n):
+    rng = np.random.default_rng(4000 + n)
+    sk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    lens = rng.integers(0, 150, n)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    msgs = rng.integers(0, 256, int(off[-1]), dtype=np.uint8)
+    pk = oracle.genpub_batch(sk)
+    sig = engine.ed25519_sign_batch(dev(sk), dev(pk), dev(msgs), msg_off=dev(off.astype(np.int64))).cpu().numpy()
+    kind = rng.integers(0, 6, n)
+    for i in np.nonzero(kind == 1)[0]: sig[i, rng.integers(0, 64)] ^= 1 << rng.integers(0, 8)
+    for i in np.nonzero(kind == 2)[0]: pk[i, rng.integers(0, 32)] ^= 1 << rng.integers(0, 8)
+    g = np.nonzero(kind == 3)[0]
+    pk[g] = rng.integers(0, 256, (len(g), 32), dtype=np.uint8)
+    want = np.array([oracle.verify(sig[i].tobytes(), pk[i].tobytes(), msgs[int(off[i]):int(off[i + 1])].tobytes())
+                     for i in range(n)], np.uint8)
+    engine.set_verify_algo(2)
+    assert np.array_equal(engine.ed25519_verify_batch(sig, pk, msgs, msg_off=off), want)
+    engine.set_verify_algo(1)
+    assert np.array_equal(engine.ed25519_verify_batch(sig, pk, msgs, msg_off=off), want)
+
+
+def test_reject_mode_keeps_every_on_curve_item(engine, oracle):
+    """set_offcurve_mode(False) has no exact path, so it must not use the half-length route (whose pair search gives
+    up on a few items): on a batch without off-curve keys it still returns the reference's verdicts"""
+    n = 1 << 16
+    sk, msg = workload.sign_inputs(n, seed=12, config=2)
+    pk = engine.ed25519_genpub_batch(sk)
+    sig = engine.ed25519_sign_batch(sk, pk, msg)
+    sig[5::16, 3] ^= 4
+    want = oracle.verify_batch(sig, pk, msg, msg.shape[1])
+    engine.set_offcurve_mode(False)
+    engine.set_verify_algo(2)
+    assert np.array_equal(engine.ed25519_verify_batch(sig, pk, msg, msg_len=msg.shape[1]), want)

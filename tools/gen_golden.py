@@ -194,6 +194,73 @@ def gen_verify_edges():
     print(f"verify_edges.json: {len(cases)} cases, {acc} accepted by the reference")
 
 
+# ---------------------------------------------------------------- 3b. mixed-order keys and commitments
+# plain affine Edwards arithmetic (test-data construction only; the verdicts below come from the reference)
+D_ED = (-121665 * pow(121666, P - 2, P)) % P
+BY = 4 * pow(5, P - 2, P) % P
+
+
+def ed_xrecover(y, sign):
+    x2 = (y * y - 1) * pow(D_ED * y * y + 1, P - 2, P) % P
+    x = pow(x2, (P + 3) // 8, P)
+    if (x * x - x2) % P:
+        x = x * pow(2, (P - 1) // 4, P) % P
+    assert (x * x - x2) % P == 0
+    return P - x if (x & 1) != sign else x
+
+
+def ed_add_affine(p1, p2):
+    (x1, y1), (x2, y2) = p1, p2
+    k = D_ED * x1 * x2 * y1 * y2 % P
+    return ((x1 * y2 + x2 * y1) * pow(1 + k, P - 2, P) % P, (y1 * y2 + x1 * x2) * pow(1 - k, P - 2, P) % P)
+
+
+def ed_mul_affine(k, pt):
+    acc = (0, 1)
+    while k:
+        if k & 1:
+            acc = ed_add_affine(acc, pt)
+        pt = ed_add_affine(pt, pt)
+        k >>= 1
+    return acc
+
+
+def ed_enc(pt):
+    return le(pt[1] | ((pt[0] & 1) << 255))
+
+
+def ed_dec(enc):
+    v = int.from_bytes(enc, "little")
+    y, sign = v & (2**255 - 1), v >> 255
+    return (ed_xrecover(y, sign) if y not in (1, P - 1) else 0, y)
+
+
+def gen_verify_torsion():
+    """A = a B + T_A, R = r B + T_R for every pair of points T_A, T_R of order dividing 8, S = r + t a: the
+    reference (cofactorless, no subgroup check) accepts exactly when t T_A + T_R = 0, i.e. depending on t mod 8.
+    Also the same with S + l and with R replaced by its non-canonical or sign-flipped spelling where one exists."""
+    Bpt = (ed_xrecover(BY, 0), BY)
+    tors = [ed_dec(e) for e in small_order_points()]
+    cases = []
+    rnd = lambda tag: int.from_bytes(hashlib.sha512(b"libeddsa-amd torsion " + tag).digest(), "little") % L  # noqa: E731
+    for ia, ta in enumerate(tors):
+        for ir, tr in enumerate(tors):
+            for mi in range(3):
+                tag = b"%d %d %d" % (ia, ir, mi)
+                a, r = rnd(b"a" + tag), rnd(b"r" + tag)
+                A = ed_enc(ed_add_affine(ed_mul_affine(a, Bpt), ta))
+                R = ed_enc(ed_add_affine(ed_mul_affine(r, Bpt), tr))
+                msg = b"torsion probe " + tag
+                t = int.from_bytes(hashlib.sha512(R + A + msg).digest(), "little") % L
+                S = (r + t * a) % L
+                sig = R + le(S if mi != 2 else S + L)
+                cases.append({"name": "A+T%d R+T%d m%d" % (ia, ir, mi), "sig": sig.hex(), "pub": A.hex(), "msg": msg.hex(),
+                              "accept": verify(sig, A, msg)})
+    json.dump(cases, open(os.path.join(GOLD, "verify_torsion.json"), "w"), indent=0)
+    acc = sum(c["accept"] for c in cases)
+    print(f"verify_torsion.json: {len(cases)} cases, {acc} accepted by the reference")
+
+
 # ---------------------------------------------------------------- 4. layer KATs
 class Ed(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int64 * 5) for n in ("x", "y", "t", "z")]
@@ -344,9 +411,13 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["digests"]:
         gen_batch_digests()
         sys.exit(0)
+    if sys.argv[1:] == ["torsion"]:
+        gen_verify_torsion()
+        sys.exit(0)
     gen_x25519_table()
     gen_ed25519_table()
     gen_verify_edges()
+    gen_verify_torsion()
     gen_layer_kats()
     gen_table_digest()
     gen_batch_digests()
