@@ -20,8 +20,9 @@ together with the opt-in batch verification on the config's items before corrupt
 `python -m torch.distributed.run`, started before this process touches the GPU) and relays rank 0's line.
 
 Prints ONE JSON line on rank 0 (see the driver contract), with two extra objects:
-  roofline      the dominant kernel (k_verify_main) against the integer-VALU multiply-issue
-                roofline SURVEY 8(d) prescribes for this path, plus the HBM view of the same launch
+  roofline      the verify pass (three kernels; the dominant one, k_verify_main_half, is broken out under
+                "dominant") against the integer-VALU multiply-issue roofline SURVEY 8(d) prescribes for
+                this path, plus the HBM view of the same launch
   cpu_baseline  the reference itself (oracle/_ref, compiled from its own sources) timed on this
                 box's host cores on a bounded sample of the same workload (N = 1 only)
 """
@@ -46,13 +47,12 @@ import workload  # noqa: E402
 
 # canonical 32x32->64 multiply counts per item (BASELINE.md "Work per item")
 MUL32_VERIFY = 312370
-MUL32_VERIFY_MAIN = 312370 - (255 * 55 + 19 * 100) - (254 * 55 + 13 * 100)  # minus ed_import, ed_export
 MUL32_X25519 = 202050
 MUL32_SIGN = 64570
 MUL32 = {"verify": MUL32_VERIFY, "x25519": MUL32_X25519, "sign": MUL32_SIGN}
 BYTES = {"verify": 129, "x25519": 96, "sign": 160}      # algorithmic HBM bytes per item
 UNIT = {"verify": "verifies/s", "x25519": "ops/s", "sign": "signs/s"}
-KERNELS = {"verify": "k_verify_main", "x25519": "k_x25519_ladder + k_x25519_finish", "sign": "k_sign_point + k_sign_finish"}
+KERNELS = {"verify": "k_verify_prepare + k_verify_halve + k_verify_main_half", "x25519": "k_x25519_ladder + k_x25519_finish", "sign": "k_sign_point + k_sign_finish"}
 # v_mad_u64_u32 issue peak: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz (profiles/r01_valu_rates.txt
 # measures 36-37 T lane-MAC/s at the clock the chip holds under this load)
 PEAK_TMUL32 = 256 * 4 * 16 * 2.4e9 / 1e12
@@ -112,8 +112,19 @@ def pmc_valu_busy(kernel):
     x 4 clocks (one VALU instruction per SIMD per 4 clocks, profiles/r01_valu_rates.txt) / (1024 SIMDs x
     GRBM_GUI_ACTIVE / 8 XCDs).  None when the profile lacks the counters."""
     try:
-        k = pmc_profile()["ed::" + kernel.split("+")[0].strip()]
-        return {"value": 4.0 * k["SQ_INSTS_VALU"] / (1024.0 * k["GRBM_GUI_ACTIVE"] / 8.0), "source": PMC_SOURCE}
+        ks = [pmc_profile()["ed::" + name.strip()] for name in kernel.split("+")]
+        return {"value": 4.0 * sum(k["SQ_INSTS_VALU"] for k in ks) / (1024.0 * sum(k["GRBM_GUI_ACTIVE"] for k in ks) / 8.0),
+                "source": PMC_SOURCE}
+    except (KeyError, TypeError, ZeroDivisionError):
+        return None
+
+
+def pmc_executed(kernel, items):
+    """VALU lane-instructions per item that `kernel` executed in the committed PMC pass (SQ_INSTS_VALU counts
+    wave-instructions, 64 lanes each)"""
+    try:
+        ks = [pmc_profile()["ed::" + name.strip()] for name in kernel.split("+")]
+        return {"value": 64.0 * sum(k["SQ_INSTS_VALU"] for k in ks) / items, "source": PMC_SOURCE}
     except (KeyError, TypeError, ZeroDivisionError):
         return None
 
@@ -267,19 +278,19 @@ def fixture_check(full, world, n, seed, config):
 
 
 def roofline_of(op, n, k_ms, phases, ms_per_step, passes):
-    """the dominant kernel against the integer-VALU multiply-issue roofline; for verify k_verify_main
-    (HIP events around it, averaged over the workspace passes) and the whole pass beside it"""
+    """the kernels of the op against the integer-VALU multiply-issue roofline, per launch of at most 2^20 items
+    (HIP events around the pass).  SURVEY 8(d): achieved = rate x the reference's canonical product count, so an
+    evaluation that needs fewer products than the reference's (verify: half-length scalars, windows, no final
+    inversion) scores above its executed-instruction share; "valu_busy" and "executed_valu_per_item" (PMC) say
+    what was actually issued."""
     kernel = KERNELS[op]
-    if op == "verify":
-        main_ms, k_mul32, items = phases[1], MUL32_VERIFY_MAIN, n / passes     # per launch of at most 2^20 items
-    else:
-        main_ms, k_mul32, items = k_ms, MUL32[op], n
+    main_ms, k_mul32, items = k_ms / passes, MUL32[op], n / passes
     achieved = items * k_mul32 / (main_ms * 1e-3) / 1e12
     r = {
         "bound": "valu", "kernel": kernel, "achieved": achieved, "peak": PEAK_TMUL32,
         "unit": "Tmul32/s", "frac": achieved / PEAK_TMUL32, "traffic": pmc_traffic(kernel),
-        "valu_busy": pmc_valu_busy(kernel), "kernel_ms": main_ms, "items_per_launch": items,
-        "canonical_mul32_per_item": k_mul32,
+        "valu_busy": pmc_valu_busy(kernel), "executed_valu_per_item": pmc_executed(kernel, 1 << 20),
+        "kernel_ms": main_ms, "items_per_launch": items, "canonical_mul32_per_item": k_mul32,
         "whole_pass": {"kernels_ms": k_ms, "canonical_mul32_per_item": MUL32[op],
                        "achieved": n * MUL32[op] / (k_ms * 1e-3) / 1e12,
                        "frac": n * MUL32[op] / (k_ms * 1e-3) / 1e12 / PEAK_TMUL32},
@@ -291,7 +302,10 @@ def roofline_of(op, n, k_ms, phases, ms_per_step, passes):
                 "algorithmic_bytes_per_item": BYTES[op]},
     }
     if phases:
-        r["phase_ms"] = {"k_verify_prepare": phases[0], "k_verify_main": phases[1], "k_verify_finish": phases[2]}
+        r["phase_ms"] = {"k_verify_prepare + k_verify_halve": phases[0], "k_verify_main_half": phases[1]}
+        r["dominant"] = {"kernel": "k_verify_main_half", "kernel_ms": phases[1], "share_of_pass": phases[1] / main_ms,
+                         "valu_busy": pmc_valu_busy("k_verify_main_half"),
+                         "executed_valu_per_item": pmc_executed("k_verify_main_half", 1 << 20)}
     return r
 
 

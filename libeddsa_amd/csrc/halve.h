@@ -56,15 +56,26 @@ ED_DEV bool halve_below(const uint32_t a[8], int bits) {
   return hi == 0;
 }
 
+// a / b for a >= 0, b > 0, to a relative error far below the 2^-40 margin of its caller: reciprocal estimate
+// (v_rcp_f64) and two Newton steps instead of the correctly rounded division's twenty instructions
+ED_DEV double halve_ratio(double a, double b) {
+#ifdef ED_HOST_CHECK
+  return a / b;
+#else
+  double y = __builtin_amdgcn_rcp(b);
+  y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+  y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+  return a * y;
+#endif
+}
+
 // One half-step of the Euclidean algorithm: (ra, ua) -= q * (rb, ub) with q = an underestimate (>= 1) of
-// floor(ra / rb), for lanes with `active` set (which have ra >= rb > 0); q = 0 otherwise.  ua, ub: 160-bit
-// two's complement.  Returns true, and changes nothing, when the quotient does not fit 31 bits (one step in
-// 2^31: the caller gives the item up).
-ED_DEV bool halve_reduce(uint32_t ra[8], uint32_t ua[5], const uint32_t rb[8], const uint32_t ub[5], bool active) {
-  const double a = halve_to_double(ra);
-  double b = halve_to_double(rb);
-  b = active ? b : 1.0;
-  double qd = __builtin_floor((a / b) * (1.0 - 0x1p-40));   // never above the true quotient
+// floor(ra / rb), for lanes with `active` set (which have ra >= rb > 0); q = 0 otherwise.  da, db = ra, rb as
+// doubles (halve_to_double).  ua, ub: 160-bit two's complement.  Returns true, and changes nothing, when the
+// quotient does not fit 31 bits (one step in 2^31: the caller gives the item up).
+ED_DEV bool halve_reduce(uint32_t ra[8], uint32_t ua[5], const uint32_t rb[8], const uint32_t ub[5], double da, double db, bool active) {
+  db = active ? db : 1.0;
+  double qd = __builtin_floor(halve_ratio(da, db) * (1.0 - 0x1p-40));   // never above the true quotient
   const bool big = active && !(qd < 2147483647.0);
   qd = qd < 2147483647.0 ? qd : 0.0;
   uint32_t q = (uint32_t)qd;
@@ -134,17 +145,24 @@ ED_DEV bool halve_scalar_lane(uint32_t vw[5], uint32_t uw[5], bool& uneg, const 
     }
   };
   examine(r1, u1, true, 1);
+  // r0 >= r1 here; from now on each half-step's comparison also tells the next one whether it has work
+  double d0 = halve_to_double(r0), d1 = halve_to_double(r1);
+  bool act = !done;                              // the half-step about to run has ra >= rb
   for (int it = 0; it < 160; it++) {
     if (done) break;
     {                                            // r0 by r1
-      const bool act = !done && !halve_less(r0, r1);
-      if (halve_reduce(r0, u0, r1, u1, act)) { done = true; good = false; }
-      examine(r0, u0, act && halve_less(r0, r1), 0);
+      if (halve_reduce(r0, u0, r1, u1, d0, d1, act)) { done = true; good = false; }
+      d0 = halve_to_double(r0);
+      const bool lt = halve_less(r0, r1);        // the step is complete
+      examine(r0, u0, act && lt, 0);
+      act = !done && lt;                         // then r1 > r0: the other half-step has work
     }
     {                                            // r1 by r0
-      const bool act = !done && !halve_less(r1, r0);
-      if (halve_reduce(r1, u1, r0, u0, act)) { done = true; good = false; }
-      examine(r1, u1, act && halve_less(r1, r0), 1);
+      if (halve_reduce(r1, u1, r0, u0, d1, d0, act)) { done = true; good = false; }
+      d1 = halve_to_double(r1);
+      const bool lt = halve_less(r1, r0);
+      examine(r1, u1, act && lt, 1);
+      act = !done && !halve_less(r0, r1);        // r0 >= r1: also after a half-step that had no work or left a partial quotient
     }
   }
   good = good && done;

@@ -247,24 +247,27 @@ ED_DEV void verify_s_lane(uint32_t sw[8]) {
   sc_to_words(sw, s);
   words_add_pattern(sw, 0x80008000u);
 }
-// a and its multiples 0..8 in cached form at tab
+// a (affine: Z = 1, as ge_frombytes leaves it) and its multiples 0..8 in cached form at tab; "+ a" is the
+// seven-multiplication mixed addition
 ED_DEV void verify_table_point_lane(uint32_t* tab, const ge& a) {
   ge p, q;
-  ge_cached c1, c;
+  ge_cached c;
+  ge_niels n1;
   ge_neutral(p);
   ge_to_cached(c, p);  cached_store(tab, 0, c);
-  ge_to_cached(c1, a); cached_store(tab, 1, c1);
+  ge_to_cached(c, a);  cached_store(tab, 1, c);
+  n1.ymx = c.ymx; n1.ypx = c.ypx; n1.t2d = c.t2d;
   ge_dbl(p, a, true);                            // 2
   ge_to_cached(c, p);  cached_store(tab, 2, c);
-  ge_add_cached(q, p, c1, true);                 // 3
+  ge_add_niels(q, p, n1, true);                  // 3
   ge_to_cached(c, q);  cached_store(tab, 3, c);
   ge_dbl(p, p, true);                            // 4
   ge_to_cached(c, p);  cached_store(tab, 4, c);
   ge_dbl(q, q, true);                            // 6
   ge_to_cached(c, q);  cached_store(tab, 6, c);
-  ge_add_cached(q, q, c1, true);                 // 7
+  ge_add_niels(q, q, n1, true);                  // 7
   ge_to_cached(c, q);  cached_store(tab, 7, c);
-  ge_add_cached(q, p, c1, true);                 // 5
+  ge_add_niels(q, p, n1, true);                  // 5
   ge_to_cached(c, q);  cached_store(tab, 5, c);
   ge_dbl(p, p, true);                            // 8
   ge_to_cached(c, p);  cached_store(tab, 8, c);

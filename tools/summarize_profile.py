@@ -57,6 +57,6 @@ for f in glob.glob(os.path.join(src, "bench_stats*.log")):
     if line:
         open(os.path.join(dst, f"{tag}_{os.path.basename(f)[:-4]}.json"), "w").write(line[-1])
 print(open(os.path.join(dst, f"{tag}_kernel_stats.csv")).read() if rows else "no stats")
-m = out.get("ed::k_verify_main", {})
+m = out.get("ed::k_verify_main_half", {})
 if m:
     print({k: m[k] for k in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE", "VGPR_Count", "Scratch_Size") if k in m})
