@@ -20,6 +20,14 @@
 
 namespace ed {
 
+// host test build only: how many Lehmer rounds and how many plain iterations ran (tests/test_device_source_on_host.py)
+#ifdef ED_HOST_CHECK
+inline long halve_counters[2];
+#define HALVE_COUNT(i) (++::ed::halve_counters[i])
+#else
+#define HALVE_COUNT(i) ((void)0)
+#endif
+
 constexpr int HALF_WINDOWS = 34;                 // 4-bit signed windows of v and |u|: values < 2^134
 constexpr int HALF_BITS = 134;
 constexpr int HALF_RETRY_MIN_BITS = 122;         // an even u is retried one step later only if r >= 2^122: |u'| <= 8l / r < 2^134
@@ -105,6 +113,70 @@ ED_DEV bool halve_reduce(uint32_t ra[8], uint32_t ua[5], const uint32_t rb[8], c
   return big;
 }
 
+// out = a * x - b * y for W-word numbers, a, b < 2^24.  W = 8: the result is known to lie in [0, 2^256) (checked
+// on the host build); W = 5: 160-bit two's complement, modulo 2^160.
+template <int W>
+ED_DEV void halve_combine(uint32_t out[W], uint32_t a, const uint32_t x[W], uint32_t b, const uint32_t y[W]) {
+  uint64_t ca = 0, cb = 0;
+  int64_t c = 0;
+#pragma unroll
+  for (int k = 0; k < W; k++) {
+    ca += (uint64_t)a * x[k];
+    cb += (uint64_t)b * y[k];
+    c += (int64_t)(uint32_t)ca - (int64_t)(uint32_t)cb;
+    out[k] = (uint32_t)c;
+    c >>= 32;
+    ca >>= 32;
+    cb >>= 32;
+  }
+  ED_CHECK(W != 8 || c + (int64_t)ca - (int64_t)cb == 0);
+}
+
+constexpr int HALF_LEHMER_MIN_BITS = 148;        // rounds run while both remainders have more bits than this
+// One round of Lehmer's acceleration: many Euclidean half-steps on the remainders as doubles, then ONE exact update
+// of the long numbers.  With nonnegative integers a0, b0, a1, b1 (kept below 2^24 as doubles)
+//     R0' = a0 R0 - b0 R1,   R1' = b1 R1 - a1 R0      (and the same combinations of U0, U1)
+// a half-step "R0' -= q R1'" is a0 += q a1, b0 += q b1.  d0, d1 carry a relative error below 2^-50, so the doubles
+// y0, y1 that track R0', R1' are off by less than (a + b) max(d0, d1) 2^-50 < E := max(d0, d1) 2^-24; every
+// quotient is taken as floor((y0 - E) / (y1 + E)), which cannot exceed the true one, so each half-step applied is a
+// legitimate (possibly partial) Euclidean step and the true remainders stay nonnegative.  A half-step is refused
+// when it cannot be shown to leave its remainder above 2^138 - nothing that halve_scalar_lane's rule would have
+// to examine (remainders below 2^134) is ever produced here; the plain loop does the last bits.
+// Returns whether anything was applied.
+ED_DEV bool halve_lehmer_round(uint32_t r0[8], uint32_t r1[8], uint32_t u0[5], uint32_t u1[5], double& d0, double& d1) {
+  const double E = (d0 > d1 ? d0 : d1) * 0x1p-24;
+  double y0 = d0, y1 = d1, a0 = 1.0, b0 = 0.0, a1 = 0.0, b1 = 1.0;
+  bool progress = false, live = true;
+  for (int it = 0; it < 40 && live; it++) {
+    bool any = false;
+    {                                            // R0' by R1'
+      const double q = __builtin_floor(halve_ratio(y0 - E, y1 + E) * (1.0 - 0x1p-40));
+      const double na = __builtin_fma(q, a1, a0), nb = __builtin_fma(q, b1, b0), ny = __builtin_fma(-q, y1, y0);
+      if (q >= 1.0 && na < 0x1p24 && nb < 0x1p24 && ny - E >= 0x1p138) { a0 = na; b0 = nb; y0 = ny; any = true; }
+    }
+    {                                            // R1' by R0'
+      const double q = __builtin_floor(halve_ratio(y1 - E, y0 + E) * (1.0 - 0x1p-40));
+      const double na = __builtin_fma(q, a0, a1), nb = __builtin_fma(q, b0, b1), ny = __builtin_fma(-q, y0, y1);
+      if (q >= 1.0 && na < 0x1p24 && nb < 0x1p24 && ny - E >= 0x1p138) { a1 = na; b1 = nb; y1 = ny; any = true; }
+    }
+    live = any;
+    progress = progress || any;
+  }
+  if (!progress) return false;
+  uint32_t t0[8], t1[8], v0[5], v1[5];
+  halve_combine<8>(t0, (uint32_t)a0, r0, (uint32_t)b0, r1);
+  halve_combine<8>(t1, (uint32_t)b1, r1, (uint32_t)a1, r0);
+  halve_combine<5>(v0, (uint32_t)a0, u0, (uint32_t)b0, u1);
+  halve_combine<5>(v1, (uint32_t)b1, u1, (uint32_t)a1, u0);
+#pragma unroll
+  for (int k = 0; k < 8; k++) { r0[k] = t0[k]; r1[k] = t1[k]; }
+#pragma unroll
+  for (int k = 0; k < 5; k++) { u0[k] = v0[k]; u1[k] = v1[k]; }
+  d0 = halve_to_double(r0);
+  d1 = halve_to_double(r1);
+  return true;
+}
+
 // |u| < 2^134 for a 160-bit two's complement u; mag = |u|, neg = u < 0
 ED_DEV bool halve_magnitude(uint32_t mag[5], bool& neg, const uint32_t u[5]) {
   neg = (u[4] >> 31) != 0;
@@ -145,11 +217,19 @@ ED_DEV bool halve_scalar_lane(uint32_t vw[5], uint32_t uw[5], bool& uneg, const 
     }
   };
   examine(r1, u1, true, 1);
-  // r0 >= r1 here; from now on each half-step's comparison also tells the next one whether it has work
   double d0 = halve_to_double(r0), d1 = halve_to_double(r1);
-  bool act = !done;                              // the half-step about to run has ra >= rb
+  // the bulk of the way down by Lehmer rounds (about 23 bits each) ...
+  for (int round = 0; round < 8; round++) {
+    if (done || halve_below(r0, HALF_LEHMER_MIN_BITS) || halve_below(r1, HALF_LEHMER_MIN_BITS)) break;
+    if (!halve_lehmer_round(r0, r1, u0, u1, d0, d1)) break;
+    HALVE_COUNT(0);
+  }
+  // ... and the rest step by step, every completed step examined; each half-step's comparison also tells the next
+  // one whether it has work
+  bool act = !done && !halve_less(r0, r1);       // the half-step about to run has ra >= rb
   for (int it = 0; it < 160; it++) {
     if (done) break;
+    HALVE_COUNT(1);
     {                                            // r0 by r1
       if (halve_reduce(r0, u0, r1, u1, d0, d1, act)) { done = true; good = false; }
       d0 = halve_to_double(r0);

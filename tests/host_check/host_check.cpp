@@ -104,6 +104,11 @@ int hc_halve(uint8_t v[20], uint8_t u[20], int* uneg, const uint8_t t[32]) {
   return good ? 1 : 0;
 }
 
+void hc_halve_counters(long out[2], int reset) {
+  out[0] = halve_counters[0]; out[1] = halve_counters[1];
+  if (reset) halve_counters[0] = halve_counters[1] = 0;
+}
+
 // the exact (reference-order) path, as k_verify_exact runs it for off-curve keys
 int hc_verify_exact(const uint8_t sig[64], const uint8_t pub[32], const uint8_t* msg, size_t len) {
   uint32_t rw[8], sw[8], aw[8];

@@ -363,6 +363,8 @@ def test_halved_scalar_pairs(hostcheck):
     ts += [((1 << 127) * k + 1) % L for k in (2, 6, 10)]
     ts += [int.from_bytes(bytes(rng.integers(0, 256, 32, dtype=np.uint8)), "little") % L for _ in range(3000)]
     found = 0
+    counters = (ctypes.c_long * 2)()
+    hostcheck.hc_halve_counters(counters, 1)
     for t in ts:
         v, u, neg = ctypes.create_string_buffer(20), ctypes.create_string_buffer(20), ctypes.c_int(0)
         good = hostcheck.hc_halve(v, u, ctypes.byref(neg), le(t))
@@ -375,6 +377,9 @@ def test_halved_scalar_pairs(hostcheck):
             assert (ui, vi) == (mu, mv), hex(t)
             assert ui & 1 and abs(ui) < 1 << 134 and 0 <= vi < 1 << 134 and (ui * t - vi) % N8L == 0
     assert found >= len(ts) - 12
+    # most of the way is covered by Lehmer rounds (one exact long update per ~23 bits), the plain loop does the rest
+    hostcheck.hc_halve_counters(counters, 1)
+    assert counters[0] >= 4 * 3000 and counters[1] <= 12 * len(ts), list(counters)
     no_violations(hostcheck)
 
 
