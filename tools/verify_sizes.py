@@ -7,6 +7,7 @@ import libeddsa_amd as ed
 import workload
 ed.init(0)
 if os.environ.get("OFFCURVE_MODE"): ed.set_offcurve_mode(int(os.environ["OFFCURVE_MODE"]))
+if os.environ.get("VERIFY_ALGO"): ed.set_verify_algo(int(os.environ["VERIFY_ALGO"]))   # 1 full-length, 2 half-length, whatever the size
 for lg in [int(x) for x in os.environ.get("SIZES", "20,19,18,17,16,15,14,13,12").split(",")]:
     n = 1 << lg
     sk, msg = workload.sign_inputs(n, seed=1, config=2)
