@@ -118,9 +118,10 @@ EDDSA_AMD_DECL void eddsa_amd_set_offcurve_mode(int exact);
 EDDSA_AMD_DECL void eddsa_amd_set_verify_algo(int algo);
 EDDSA_AMD_DECL void eddsa_amd_set_rlc_min_items(size_t items);   /* see ed25519_verify_batch_rlc */
 
-/* measurement aid: when on, HIP events are recorded on the launch stream around the three kernels
+/* measurement aid: when on, HIP events are recorded on the launch stream around the kernels
  * of every verify pass (up to 256 passes); eddsa_amd_verify_phase_ms() waits for them and returns
- * the average duration of each kernel (prepare, main, finish) in milliseconds. */
+ * the average duration of each phase in milliseconds: out[0] k_verify_prepare (+ k_verify_halve), out[1] the main
+ * kernel, out[2] k_verify_finish (the half-length route has none: 0). */
 EDDSA_AMD_DECL void eddsa_amd_set_profiling(int on);
 EDDSA_AMD_DECL int eddsa_amd_verify_phase_ms(float out[3]);
 /* diagnostic for the secret-hygiene tests: waits for the default device to go idle and counts the

@@ -134,8 +134,10 @@ __global__ void __launch_bounds__(64) k_init_comb_image(uint32_t* img, const uin
 }
 
 // ---------------------------------------------------------------------------------------------
-// Ed25519 verify.  Three kernels per chunk, so that each stays inside its register budget and its
-// own I-cache footprint (one fused kernel spilled 4.5 KB/lane):
+// Ed25519 verify, the full-length route (passes of up to QUAD_MAIN_MAX_N items, eddsa_amd_set_verify_algo(1), the
+// reject mode; larger passes take the half-length route further down, which shares k_verify_prepare and the exact
+// path).  Three kernels per chunk, so that each stays inside its register budget and its own I-cache footprint
+// (one fused kernel spilled 4.5 KB/lane):
 //   k_verify_prepare  hash, scalars -> digit words, decompress -A, table of 0..8 * -A
 //   k_verify_main     the 252 doublings + 80 additions            (~85 % of the time)
 //   k_verify_finish   invert Z (shared by 8 items per lane), encode, compare with R
