@@ -10,6 +10,7 @@ device is missing.
 from .api import (  # noqa: F401
     EddsaAmdError,
     DH,
+    debug_halve,
     ed25519_genpub,
     ed25519_genpub_batch,
     ed25519_sign,

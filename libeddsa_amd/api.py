@@ -87,6 +87,21 @@ def set_verify_algo(algo=0):
     library().eddsa_amd_set_verify_algo(int(algo))
 
 
+def debug_halve(ts):
+    """diagnostic: the device's pair search on scalars t (ints below l); returns a list of (found, u, v)"""
+    n = len(ts)
+    tin = np.frombuffer(b"".join(int(t).to_bytes(32, "little") for t in ts), np.uint8).copy()
+    out = np.zeros(48 * max(n, 1), np.uint8)
+    _check(library().eddsa_amd_debug_halve(out.ctypes.data_as(ctypes.c_void_p), tin.ctypes.data_as(ctypes.c_void_p), _c_size(n)),
+           "eddsa_amd_debug_halve")
+    res = []
+    for i in range(n):
+        row = out[48 * i:48 * i + 48].tobytes()
+        u = int.from_bytes(row[20:40], "little") * (-1 if row[40] else 1)
+        res.append((bool(row[41]), u, int.from_bytes(row[:20], "little")))
+    return res
+
+
 def set_rlc_min_items(items):
     """ed25519_verify_batch_rlc calls with fewer items go straight to the per-item kernels (default 3 x 2^17,
     the measured break-even; 0 = always try the combination)"""

@@ -421,13 +421,6 @@ out:
     return rc;
 }
 
-/* How verify treats a public key that does not decode to a curve point (ed_import never fails,
- * reference lib/ed.c:100-149).  EXACT (default): such items are evaluated in the reference's own
- * order of operations, which is the only way to reproduce its bytes there.  REJECT: they are
- * rejected outright; this differs from the reference only if encode(C) == R for a C that depends on
- * SHA-512(R || A || M), i.e. on a fixed point of a random function, and saves the ~1 ms the exact
- * pass costs whenever a batch contains such keys.  ALL (2): every item takes the reference-order
- * path and the windowed evaluation's result is ignored -- slow (latency-bound), for self-checks. */
 /* Which evaluation ed25519_verify* uses (same verdicts; a measurement and test aid).  0 (default): half-length
  * scalars (csrc/halve.h) for passes of more than 2^14 items, full-length windows with four lanes per item below;
  * 1: full-length windows always; 2: half-length scalars always. */
@@ -438,6 +431,34 @@ void eddsa_amd_set_verify_algo(int algo)
     pthread_rwlock_unlock(&g_table);
 }
 
+/* diagnostic for the tests: the device's pair search (csrc/halve.h) on n given scalars t (32 bytes each, < l);
+ * out48: v (20 bytes) | |u| (20) | u < 0 (1) | found (1) | padding (6) per item.  Host pointers. */
+int eddsa_amd_debug_halve(uint8_t *out48, const uint8_t *t32, size_t n)
+{
+    struct call c;
+    uint8_t *d_t = NULL, *d_o = NULL;
+    int rc = enter(&c, -1);
+    if (rc) return rc;
+    if (n == 0) goto out;
+    TRY(hipMalloc((void **)&d_t, n * 32));
+    TRY(hipMalloc((void **)&d_o, n * 48));
+    TRY(hipMemcpy(d_t, t32, n * 32, hipMemcpyHostToDevice));
+    TRY(edk_debug_halve(d_o, d_t, n, NULL));
+    TRY(hipMemcpy(out48, d_o, n * 48, hipMemcpyDeviceToHost));
+out:
+    if (d_t) (void)hipFree(d_t);
+    if (d_o) (void)hipFree(d_o);
+    leave(&c);
+    return rc;
+}
+
+/* How verify treats a public key that does not decode to a curve point (ed_import never fails,
+ * reference lib/ed.c:100-149).  EXACT (default): such items are evaluated in the reference's own
+ * order of operations, which is the only way to reproduce its bytes there.  REJECT: they are
+ * rejected outright; this differs from the reference only if encode(C) == R for a C that depends on
+ * SHA-512(R || A || M), i.e. on a fixed point of a random function, and saves the ~1 ms the exact
+ * pass costs whenever a batch contains such keys.  ALL (2): every item takes the reference-order
+ * path and the windowed evaluation's result is ignored -- slow (latency-bound), for self-checks. */
 void eddsa_amd_set_offcurve_mode(int exact)
 {
     pthread_rwlock_wrlock(&g_table);

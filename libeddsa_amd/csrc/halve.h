@@ -11,8 +11,8 @@
 // there mod the prime group order; mod 8l and with u odd here so that the equivalence is exact for every input
 // on the curve, which is what bit-exactness with the reference's cofactorless check needs).  The evaluation is
 // then 132 doublings and three half-length scalars.  Items for which no suitable pair turns up in the two
-// candidates examined, or whose expansion has a quotient of 31 bits or more before that (together about 1 in
-// 10^4 random t), are handed to the exact path like off-curve keys.
+// candidates examined, or whose expansion has a quotient of 31 bits or more before that which the Lehmer rounds
+// have not already used up in partial steps (together about 1 in 10^4 random t), are handed to the exact path like off-curve keys.
 //
 // Public data only (verification): control flow and timing depend on t.
 #pragma once

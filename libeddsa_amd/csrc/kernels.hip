@@ -705,6 +705,28 @@ hipError_t edk_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* point
   return hipGetLastError();
 }
 
+// diagnostic (eddsa_amd_debug_halve): halve_scalar_lane on the device for given t; out = v (20 bytes) | |u| (20) |
+// u < 0 (1) | found (1) | 6 bytes of padding per item
+__global__ void __launch_bounds__(BLOCK) k_debug_halve(uint8_t* out, const uint8_t* t, size_t n) {
+  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t tw[8], vw[5], uw[5];
+  load32(tw, t, i, 32);
+  bool uneg;
+  const bool found = halve_scalar_lane(vw, uw, uneg, tw);
+  uint32_t* o = reinterpret_cast<uint32_t*>(out + 48 * i);
+#pragma unroll
+  for (int k = 0; k < 5; k++) { o[k] = vw[k]; o[5 + k] = uw[k]; }
+  o[10] = (uneg ? 1u : 0u) | (found ? 0x100u : 0u);
+  o[11] = 0;
+}
+
+hipError_t edk_debug_halve(uint8_t* out, const uint8_t* t, size_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_debug_halve, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, out, t, n);
+  return hipGetLastError();
+}
+
 hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const uint32_t* base16,
                       const edk_verify_ws* ws, hipEvent_t* marks, hipStream_t stream) {
   const edk_verify_src src = *srcp;

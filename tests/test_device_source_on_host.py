@@ -415,3 +415,14 @@ def test_verify_half_length_random_against_oracle(hostcheck, oracle):
             want = int(oracle.verify(s, p_, msg))
             assert got == want or (got == 2 and hostcheck.hc_verify_exact(s, p_, msg, SZ(len(msg))) == want)
     no_violations(hostcheck)
+
+
+def test_verify_half_length_rejects_what_export_never_writes(hostcheck, oracle):
+    """x = 0 with the sign bit, y >= p: R strings only a permissive decoder takes (cf. tests/test_gpu_half.py)"""
+    rs = [le(1), le(1 | 1 << 255), le(P + 1), le(P - 1), le((P - 1) | 1 << 255), le(P), le(2**255 - 1)]
+    for r in rs:
+        for a in (le(1), le(P - 1), le(1 | 1 << 255)):
+            for m in (b"a", b"bb", b"ccc", b"dddd"):
+                got = hostcheck.hc_verify_half(r + le(0), a, m, SZ(len(m)))
+                assert got == int(oracle.verify(r + le(0), a, m)), (r.hex(), a.hex(), m)
+    no_violations(hostcheck)

@@ -104,3 +104,75 @@ def test_reject_mode_keeps_every_on_curve_item(engine, oracle):
     engine.set_offcurve_mode(False)
     engine.set_verify_algo(2)
     assert np.array_equal(engine.ed25519_verify_batch(sig, pk, msg, msg_len=msg.shape[1]), want)
+
+
+def test_commitments_that_only_decode_permissively(engine, oracle):
+    """R strings that ed_import would accept but ed_export never produces - x = 0 with the sign bit set, y >= p -
+    next to their canonical spellings, under keys and S for which the canonical one is accepted: the byte comparison
+    of the reference rejects the former, and so must the point comparison of the half-length route"""
+    P = 2**255 - 19
+    le = lambda x: int(x).to_bytes(32, "little")   # noqa: E731
+    ident, minus1 = le(1), le(P - 1)
+    rs = [ident, le(1 | 1 << 255), le(P + 1), le((P + 1) | 1 << 255), minus1, le((P - 1) | 1 << 255), le(P), le(2**255 - 1)]
+    keys = [ident, minus1, le(1 | 1 << 255)]
+    sigs, pubs, msgs = [], [], []
+    for r in rs:
+        for a in keys:
+            for m in range(4):
+                sigs.append(r + le(0)); pubs.append(a); msgs.append(b"permissive R %d" % m + bytes(19))
+    sig, pub, msg = arr(sigs), arr(pubs), arr(msgs)
+    want = np.array([oracle.verify(s, p, m) for s, p, m in zip(sigs, pubs, msgs)], np.uint8)
+    assert want[:12].sum() >= 8 and want[12:24].sum() == 0          # canonical identity accepted, its signed spelling never
+    for algo in (2, 1):
+        engine.set_verify_algo(algo)
+        assert np.array_equal(engine.ed25519_verify_batch(sig, pub, msg, msg_len=msg.shape[1]), want), algo
+
+
+def test_device_pair_search_against_integers(engine):
+    """the pair search as the DEVICE runs it (reciprocal by Newton steps instead of the host build's division) against
+    Euclid on Python integers: random t, tiny t, t = (8l)/k with giant quotients at the start, in the middle and
+    right at the threshold, quotients just below and above the 2^31 limit"""
+    L = 2**252 + 27742317777372353535851937790883648493
+    N = 8 * L
+
+    def model(t, th=134, retry_min=122):
+        """(found, u, v, largest quotient met) by the rule of halve.h without its 31-bit quotient limit"""
+        r0, u0, r1, u1, tried, qmax = N, 0, t, 1, False, 0
+        while True:
+            if r1 < (1 << th):
+                if u1 & 1:
+                    return abs(u1) < (1 << th), u1, r1, qmax
+                if tried or r1 < (1 << retry_min):
+                    return False, u1, r1, qmax
+                tried = True
+            q = r0 // r1
+            qmax = max(qmax, q)
+            r0, r1, u0, u1 = r1, r0 - q * r1, u1, u0 - q * u1
+
+    rng = np.random.default_rng(99)
+    ts = [0, 1, 2, 3, 5, L - 1, L - 2, L // 2, L // 3, (1 << 134) - 1, 1 << 134, (1 << 134) + 1]
+    ts += [N // k % L for k in (3, 5, 7, 9, 1000003, (1 << 31) - 2, (1 << 31) - 1, 1 << 31, (1 << 31) + 1, (1 << 61) - 1,
+                                (1 << 100) + 277, (1 << 120) + 1, (1 << 121) + 7, (1 << 125) + 1, (1 << 126) + 3, (1 << 128) + 51)]
+    # continued fractions with a chosen large quotient q after a random prefix: t = N * (convergent-like ratio)
+    for q in (1 << 10, 1 << 20, (1 << 24) - 1, 1 << 24, (1 << 24) + 1, 1 << 30, (1 << 31) - 3):
+        for depth in (1, 20, 40, 60, 70, 75):
+            a, b = 1, 0
+            for k in range(depth):
+                a, b = int(rng.integers(1, 4)) * a + b, a
+            a, b = q * a + b, a
+            ts.append(N * b // a % L)
+    ts += [int.from_bytes(bytes(rng.integers(0, 256, 32, dtype=np.uint8)), "little") % L for _ in range(20000)]
+    got = engine.debug_halve(ts)
+    found = 0
+    for t, (ok, u, v) in zip(ts, got):
+        want, mu, mv, qmax = model(t)
+        # a quotient of 31 bits or more makes the search give up, unless the Lehmer rounds have already taken
+        # enough of it away in partial steps: either outcome is fine near the limit, a found pair must be Euclid's
+        if qmax < (1 << 31) - (1 << 28):
+            assert ok == want, hex(t)
+        elif qmax >= (1 << 32):
+            assert not ok, hex(t)
+        if ok:
+            found += 1
+            assert want and (u, v) == (mu, mv) and u & 1 and (u * t - v) % N == 0, hex(t)
+    assert found > len(ts) - 40
