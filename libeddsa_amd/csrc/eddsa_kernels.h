@@ -21,7 +21,7 @@
 #endif
 #define VERIFY_TABLE_WORDS_PER_TILE (VERIFY_TABLE_ENTRIES * 40 * 256)
 #define VERIFY_TILE 256            /* items per tile = threads per block */
-#define EDK_HALF_DIGIT_WORDS 20     /* = HALF_DIGIT_WORDS of lanes.h */
+#define EDK_HALF_DIGIT_WORDS 28     /* = HALF_DIGIT_WORDS of lanes.h */
 #define ACC_WORDS 40               /* point workspace per item: X, Y, Z and one slot for the finish kernels' prefix products */
 
 #ifdef __cplusplus
@@ -41,7 +41,7 @@ typedef struct edk_verify_ws {
   uint32_t* hdigits;  /* capacity * EDK_HALF_DIGIT_WORDS words: the half-length scalars (kernels.hip k_verify_halve) */
   uint32_t* rtable;   /* like table: 0..8 times -R' */
   uint8_t* flags;     /* capacity bytes */
-  uint32_t* offlist;  /* capacity words: items whose key is off the curve */
+  uint32_t* offlist;  /* capacity words: the exact path's work list (keys off the curve; large passes: items without a short pair) */
   uint32_t* offcount; /* 1 word */
   uint32_t* exact_pad;/* EDK_EXACT_PAD_BYTES: per-lane scratchpad of k_verify_exact */
   hipStream_t side;   /* the exact path runs here, beside the main kernel */

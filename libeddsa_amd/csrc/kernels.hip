@@ -281,24 +281,30 @@ k_verify_halve(const uint8_t* sigs, size_t sig_stride, size_t n, const uint32_t*
     tdig[0] = a.x; tdig[1] = a.y; tdig[2] = a.z; tdig[3] = a.w; tdig[4] = b.x; tdig[5] = b.y; tdig[6] = b.z; tdig[7] = b.w;
     sdig[0] = c.x; sdig[1] = c.y; sdig[2] = c.z; sdig[3] = c.w; sdig[4] = e.x; sdig[5] = e.y; sdig[6] = e.z; sdig[7] = e.w;
   }
-  const bool found = verify_half_scalars_lane(hd, tdig, sdig);
+  verify_half_scalars_lane(hd, tdig, sdig);
   uint4* o = reinterpret_cast<uint4*>(hdigits + HALF_DIGIT_WORDS * i);
 #pragma unroll
   for (int q = 0; q < HALF_DIGIT_WORDS / 4; q++) o[q] = make_uint4(hd[4 * q], hd[4 * q + 1], hd[4 * q + 2], hd[4 * q + 3]);
   uint32_t rw[8];
   load32(rw, sigs, item, sig_stride);
   const bool rvalid = verify_half_point_lane(rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), rw);
-  const bool mine = (fl & 1) != 0 && found;
+  // An item without a short pair ("long", lanes.h) joins the exact path's work list here: k_verify_main_half's grid
+  // has no slack, and both alternatives measured slower at 2^20 items - the long loop inside this kernel for the
+  // waves that contain such an item (one in 180: 7.2 -> 7.8 ms) and a separate four-lane kernel for them beside it
+  // (7.4 -> 7.65 ms).  Small passes, whose waves have the chip to themselves, do run the long loop in place
+  // (k_verify_main_half_quad).
+  const bool mine = (fl & 1) != 0 && (hd[24] & 2u) == 0;
   flags[i] = (uint8_t)((mine ? 1 : 0) | (rvalid ? 4 : 0));
-  if ((fl & 1) != 0 && !found && i < n) offlist[atomicAdd(offcount, 1u)] = (uint32_t)i;
+  if ((fl & 1) != 0 && !mine && i < n) offlist[atomicAdd(offcount, 1u)] = (uint32_t)i;
 }
 
 __global__ void __launch_bounds__(BLOCK, 2)
 k_verify_main_half(uint8_t* ok, const uint32_t* hdigits, const uint32_t* table, const uint32_t* rtable,
                    const uint32_t* base16, const uint8_t* flags, size_t n, int exact_offcurve) {
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;   // < workspace capacity
-  const bool neutral = verify_half_main_lane(hdigits + HALF_DIGIT_WORDS * i, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
-                                             rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16);
+  const uint32_t* hd = hdigits + HALF_DIGIT_WORDS * i;
+  const bool neutral = verify_half_main_lane<false>(hd, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
+                                             rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16, false);
   if (i >= n) return;
   const uint8_t fl = flags[i];
   if ((fl & 1) == 0) {                           // the exact path owns this verdict (or, in reject mode, nobody does)
@@ -436,6 +442,12 @@ struct verify_finish_policy {
 
 // small passes: four lanes per item (quad_lanes.h: verify_main_quad); writes the same workspace
 constexpr size_t QUAD_MAIN_MAX_N = (size_t)1 << 14;   // measured: 0.57 vs 0.86 ms at 2^14, equal at 2^15 (tools/verify_sizes.py)
+#ifndef HALF_QUAD_LOG2
+#define HALF_QUAD_LOG2 15
+#endif
+// k_verify_prepare_pair + k_verify_main_half_quad up to here.  Measured (tools/verify_small.py, valid signatures, ms per pass):
+// 2^15 items 0.74 against 1.12 with one lane per item, 2^16 items 1.15 against 1.30 but 1.59 against 1.27 on the config-2 mix
+constexpr size_t HALF_QUAD_MAX_N = (size_t)1 << HALF_QUAD_LOG2;
 __global__ void __launch_bounds__(QUAD_BLOCK, 2)
 k_verify_main_quad(const uint32_t* digits, const uint32_t* table, const uint32_t* base16, uint32_t* accout, size_t n) {
   const size_t i = ((size_t)blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;       // quads are all-or-nothing
@@ -675,6 +687,89 @@ k_sk_to_x(uint8_t* out, const uint8_t* in, size_t n) {
   store32(out, i, 32, o);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The half-length route for SMALL passes (up to QUAD_MAIN_MAX_N items), where what counts is the latency of one
+// item: k_verify_prepare_pair does the work of k_verify_prepare + k_verify_halve with two lanes per item - both
+// hash and search the pair (the same values twice, no divergence), then lane 0 decompresses A and builds its table
+// while lane 1 does the same for R - and k_verify_main_half_quad is verify_half_main_lane with a coordinate per
+// lane (quad_lanes.h).  Two kernels, 132 doublings and no inversion instead of three, 252 and one.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK, 2)
+k_verify_prepare_pair(edk_verify_src src, size_t n, uint32_t* digits, uint32_t* hdigits, uint32_t* table, uint32_t* rtable,
+                      uint8_t* flags, uint32_t* offlist, uint32_t* offcount, int all_exact) {
+  const size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const size_t i = g >> 1;                       // pairs are all-or-nothing
+  if (i >= n) return;
+  const bool second = (g & 1) != 0;
+  uint32_t rw[8], aw[8], sw[8], tw[8], hd[HALF_DIGIT_WORDS];
+  const uint8_t* m; size_t mlen;
+  verify_item(rw, sw, aw, m, mlen, src, i);
+  verify_hash_lane(tw, rw, aw, m, mlen);
+  verify_s_lane(sw);
+  verify_half_scalars_lane(hd, tw, sw);
+  if (!second) {
+    uint4* d = reinterpret_cast<uint4*>(digits + 16 * i);
+    d[0] = make_uint4(tw[0], tw[1], tw[2], tw[3]); d[1] = make_uint4(tw[4], tw[5], tw[6], tw[7]);
+    d[2] = make_uint4(sw[0], sw[1], sw[2], sw[3]); d[3] = make_uint4(sw[4], sw[5], sw[6], sw[7]);
+    uint4* o = reinterpret_cast<uint4*>(hdigits + HALF_DIGIT_WORDS * i);
+#pragma unroll
+    for (int q = 0; q < HALF_DIGIT_WORDS / 4; q++) o[q] = make_uint4(hd[4 * q], hd[4 * q + 1], hd[4 * q + 2], hd[4 * q + 3]);
+  }
+  // lane 0: -A permissively (ed.c:100-149), lane 1: -R' strictly (lanes.h: verify_half_point_lane)
+  uint32_t pw[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) pw[k] = second ? rw[k] : aw[k];
+  uint32_t* tab = (second ? rtable : table) + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS);
+  bool oncurve;
+  ge p;
+  ge_frombytes(p, oncurve, pw, true);
+  bool top = (pw[7] & 0x7fffffffu) == 0x7fffffffu && pw[0] >= 0xffffffedu;
+#pragma unroll
+  for (int k = 1; k < 7; k++) top = top && pw[k] == 0xffffffffu;
+  const bool strict = oncurve && !top && !((pw[7] >> 31) != 0 && fe_iszero(p.X));
+  verify_table_point_lane(tab, p);
+  const int mine = second ? (strict ? 1 : 0) : (oncurve ? 1 : 0);
+  const int other = __shfl_xor(mine, 1);
+  if (!second) {
+    const bool keep = oncurve && !all_exact;
+    flags[i] = (uint8_t)((keep ? 1 : 0) | (other ? 4 : 0));
+    if (!keep) offlist[atomicAdd(offcount, 1u)] = (uint32_t)i;
+  }
+}
+
+__global__ void __launch_bounds__(QUAD_BLOCK, 2)
+k_verify_main_half_quad(uint8_t* ok, const uint32_t* hdigits, const uint32_t* table, const uint32_t* rtable,
+                        const uint32_t* base16, const uint8_t* flags, size_t n, int exact_offcurve) {
+  const size_t i = ((size_t)blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;      // quads are all-or-nothing
+  if (i >= n) return;
+  const int q = (int)(threadIdx.x & 3u);
+  const bool neutral = verify_half_main_quad(hdigits + HALF_DIGIT_WORDS * i, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
+                                             rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16, q);
+  if (q != 0) return;
+  const uint8_t fl = flags[i];
+  if ((fl & 1) == 0) {                           // the exact path owns this verdict
+    if (!exact_offcurve) ok[i] = 0;
+    return;
+  }
+  ok[i] = (uint8_t)(neutral && (fl & 4) != 0);
+}
+
+// diagnostic (eddsa_amd_debug_halve): halve_scalar_lane on the device for given t; out = v (20 bytes) | |u| (20) |
+// u < 0 (1) | found (1) | 6 bytes of padding per item
+__global__ void __launch_bounds__(BLOCK) k_debug_halve(uint8_t* out, const uint8_t* t, size_t n) {
+  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t tw[8], vw[5], uw[5];
+  load32(tw, t, i, 32);
+  bool uneg;
+  const bool found = halve_scalar_lane(vw, uw, uneg, tw);
+  uint32_t* o = reinterpret_cast<uint32_t*>(out + 48 * i);
+#pragma unroll
+  for (int k = 0; k < 5; k++) { o[k] = vw[k]; o[5 + k] = uw[k]; }
+  o[10] = (uneg ? 1u : 0u) | (found ? 0x100u : 0u);
+  o[11] = 0;
+}
+
 }  // namespace ed
 
 // =============================================================================================
@@ -705,22 +800,6 @@ hipError_t edk_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* point
   return hipGetLastError();
 }
 
-// diagnostic (eddsa_amd_debug_halve): halve_scalar_lane on the device for given t; out = v (20 bytes) | |u| (20) |
-// u < 0 (1) | found (1) | 6 bytes of padding per item
-__global__ void __launch_bounds__(BLOCK) k_debug_halve(uint8_t* out, const uint8_t* t, size_t n) {
-  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= n) return;
-  uint32_t tw[8], vw[5], uw[5];
-  load32(tw, t, i, 32);
-  bool uneg;
-  const bool found = halve_scalar_lane(vw, uw, uneg, tw);
-  uint32_t* o = reinterpret_cast<uint32_t*>(out + 48 * i);
-#pragma unroll
-  for (int k = 0; k < 5; k++) { o[k] = vw[k]; o[5 + k] = uw[k]; }
-  o[10] = (uneg ? 1u : 0u) | (found ? 0x100u : 0u);
-  o[11] = 0;
-}
-
 hipError_t edk_debug_halve(uint8_t* out, const uint8_t* t, size_t n, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_debug_halve, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, out, t, n);
@@ -734,10 +813,19 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   const unsigned blocks = (unsigned)((n + BLOCK - 1) / BLOCK);
   (void)hipMemsetAsync(ws->offcount, 0, sizeof(uint32_t), stream);
   if (marks) (void)hipEventRecord(marks[0], stream);
-  hipLaunchKernelGGL(k_verify_prepare, dim3(blocks), dim3(BLOCK), 0, stream, src, n, ws->digits, ws->table, ws->flags, ws->offlist, ws->offcount,
-                     ws->exact_offcurve == 2);
-  // algo 0: half-length scalars above QUAD_MAIN_MAX_N items, full-length windows below; 1 / 2 force one of them
-  const bool half = ws->algo == 2 || (ws->algo == 0 && n > QUAD_MAIN_MAX_N);
+  // algo 0: half-length scalars - one lane per item above QUAD_MAIN_MAX_N items, lane pairs and quads below;
+  // 1: full-length windows (one lane per item above QUAD_MAIN_MAX_N items, quads below); 2: half-length, one lane per item
+  const bool small = n <= QUAD_MAIN_MAX_N;
+  const bool small_half = n <= HALF_QUAD_MAX_N;
+  const int algo = ws->exact_offcurve ? ws->algo : 1;   // the half-length route relies on the exact path for its give-ups
+  const bool half = algo == 2 || (algo == 0 && !small_half);
+  const bool half_quad = algo == 0 && small_half;
+  if (half_quad)
+    hipLaunchKernelGGL(k_verify_prepare_pair, dim3((unsigned)((2 * n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, src, n,
+                       ws->digits, ws->hdigits, ws->table, ws->rtable, ws->flags, ws->offlist, ws->offcount, ws->exact_offcurve == 2);
+  else
+    hipLaunchKernelGGL(k_verify_prepare, dim3(blocks), dim3(BLOCK), 0, stream, src, n, ws->digits, ws->table, ws->flags, ws->offlist, ws->offcount,
+                       ws->exact_offcurve == 2);
   if (half)
     hipLaunchKernelGGL(k_verify_halve, dim3(blocks), dim3(BLOCK), 0, stream, src.sigs, src.sig_stride, n, ws->digits, ws->hdigits,
                        ws->rtable, ws->flags, ws->offlist, ws->offcount);
@@ -756,12 +844,16 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
                        ws->exact_pad);
     (void)hipEventRecord(ws->ev_exact, ws->side);
   }
-  if (half) {
+  if (half_quad) {
+    hipLaunchKernelGGL(k_verify_main_half_quad, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, stream,
+                       ok, ws->hdigits, ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
+    if (marks) { (void)hipEventRecord(marks[2], stream); (void)hipEventRecord(marks[3], stream); }
+  } else if (half) {
     hipLaunchKernelGGL(k_verify_main_half, dim3(blocks), dim3(BLOCK), MAIN_LDS_RESERVE, stream, ok, ws->hdigits, ws->table,
                        ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
     if (marks) { (void)hipEventRecord(marks[2], stream); (void)hipEventRecord(marks[3], stream); }
   } else {
-    if (n <= QUAD_MAIN_MAX_N)
+    if (small)
       hipLaunchKernelGGL(k_verify_main_quad, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0,
                          stream, ws->digits, ws->table, base16, ws->acc, n);
     else

@@ -340,49 +340,42 @@ ED_DEV bool verify_encode_lane(const fe& X, const fe& Y, const fe& zinv, const u
 //     acc = 16*acc + sigma*d_i*(-A) + e_i*(-R')  [+ f_j*B + g_j*(2^128 B) when i = 4j, j < 8]
 // over 34 four-bit windows, d = digits of v, e = digits of |u|, sigma = sign of u, f / g = the 16-bit digits
 // of the low / high half of s' = |u| S mod l; accept iff the result is the neutral element and R was a
-// canonical encoding.  hd (HALF_DIGIT_WORDS per item): v + 0x88.. [0,5) | |u| + 0x88.. [5,10) |
-// s' + 0x8000.. [10,18) | bit 0 of [18]: u < 0.
+// canonical encoding.  An item for which halve.h finds no pair keeps (u, v) = (1, t) and s' = S: the same equation,
+// read over 64 windows ("long"; f_j*B then for every j < 16 and no g); its wave runs the long loop, in which the
+// short items of the wave add neutral elements from window 34 on.  About one wave in 180 is long.
+// hd (HALF_DIGIT_WORDS per item): v + 0x88.. [0,8) | |u| + 0x88.. [8,16) | s' + 0x8000.. [16,24) |
+// [24]: bit 0 = (u < 0), bit 1 = long.
 // ---------------------------------------------------------------------------------------------
-#define HALF_DIGIT_WORDS 20
+#define HALF_DIGIT_WORDS 28
+constexpr int HALF_LONG_WINDOWS = 64;
 
-// 160-bit add of the 34-nibble pattern 0x88..8
-ED_DEV void half_add_pattern(uint32_t w[5]) {
-  uint64_t c = 0;
-#pragma unroll
-  for (int k = 0; k < 5; k++) {
-    c += (uint64_t)w[k] + (k < 4 ? 0x88888888u : 0x00000088u);
-    w[k] = (uint32_t)c;
-    c >>= 32;
-  }
-}
-
-// tdig / sdig: the digit words k_verify_prepare wrote (t + 0x88.., S mod l + 0x8000..).  Returns false when the
-// item has to take the exact path.
-ED_DEV bool verify_half_scalars_lane(uint32_t hd[HALF_DIGIT_WORDS], const uint32_t tdig[8], const uint32_t sdig[8]) {
-  uint32_t tw[8], sw[8], vw[5], uw[5], u8[8];
+// tdig / sdig: the digit words k_verify_prepare wrote (t + 0x88.., S mod l + 0x8000..)
+ED_DEV void verify_half_scalars_lane(uint32_t hd[HALF_DIGIT_WORDS], const uint32_t tdig[8], const uint32_t sdig[8]) {
+  uint32_t tw[8], sw[8], vw[5], uw[5], v8[8], u8[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) { tw[k] = tdig[k]; sw[k] = sdig[k]; }
   words_sub_pattern(tw, 0x88888888u);
   words_sub_pattern(sw, 0x80008000u);
   bool uneg;
-  const bool good = halve_scalar_lane(vw, uw, uneg, tw);
+  const bool found = halve_scalar_lane(vw, uw, uneg, tw);
 #pragma unroll
-  for (int k = 0; k < 8; k++) u8[k] = k < 5 ? uw[k] : 0;
+  for (int k = 0; k < 8; k++) {
+    v8[k] = found ? (k < 5 ? vw[k] : 0u) : tw[k];
+    u8[k] = found ? (k < 5 ? uw[k] : 0u) : (k == 0 ? 1u : 0u);
+  }
+  uneg = uneg && found;
   sc s, u, su;
   sc_from_words<8>(s, sw);
   sc_from_words<8>(u, u8);
   sc_mul(su, s, u);                              // |u| S mod l
   sc_to_words(sw, su);
   words_add_pattern(sw, 0x80008000u);
-  half_add_pattern(vw);
-  half_add_pattern(uw);
+  words_add_pattern(v8, 0x88888888u);            // v < 2^253, |u| < 2^134: no carry out of the 64 nibbles
+  words_add_pattern(u8, 0x88888888u);
 #pragma unroll
-  for (int k = 0; k < 5; k++) { hd[k] = vw[k]; hd[5 + k] = uw[k]; }
-#pragma unroll
-  for (int k = 0; k < 8; k++) hd[10 + k] = sw[k];
-  hd[18] = uneg ? 1u : 0u;
-  hd[19] = 0;
-  return good;
+  for (int k = 0; k < 8; k++) { hd[k] = v8[k]; hd[8 + k] = u8[k]; hd[16 + k] = sw[k]; }
+  hd[24] = (uneg ? 1u : 0u) | (found ? 0u : 2u);
+  hd[25] = 0; hd[26] = 0; hd[27] = 0;
 }
 
 // Table of 0..8 times -R' at tab, R' the point R encodes.  Returns whether R is what ed_export can produce
@@ -415,22 +408,27 @@ ED_DEV void cached_from_raw(ge_cached& c, const cached_raw& r) {
   for (int j = 0; j < 10; j++) { c.ymx.v[j] = w[j]; c.ypx.v[j] = w[10 + j]; c.t2d.v[j] = w[20 + j]; c.z2.v[j] = w[30 + j]; }
 }
 
-// returns whether the combination is the neutral element.  The two per-item table entries of a window are
-// requested before the window's four doublings and consumed after them (the kernel runs two waves per SIMD, which
-// is not enough to hide a miss to HBM per addition otherwise).
-ED_DEV bool verify_half_main_lane(const uint32_t* hd, const uint32_t* tab_a, const uint32_t* tab_r, const uint32_t* base16) {
+// returns whether the combination is the neutral element.  WITH_LONG = false: the caller keeps long items out (their
+// result here is meaningless) and the loop is the short one; true: long_loop says whether some item of the wave is
+// long (wave-uniform; the caller's vote).  The two per-item table entries of a window are requested before the
+// window's four doublings and consumed after them (the kernel runs two waves per SIMD, which is not enough to hide a
+// miss to HBM per addition otherwise).
+template <bool WITH_LONG>
+ED_DEV bool verify_half_main_lane(const uint32_t* hd, const uint32_t* tab_a, const uint32_t* tab_r, const uint32_t* base16,
+                                  bool long_loop) {
   ge acc;
   ge_neutral(acc);
-  const bool uneg = (hd[18] & 1u) != 0;
+  const bool uneg = (hd[24] & 1u) != 0, is_long = WITH_LONG && (hd[24] & 2u) != 0;
+  const int top = (WITH_LONG && long_loop ? HALF_LONG_WINDOWS : HALF_WINDOWS) - 1;
 #pragma unroll 1
-  for (int w = HALF_WINDOWS - 1; w >= 0; w--) {
+  for (int w = top; w >= 0; w--) {
     const int dv = (int)((hd[w >> 3] >> (4 * (w & 7))) & 15u) - 8;
-    const int du = (int)((hd[5 + (w >> 3)] >> (4 * (w & 7))) & 15u) - 8;
+    const int du = (int)((hd[8 + (w >> 3)] >> (4 * (w & 7))) & 15u) - 8;
     cached_raw ra, rr;
     cached_load_raw(ra, tab_a, (uint32_t)(dv < 0 ? -dv : dv));
     cached_load_raw(rr, tab_r, (uint32_t)(du < 0 ? -du : du));
-    const bool base_here = (w & 3) == 0 && w < 32;
-    if (w != HALF_WINDOWS - 1) {
+    const bool base_here = (w & 3) == 0 && (WITH_LONG || w < 32);
+    if (w != top) {
 #pragma unroll 1
       for (int k = 0; k < 4; k++) ge_dbl(acc, acc, k == 3);
     }
@@ -446,14 +444,16 @@ ED_DEV bool verify_half_main_lane(const uint32_t* hd, const uint32_t* tab_a, con
     if (base_here) {
       const int j = w >> 2;                      // digit j of s' sits at bit 16 j, digit 8 + j at bit 128 + 16 j
 #pragma unroll 1
-      for (int h = 0; h < 2; h++) {
+      for (int h = 0; h < (j < 8 ? 2 : 1); h++) {
+        // short items: digit j from k*B and digit 8 + j from k*2^128*B, j < 8; long items: digit j from k*B, j < 16
         const int jj = j + 8 * h;
-        const int dig = (int)((hd[10 + (jj >> 1)] >> (16 * (jj & 1))) & 0xffffu) - 32768;
+        int dig = (int)((hd[16 + (jj >> 1)] >> (16 * (jj & 1))) & 0xffffu) - 32768;
+        if (WITH_LONG) dig = (is_long ? h == 0 : j < 8) ? dig : 0;
         const uint32_t mag = (uint32_t)(dig < 0 ? -dig : dig);
         ge_niels nb;
         niels_load(nb, base16 + TABLE_ENTRY_WORDS * ((size_t)mag + (h ? (size_t)TABLE_BASE16_ENTRIES : 0)));
         ge_niels_cneg(nb, dig < 0);
-        ge_add_niels(acc, acc, nb, h == 0);
+        ge_add_niels(acc, acc, nb, h == 0 && j < 8);
       }
     }
   }

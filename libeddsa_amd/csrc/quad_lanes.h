@@ -290,6 +290,48 @@ ED_DEV void verify_main_quad(fe& r, const uint32_t* digits, const uint32_t* tab,
 }
 
 
+// lanes.h: verify_half_main_lane (the half-length evaluation, halve.h) with four lanes per item, for small passes:
+// same digits, tables and field expressions, so the same projective result; returns, in every lane of the quad,
+// whether that result is the neutral element.
+ED_DEV bool verify_half_main_quad(const uint32_t* hd, const uint32_t* tab_a, const uint32_t* tab_r, const uint32_t* base16, int q) {
+  fe r;
+  fe_set(r, (uint32_t)(q & 1));                  // neutral element (0, 1, 0, 1) as (X, Y, T, Z)
+  const bool uneg = (hd[24] & 1u) != 0, is_long = (hd[24] & 2u) != 0;
+  const int top = (__any(is_long) ? HALF_LONG_WINDOWS : HALF_WINDOWS) - 1;   // the wave's loop (lanes.h: verify_half_main_lane)
+#pragma unroll 1
+  for (int w = top; w >= 0; w--) {
+    if (w != top) {
+#pragma unroll 1
+      for (int k = 0; k < 4; k++) quad_dbl(r, q);
+    }
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {                // h = 0: v on -A (sign of u applied), h = 1: |u| on -R'
+      const int dig = (int)((hd[8 * h + (w >> 3)] >> (4 * (w & 7))) & 15u) - 8;
+      const uint32_t mag = (uint32_t)(dig < 0 ? -dig : dig);
+      quad_add_entry(r, (h ? tab_r : tab_a) + mag * VERIFY_ENTRY_WORDS, (dig < 0) != (h == 0 && uneg), true, q);
+    }
+    if ((w & 3) == 0) {
+      const int j = w >> 2;
+#pragma unroll 1
+      for (int h = 0; h < (j < 8 ? 2 : 1); h++) {
+        const int jj = j + 8 * h;
+        int dig = (int)((hd[16 + (jj >> 1)] >> (16 * (jj & 1))) & 0xffffu) - 32768;
+        dig = (is_long ? h == 0 : j < 8) ? dig : 0;
+        const uint32_t mag = (uint32_t)(dig < 0 ? -dig : dig);
+        quad_add_entry(r, base16 + TABLE_ENTRY_WORDS * ((size_t)mag + (h ? (size_t)TABLE_BASE16_ENTRIES : 0)), dig < 0, false, q);
+      }
+    }
+  }
+  // X = 0 (lane 0), Y = Z (lane 1 against lane 3), Z != 0 (lane 3); lane 2 (T) has no say
+  fe z, d;
+  fe_quad_perm<3, 3, 3, 3>(z, r);
+  fe_sub(d, r, z);
+  const bool mine = q == 0 ? fe_iszero(r) : q == 1 ? fe_iszero(d) : q == 3 ? !fe_iszero(r) : true;
+  const uint64_t votes = __ballot(mine);
+  const unsigned lane = __lane_id();
+  return ((votes >> (lane & ~3u)) & 0xfu) == 0xfu;
+}
+
 // ---------------------------------------------------------------------------------------------
 // X25519 with four lanes per item, for SMALL passes (lanes.h: x25519_ladder_lane is the one-lane form):
 // a ladder step is nine multiplications / squarings deep with one lane; with the quad holding

@@ -81,16 +81,33 @@ int hc_verify(const uint8_t sig[64], const uint8_t pub[32], const uint8_t* msg, 
 }
 
 // the half-length path (halve.h; k_verify_prepare + k_verify_halve + k_verify_main_half) for one item:
-// 0 / 1 = its verdict, 2 = the item is handed to the exact path (key off the curve, or no short pair)
+// 0 / 1 = its verdict (+ 4 when no short pair was found and the item ran the long loop), 2 = the item is handed
+// to the exact path (key off the curve)
 int hc_verify_half(const uint8_t sig[64], const uint8_t pub[32], const uint8_t* msg, size_t len) {
   alignas(16) uint32_t tab[VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS], rtab[VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS];
   uint32_t rw[8], sw[8], aw[8], tw[8], hd[HALF_DIGIT_WORDS];
   rd(rw, sig); rd(sw, sig + 32); rd(aw, pub);
   const bool oncurve = verify_prepare_lane(tw, sw, tab, rw, aw, msg, len);
-  const bool shortpair = verify_half_scalars_lane(hd, tw, sw);
+  verify_half_scalars_lane(hd, tw, sw);
   const bool rvalid = verify_half_point_lane(rtab, rw);
-  if (!oncurve || !shortpair) return 2;
-  return verify_half_main_lane(hd, tab, rtab, tables().b16()) && rvalid ? 1 : 0;
+  if (!oncurve) return 2;
+  const bool is_long = (hd[24] & 2u) != 0;
+  // short items as k_verify_main_half evaluates them, long ones as their wave of k_verify_main_half_quad does
+  const bool neutral = is_long ? verify_half_main_lane<true>(hd, tab, rtab, tables().b16(), true)
+                               : verify_half_main_lane<false>(hd, tab, rtab, tables().b16(), false);
+  return (neutral && rvalid ? 1 : 0) + (is_long ? 4 : 0);
+}
+
+// the same with the long loop forced, as a short item runs it in a wave that contains a long one
+int hc_verify_half_in_long_wave(const uint8_t sig[64], const uint8_t pub[32], const uint8_t* msg, size_t len) {
+  alignas(16) uint32_t tab[VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS], rtab[VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS];
+  uint32_t rw[8], sw[8], aw[8], tw[8], hd[HALF_DIGIT_WORDS];
+  rd(rw, sig); rd(sw, sig + 32); rd(aw, pub);
+  const bool oncurve = verify_prepare_lane(tw, sw, tab, rw, aw, msg, len);
+  verify_half_scalars_lane(hd, tw, sw);
+  const bool rvalid = verify_half_point_lane(rtab, rw);
+  if (!oncurve) return 2;
+  return verify_half_main_lane<true>(hd, tab, rtab, tables().b16(), true) && rvalid ? 1 : 0;
 }
 
 // halve_scalar_lane: v (20 bytes), |u| (20 bytes), sign of u; returns whether a pair was found

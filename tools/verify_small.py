@@ -1,16 +1,23 @@
+"""Time of one verify pass for small batches, device-resident, back to back (no host sync between calls):
+valid signatures only (no key off the curve, so the exact path has nothing to do) and the config-2 recipe
+(corruptions and edge vectors: the reference-order chain for the off-curve keys sets the floor)."""
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tools"))
 import libeddsa_amd as ed, workload
 ed.init(0)
-for l in (16, 15, 14, 13):
-    n = 1 << l
-    sk, msg = workload.sign_inputs(n, seed=1, config=2)
-    d = lambda a: torch.from_numpy(a).cuda()
-    pk = ed.ed25519_genpub_batch(d(sk)); sig = ed.ed25519_sign_batch(d(sk), pk, d(msg)).cpu().numpy(); pk = pk.cpu().numpy()
-    workload.corrupt_for_verify(sig, pk, msg)
-    ds, dp, dm = d(sig), d(pk), d(msg)
-    for _ in range(5): ed.ed25519_verify_batch(ds, dp, dm)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(30): ed.ed25519_verify_batch(ds, dp, dm)
-    torch.cuda.synchronize(); print(f"2^{l}: {(time.perf_counter()-t0)/30*1e3:.3f} ms", end="  ")
-print()
+d = lambda a: torch.from_numpy(a).cuda()
+for algo in (0, 1):
+    ed.set_verify_algo(algo)
+    for clean in (True, False):
+        print(f"algo {algo} {'valid only   ' if clean else 'config-2 mix '}", end=" ")
+        for l in (17, 16, 15, 14, 13, 12, 10, 6, 0):
+            n = 1 << l
+            sk, msg = workload.sign_inputs(n, seed=1, config=2)
+            pk = ed.ed25519_genpub_batch(d(sk)); sig = ed.ed25519_sign_batch(d(sk), pk, d(msg)).cpu().numpy(); pk = pk.cpu().numpy()
+            if not clean: workload.corrupt_for_verify(sig, pk, msg)
+            ds, dp, dm = d(sig), d(pk), d(msg)
+            for _ in range(5): ed.ed25519_verify_batch(ds, dp, dm)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(30): ed.ed25519_verify_batch(ds, dp, dm)
+            torch.cuda.synchronize(); print(f"2^{l}: {(time.perf_counter()-t0)/30*1e3:.3f}", end="  ")
+        print("ms")
