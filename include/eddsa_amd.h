@@ -111,10 +111,11 @@ EDDSA_AMD_DECL int eddsa_amd_dump_tables(uint32_t *base16_words, uint32_t *comb_
  * reference's order of operations (JSF/Shamir chain, lib/ed.c:455-507) and the windowed kernel's
  * result is ignored -- same verdicts, latency-bound, meant for self-checks. */
 EDDSA_AMD_DECL void eddsa_amd_set_offcurve_mode(int exact);
-/* Which evaluation ed25519_verify* uses; the verdicts are the same.  0 (default): passes of more than 2^14 items
- * check u*(S*B - t*A - R) = 0 with half-length u, v = u*t mod 8l (132 doublings instead of 252; items it cannot
- * serve take the reference-order path), smaller passes evaluate S*B - t*A with four lanes per item; 1: the
- * full-length evaluation always; 2: the half-length one always.  A measurement and test aid. */
+/* Which evaluation ed25519_verify* uses; the verdicts are the same.  0 (default): every pass checks
+ * u*(S*B - t*A - R) = 0 with half-length u, v = u*t mod 8l (132 doublings instead of 252; csrc/halve.h) - passes of
+ * up to 2^15 items with four lanes per item, larger ones with one; 1: the full-length evaluation of S*B - t*A
+ * (four lanes per item up to 2^14 items); 2: the half-length one with one lane per item whatever the size.
+ * A measurement and test aid. */
 EDDSA_AMD_DECL void eddsa_amd_set_verify_algo(int algo);
 EDDSA_AMD_DECL void eddsa_amd_set_rlc_min_items(size_t items);   /* see ed25519_verify_batch_rlc */
 /* diagnostic for the tests: the device's search for the half-length pair (u, v), v = u*t mod 8l, on n given scalars

@@ -422,8 +422,8 @@ out:
 }
 
 /* Which evaluation ed25519_verify* uses (same verdicts; a measurement and test aid).  0 (default): half-length
- * scalars (csrc/halve.h) for passes of more than 2^14 items, full-length windows with four lanes per item below;
- * 1: full-length windows always; 2: half-length scalars always. */
+ * scalars (csrc/halve.h), four lanes per item up to 2^15 items and one above; 1: full-length windows always;
+ * 2: half-length scalars with one lane per item always. */
 void eddsa_amd_set_verify_algo(int algo)
 {
     pthread_rwlock_wrlock(&g_table);

@@ -46,7 +46,7 @@ typedef struct edk_verify_ws {
   uint32_t* exact_pad;/* EDK_EXACT_PAD_BYTES: per-lane scratchpad of k_verify_exact */
   hipStream_t side;   /* the exact path runs here, beside the main kernel */
   hipEvent_t ev_prepared, ev_exact;
-  int algo;           /* 0: half-length scalars for passes above 2^14 items, full-length windows below; 1: always full-length; 2: always half-length */
+  int algo;           /* 0: half-length scalars (four lanes per item up to 2^15 items, one above); 1: always full-length; 2: half-length, one lane per item */
   int exact_offcurve; /* 1: replay the reference's chain for off-curve keys (default); 0: reject them; 2: replay for every item */
 } edk_verify_ws;
 
