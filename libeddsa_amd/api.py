@@ -27,6 +27,29 @@ def library_path():
     return os.path.join(_HERE, "libeddsa_amd.so")
 
 
+def _share_the_hip_runtime_with_torch():
+    """A process must hold ONE HIP runtime.  PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's,
+    which libeddsa_amd.so is linked against); whichever is loaded first serves both.  If this library came first,
+    a later `import torch` would bring a second runtime, and the first one then finds no device.  So when PyTorch is
+    installed but not yet imported, load its runtime before ours - the one its tensors will live in."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    for d in (spec.submodule_search_locations or []) if spec else []:
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            path = os.path.join(d, "lib", name)
+            if os.path.exists(path):
+                try:
+                    ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+                except OSError:
+                    return
+
+
 def library():
     """Load libeddsa_amd.so (built in-tree by `make` / __graft_entry__.build())."""
     global _LIB
@@ -36,6 +59,7 @@ def library():
             raise EddsaAmdError(
                 f"{path} is missing: build it with `make` (hipcc --offload-arch=gfx950); "
                 "there is no CPU fallback")
+        _share_the_hip_runtime_with_torch()
         lib = ctypes.CDLL(path)
         lib.eddsa_amd_strerror.restype = ctypes.c_char_p
         lib.ed25519_verify.restype = ctypes.c_bool
