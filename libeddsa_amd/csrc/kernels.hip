@@ -5,7 +5,9 @@
 // item-major byte arrays of the batch API (include/eddsa_amd.h) in and out.
 //
 //   k_x25519_*       x25519.c:129-150 do_x25519                      (config 3)
-//   k_verify_*       ed25519-sha512.c:148-181 ed25519_verify        (config 2, 4)
+//   k_verify_*       ed25519-sha512.c:148-181 ed25519_verify        (config 2, 4): prepare / halve / main_half by
+//                    default (half-length scalars, halve.h), prepare / main / finish for the full-length route,
+//                    *_pair / *_quad forms for small passes, k_verify_exact* for keys that are not curve points
 //   k_sign_*         ed25519-sha512.c:84-123 sign                    (config 5)
 //   k_genpub_point + k_encode_finish          ed25519-sha512.c:53-67 genpub
 //   k_x25519_base_*  x25519.c:158-197 do_x25519_base
@@ -259,7 +261,8 @@ k_verify_main(const uint32_t* digits, const uint32_t* table, const uint32_t* bas
 }
 
 // ---------------------------------------------------------------------------------------------
-// Half-length verification (halve.h), the route of passes above QUAD_MAIN_MAX_N items:
+// Half-length verification (halve.h), one lane per item: the route of passes above HALF_QUAD_MAX_N items (smaller
+// ones: k_verify_prepare_pair + k_verify_main_half_quad further down):
 //   k_verify_prepare    as above
 //   k_verify_halve      (u, v) with v = u t mod 8l from t; s' = |u| S; decompress R strictly, table of 0..8 * -R'
 //   k_verify_main_half  132 doublings + 68 + 16 additions, neutral-element test, verdict byte
@@ -289,7 +292,7 @@ k_verify_halve(const uint8_t* sigs, size_t sig_stride, size_t n, const uint32_t*
   load32(rw, sigs, item, sig_stride);
   const bool rvalid = verify_half_point_lane(rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), rw);
   // An item without a short pair ("long", lanes.h) joins the exact path's work list here: k_verify_main_half's grid
-  // has no slack, and both alternatives measured slower at 2^20 items - the long loop inside this kernel for the
+  // has no slack, and both alternatives measured slower at 2^20 items - the long loop inside that kernel for the
   // waves that contain such an item (one in 180: 7.2 -> 7.8 ms) and a separate four-lane kernel for them beside it
   // (7.4 -> 7.65 ms).  Small passes, whose waves have the chip to themselves, do run the long loop in place
   // (k_verify_main_half_quad).

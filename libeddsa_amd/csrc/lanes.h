@@ -8,6 +8,8 @@
 //   verify_prepare_lane    ed25519-sha512.c:148-172 (hash, scalars, import of -A) + table 0..8 * -A
 //   verify_main_lane       ed.c:455-507 ed_dual_scale (windowed, uniform control flow)
 //   verify_encode_lane     ed.c:155-169 ed_export + ed25519-sha512.c:176-180 (given 1/Z)
+//   verify_half_scalars_lane, verify_half_point_lane, verify_half_main_lane   the same verdict from half-length
+//                          scalars (halve.h): u (S B - t A - R) = 0, 132 doublings
 //   verify_exact_lane      the reference's own JSF/Shamir chain, for keys that are not on the curve
 //   scale_base_lane        ed.c:397-430 ed_scale_base (comb, constant-time select)
 //   genpub_point_lane, sign_point_lane, sign_finish_lane, encode_lane   ed25519-sha512.c:53-123
