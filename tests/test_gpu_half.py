@@ -28,7 +28,7 @@ def restore(engine):
     engine.set_offcurve_mode(True)
 
 
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [0, 1, 2])
 def test_edge_and_torsion_vectors_on_either_evaluation(engine, golden, algo):
     """verify_edges.json (S + k l, non-canonical / small-order / off-curve A, non-canonical R, flipped bits) and
     verify_torsion.json (A = a B + T, R = r B + T' for all 64 pairs of points of order dividing 8: accepted
@@ -86,10 +86,9 @@ def test_forced_half_length_on_small_and_ragged_passes(engine, oracle, n):
     pk[g] = rng.integers(0, 256, (len(g), 32), dtype=np.uint8)
     want = np.array([oracle.verify(sig[i].tobytes(), pk[i].tobytes(), msgs[int(off[i]):int(off[i + 1])].tobytes())
                      for i in range(n)], np.uint8)
-    engine.set_verify_algo(2)
-    assert np.array_equal(engine.ed25519_verify_batch(sig, pk, msgs, msg_off=off), want)
-    engine.set_verify_algo(1)
-    assert np.array_equal(engine.ed25519_verify_batch(sig, pk, msgs, msg_off=off), want)
+    for algo in (0, 2, 1):
+        engine.set_verify_algo(algo)
+        assert np.array_equal(engine.ed25519_verify_batch(sig, pk, msgs, msg_off=off), want), algo
 
 
 def test_reject_mode_keeps_every_on_curve_item(engine, oracle):
@@ -123,7 +122,7 @@ def test_commitments_that_only_decode_permissively(engine, oracle):
     sig, pub, msg = arr(sigs), arr(pubs), arr(msgs)
     want = np.array([oracle.verify(s, p, m) for s, p, m in zip(sigs, pubs, msgs)], np.uint8)
     assert want[:12].sum() >= 8 and want[12:24].sum() == 0          # canonical identity accepted, its signed spelling never
-    for algo in (2, 1):
+    for algo in (0, 2, 1):                         # 0: lane pairs and quads at this size
         engine.set_verify_algo(algo)
         assert np.array_equal(engine.ed25519_verify_batch(sig, pub, msg, msg_len=msg.shape[1]), want), algo
 
@@ -176,3 +175,39 @@ def test_device_pair_search_against_integers(engine):
             found += 1
             assert want and (u, v) == (mu, mv) and u & 1 and (u * t - v) % N == 0, hex(t)
     assert found > len(ts) - 40
+
+
+def test_small_passes_with_items_that_have_no_short_pair(engine, oracle):
+    """a pass of 2^15 signatures (the four-lane route) contains two or three items whose t has no short pair: their
+    waves run 64 windows and the other items of those waves add neutral elements; same bytes as the oracle, also
+    with corrupted items next to them"""
+    import hashlib
+    L = 2**252 + 27742317777372353535851937790883648493
+    N = 8 * L
+
+    def has_pair(t):
+        r0, u0, r1, u1, tried = N, 0, t, 1, False
+        while True:
+            if r1 < (1 << 134):
+                if u1 & 1:
+                    return abs(u1) < (1 << 134)
+                if tried or r1 < (1 << 122):
+                    return False
+                tried = True
+            q = r0 // r1
+            r0, r1, u0, u1 = r1, r0 - q * r1, u1, u0 - q * u1
+
+    n = 1 << 15
+    sk, msg = workload.sign_inputs(n, seed=21, config=2)
+    pk = engine.ed25519_genpub_batch(sk)
+    sig = engine.ed25519_sign_batch(sk, pk, msg)
+    long_items = [i for i in range(n) if not has_pair(
+        int.from_bytes(hashlib.sha512(sig[i, :32].tobytes() + pk[i].tobytes() + msg[i].tobytes()).digest(), "little") % L)]
+    assert 1 <= len(long_items) <= 12, long_items
+    want = np.ones(n, np.uint8)
+    assert np.array_equal(engine.ed25519_verify_batch(sig, pk, msg, msg_len=32), want)
+    for i in long_items[:2]:                       # a neighbour in the same wave, and the long item itself
+        sig[i ^ 1, 40] ^= 1; want[i ^ 1] = 0
+    sig[long_items[-1], 33] ^= 4; want[long_items[-1]] = 0
+    got = engine.ed25519_verify_batch(sig, pk, msg, msg_len=32)
+    assert np.array_equal(got, want) and np.array_equal(oracle.verify_batch(sig, pk, msg, 32), want)
