@@ -224,7 +224,7 @@ constexpr int QUAD_BLOCK = 256;                  // k_verify_main_quad
 constexpr int QUAD_CHAIN_BLOCK = 64;             // k_verify_exact_chain_quad: one wave = 16 items
 static_assert((size_t)QUAD_MAX_ITEMS * QUAD_ITEM_WORDS * 4 <= EDK_EXACT_PAD_BYTES, "scratchpad too small");
 
-__global__ void __launch_bounds__(EXACT_BLOCK, 2)
+__global__ void __launch_bounds__(EXACT_BLOCK, 4)
 k_verify_exact_setup_quad(const uint32_t* digits, const uint32_t* table, const uint32_t* offlist,
                           const uint32_t* offcount, const uint32_t* base16, uint32_t* pad) {
   const size_t g = (size_t)blockIdx.x * EXACT_BLOCK + threadIdx.x;
