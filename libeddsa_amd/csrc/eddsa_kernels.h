@@ -14,12 +14,12 @@
 #define TABLE_COMB_ENTRIES (COMB_ROWS * COMB_HALF) /* comb[i][k] = (k+1) * 2^(2*COMB_W*i) * B, k < COMB_HALF */
 #define TABLE_ENTRY_WORDS 32      /* 3 x 10 limbs + 2 padding words */
 #define VERIFY_TABLE_ENTRIES 9    /* 0..8 times -A, cached form */
-#define VERIFY_ENTRY_WORDS 40     /* ymx | ypx | t2d | z2 */
+#define VERIFY_ENTRY_WORDS 32     /* ymx | ypx | t2d | z2, 255 bits packed into eight words each: one 128-byte line */
 #define COMB_IMG_ENTRIES COMB_HALF       /* LDS image of a comb row: entry m - 1 = m * 2^(2*COMB_W*i) * B, m = 1..COMB_HALF */
 #define COMB_IMG_ENTRY_WORDS 36
 #define COMB_IMG_WORDS (COMB_ROWS * COMB_IMG_ENTRIES * COMB_IMG_ENTRY_WORDS)
 #endif
-#define VERIFY_TABLE_WORDS_PER_TILE (VERIFY_TABLE_ENTRIES * 40 * 256)
+#define VERIFY_TABLE_WORDS_PER_TILE (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS * 256)
 #define VERIFY_TILE 256            /* items per tile = threads per block */
 #define EDK_HALF_DIGIT_WORDS 28     /* = HALF_DIGIT_WORDS of lanes.h */
 #define ACC_WORDS 40               /* point workspace per item: X, Y, Z and one slot for the finish kernels' prefix products */

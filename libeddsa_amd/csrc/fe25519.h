@@ -151,6 +151,32 @@ ED_DEV void fe_fold_top(fe& h, const uint32_t r[10], uint64_t top) {
   ED_SCHED_FENCE();
 }
 
+// 255-bit packing of a tight element for tables in memory (lanes.h: cached entries): the integer sum f_i 2^off(i) as
+// eight little-endian words (no reduction: any representative below 2^256 will do), and back.  Unpacked limbs are
+// exact except the last, which keeps whatever lies above bit 230 (< 2^26).
+ED_DEV constexpr int limb_offset(int i) { return 26 * ((i + 1) / 2) + 25 * (i / 2); }   // 0 26 51 77 102 128 153 179 204 230
+ED_DEV void fe_pack(uint32_t w[8], const fe& f) {
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+#pragma unroll
+    for (int i = 0; i < 10; i++)
+      if ((limb_offset(i) >> 5) == k) acc += (uint64_t)f.v[i] << (limb_offset(i) & 31);
+    w[k] = (uint32_t)acc;
+    acc >>= 32;
+  }
+  ED_CHECK(acc == 0);                            // tight limbs: the sum stays below 2^256
+}
+ED_DEV void fe_unpack(fe& f, const uint32_t w[8]) {
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    const int k = limb_offset(i) >> 5, sh = limb_offset(i) & 31;
+    uint32_t v = w[k] >> sh;
+    if (sh + limb_bits(i) > 32 && k < 7) v |= w[k + 1] << (32 - sh);
+    f.v[i] = i < 9 ? (v & limb_mask(i)) : v;
+  }
+}
+
 // 19 g, for a second operand that many multiplications share (the ladder's x1): computed once
 struct fe19 { uint32_t v[10]; };
 ED_DEV void fe_premul19(fe19& g19, const fe& g) {

@@ -33,7 +33,7 @@
 #define COMB_IMG_ENTRY_WORDS 36   /* 30 limbs + 6 padding words: entries start 4 banks apart */
 #define COMB_IMG_WORDS (COMB_ROWS * COMB_IMG_ENTRIES * COMB_IMG_ENTRY_WORDS)
 #define VERIFY_TABLE_ENTRIES 9    /* 0..8 times -A, cached form */
-#define VERIFY_ENTRY_WORDS 40     /* ymx | ypx | t2d | z2 */
+#define VERIFY_ENTRY_WORDS 32     /* ymx | ypx | t2d | z2, 255 bits packed into eight words each: one 128-byte line */
 
 namespace ed {
 
@@ -202,31 +202,41 @@ ED_DEV void table_entry_lane(uint32_t* dst, uint32_t mult, uint32_t shift) {
 // serialise all 64 lanes of a wave.  Equality of the result with the reference's:
 // DESIGN.md "Why the windowed evaluation is bit-exact".
 
-// table entry = 40 words (ymx | ypx | t2d | z2), contiguous per item so that one lookup reads
-// 160 contiguous bytes (ten 16-byte loads) instead of touching one 128-byte line per word.
+// table entry = 32 words: ymx | ypx | t2d | z2, each packed into eight words (fe_pack), contiguous per item and
+// 128-byte aligned, so that a lookup is ONE L2 line (eight 16-byte loads).  As forty plain limbs an entry straddled
+// two lines, and the table reads - 3 TB/s at 2^20 items - cost the power-bound chip 10 % of the main kernel in clock
+// (measurement); the unpacking costs 2 % in instructions.
 ED_DEV void cached_store(uint32_t* tab, int entry, const ge_cached& c) {
   word4* p = reinterpret_cast<word4*>(tab + entry * VERIFY_ENTRY_WORDS);
   const fe* f[4] = {&c.ymx, &c.ypx, &c.t2d, &c.z2};
-  uint32_t w[40];
 #pragma unroll
-  for (int k = 0; k < 4; k++)
+  for (int k = 0; k < 4; k++) {
+    uint32_t w[8];
+    fe_pack(w, *f[k]);
+    p[2 * k] = word4{w[0], w[1], w[2], w[3]};
+    p[2 * k + 1] = word4{w[4], w[5], w[6], w[7]};
+  }
+}
+// an entry as loaded, so that the loads can be issued a window ahead of their use
+struct cached_raw { word4 q[8]; };
+ED_DEV void cached_load_raw(cached_raw& r, const uint32_t* tab, uint32_t entry) {
+  const word4* p = reinterpret_cast<const word4*>(tab + entry * VERIFY_ENTRY_WORDS);
 #pragma unroll
-    for (int j = 0; j < 10; j++) w[10 * k + j] = f[k]->v[j];
+  for (int q = 0; q < 8; q++) r.q[q] = p[q];
+}
+ED_DEV void cached_from_raw(ge_cached& c, const cached_raw& r) {
+  fe* f[4] = {&c.ymx, &c.ypx, &c.t2d, &c.z2};
 #pragma unroll
-  for (int q = 0; q < 10; q++) p[q] = word4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+  for (int k = 0; k < 4; k++) {
+    const uint32_t w[8] = {r.q[2 * k].x, r.q[2 * k].y, r.q[2 * k].z, r.q[2 * k].w,
+                           r.q[2 * k + 1].x, r.q[2 * k + 1].y, r.q[2 * k + 1].z, r.q[2 * k + 1].w};
+    fe_unpack(*f[k], w);
+  }
 }
 ED_DEV void cached_load(ge_cached& c, const uint32_t* tab, uint32_t entry) {
-  const word4* p = reinterpret_cast<const word4*>(tab + entry * VERIFY_ENTRY_WORDS);
-  uint32_t w[40];
-#pragma unroll
-  for (int q = 0; q < 10; q++) {
-    const word4 v = p[q];
-    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
-  }
-#pragma unroll
-  for (int j = 0; j < 10; j++) {
-    c.ymx.v[j] = w[j]; c.ypx.v[j] = w[10 + j]; c.t2d.v[j] = w[20 + j]; c.z2.v[j] = w[30 + j];
-  }
+  cached_raw r;
+  cached_load_raw(r, tab, entry);
+  cached_from_raw(c, r);
 }
 
 // The three steps of the prepare kernel, separate so that the kernel can load S only when it is needed
@@ -393,21 +403,6 @@ ED_DEV bool verify_half_point_lane(uint32_t* tab, const uint32_t rw[8]) {
   const bool zero_x_signed = (rw[7] >> 31) != 0 && fe_iszero(r.X);
   verify_table_point_lane(tab, r);
   return oncurve && !top && !zero_x_signed;
-}
-
-// a table entry as loaded (ten 16-byte words), so that the loads can be issued a window ahead of their use
-struct cached_raw { word4 q[10]; };
-ED_DEV void cached_load_raw(cached_raw& r, const uint32_t* tab, uint32_t entry) {
-  const word4* p = reinterpret_cast<const word4*>(tab + entry * VERIFY_ENTRY_WORDS);
-#pragma unroll
-  for (int q = 0; q < 10; q++) r.q[q] = p[q];
-}
-ED_DEV void cached_from_raw(ge_cached& c, const cached_raw& r) {
-  uint32_t w[40];
-#pragma unroll
-  for (int q = 0; q < 10; q++) { w[4 * q] = r.q[q].x; w[4 * q + 1] = r.q[q].y; w[4 * q + 2] = r.q[q].z; w[4 * q + 3] = r.q[q].w; }
-#pragma unroll
-  for (int j = 0; j < 10; j++) { c.ymx.v[j] = w[j]; c.ypx.v[j] = w[10 + j]; c.t2d.v[j] = w[20 + j]; c.z2.v[j] = w[30 + j]; }
 }
 
 // returns whether the combination is the neutral element.  WITH_LONG = false: the caller keeps long items out (their

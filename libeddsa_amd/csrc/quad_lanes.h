@@ -254,10 +254,18 @@ ED_DEV void quad_dbl(fe& r, int q) {
 // r += +-entry, entry = words (ymx | ypx | t2d [| z2]) at `e`; has_z2 = false: affine (z2 = 2)
 ED_DEV void quad_add_entry(fe& r, const uint32_t* e, bool neg, bool has_z2, int q) {
   // lane 0 takes y-x (y+x when negated), lane 1 the other, lane 2 2d*t (negated), lane 3 2z
-  const int off = q == 0 ? (neg ? 10 : 0) : q == 1 ? (neg ? 0 : 10) : q == 2 ? 20 : (has_z2 ? 30 : 0);
+  // coordinate index: per-item entries (has_z2) hold packed coordinates of eight words, the shared tables ten limbs
+  const int co = q == 0 ? (neg ? 1 : 0) : q == 1 ? (neg ? 0 : 1) : q == 2 ? 2 : (has_z2 ? 3 : 0);
   fe mult, nm, first, m;
-  quad_coord_load(mult, e + off);
-  if (!has_z2) { fe two; fe_set(two, 2); fe_cmov(mult, two, q == 3); }
+  if (has_z2) {
+    const word4* p = reinterpret_cast<const word4*>(e + 8 * co);
+    const word4 a = p[0], b = p[1];
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    fe_unpack(mult, w);
+  } else {
+    quad_coord_load(mult, e + 10 * co);
+    fe two; fe_set(two, 2); fe_cmov(mult, two, q == 3);
+  }
   fe_neg(nm, mult); fe_carry(nm);
   fe_cmov(mult, nm, neg && q == 2);
   quad_stage_a_operand(first, r, q);

@@ -72,7 +72,7 @@ __host__ inline rlc_layout rlc_carve(size_t cap) {
   L.bdig = o;    o += rlc_align(L.groups * 32);
   L.gflags = o;  o += rlc_align(L.groups * 4);
   L.gok = o;     o += rlc_align(L.groups);
-  L.seg = o;     o += rlc_align(L.groups * RLC_SEGS * 160);      // window points, cached form (40 words)
+  L.seg = o;     o += rlc_align(L.groups * RLC_SEGS * VERIFY_ENTRY_WORDS * 4);      // window points, cached form (packed)
   L.tree = o;    o += rlc_align((cap / RLC_TREE_FAN + 2) * 32 * 2);
   L.seed = o;    o += 256;
   L.total = o;
