@@ -120,8 +120,8 @@ EDDSA_AMD_DECL void eddsa_amd_set_verify_algo(int algo);
 EDDSA_AMD_DECL void eddsa_amd_set_rlc_min_items(size_t items);   /* see ed25519_verify_batch_rlc */
 /* diagnostic for the tests: the device's search for the half-length pair (u, v), v = u*t mod 8l, on n given scalars
  * t < l (32 bytes each, host memory); out48 per item: v (20 bytes, little-endian) | |u| (20) | u < 0 (1) | found (1) |
- * 6 bytes of padding. */
-EDDSA_AMD_DECL int eddsa_amd_debug_halve(uint8_t *out48, const uint8_t *t32, size_t n);
+ * 6 bytes of padding.  wide != 0: |u|, v < 2^138 (what passes below 2^18 items use) instead of 2^134. */
+EDDSA_AMD_DECL int eddsa_amd_debug_halve(uint8_t *out48, const uint8_t *t32, size_t n, int wide);
 
 /* measurement aid: when on, HIP events are recorded on the launch stream around the kernels
  * of every verify pass (up to 256 passes); eddsa_amd_verify_phase_ms() waits for them and returns

@@ -111,13 +111,13 @@ def set_verify_algo(algo=0):
     library().eddsa_amd_set_verify_algo(int(algo))
 
 
-def debug_halve(ts):
+def debug_halve(ts, wide=False):
     """diagnostic: the device's pair search on scalars t (ints below l); returns a list of (found, u, v)"""
     n = len(ts)
     tin = np.frombuffer(b"".join(int(t).to_bytes(32, "little") for t in ts), np.uint8).copy()
     out = np.zeros(48 * max(n, 1), np.uint8)
-    _check(library().eddsa_amd_debug_halve(out.ctypes.data_as(ctypes.c_void_p), tin.ctypes.data_as(ctypes.c_void_p), _c_size(n)),
-           "eddsa_amd_debug_halve")
+    _check(library().eddsa_amd_debug_halve(out.ctypes.data_as(ctypes.c_void_p), tin.ctypes.data_as(ctypes.c_void_p), _c_size(n),
+                                            ctypes.c_int(int(bool(wide)))), "eddsa_amd_debug_halve")
     res = []
     for i in range(n):
         row = out[48 * i:48 * i + 48].tobytes()

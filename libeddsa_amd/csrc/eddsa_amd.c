@@ -432,8 +432,9 @@ void eddsa_amd_set_verify_algo(int algo)
 }
 
 /* diagnostic for the tests: the device's pair search (csrc/halve.h) on n given scalars t (32 bytes each, < l);
- * out48: v (20 bytes) | |u| (20) | u < 0 (1) | found (1) | padding (6) per item.  Host pointers. */
-int eddsa_amd_debug_halve(uint8_t *out48, const uint8_t *t32, size_t n)
+ * out48: v (20 bytes) | |u| (20) | u < 0 (1) | found (1) | padding (6) per item.  wide: the bound 2^138 of passes
+ * below 2^18 items instead of 2^134.  Host pointers. */
+int eddsa_amd_debug_halve(uint8_t *out48, const uint8_t *t32, size_t n, int wide)
 {
     struct call c;
     uint8_t *d_t = NULL, *d_o = NULL;
@@ -443,7 +444,7 @@ int eddsa_amd_debug_halve(uint8_t *out48, const uint8_t *t32, size_t n)
     TRY(hipMalloc((void **)&d_t, n * 32));
     TRY(hipMalloc((void **)&d_o, n * 48));
     TRY(hipMemcpy(d_t, t32, n * 32, hipMemcpyHostToDevice));
-    TRY(edk_debug_halve(d_o, d_t, n, NULL));
+    TRY(edk_debug_halve(d_o, d_t, n, wide, NULL));
     TRY(hipMemcpy(out48, d_o, n * 48, hipMemcpyDeviceToHost));
 out:
     if (d_t) (void)hipFree(d_t);

@@ -92,7 +92,7 @@ hipError_t edk_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, con
                     const edk_fixed_ws* ws, hipStream_t stream);
 hipError_t edk_x25519_base(uint8_t* out, const uint8_t* scalars, size_t n, const uint32_t* comb,
                            const edk_fixed_ws* ws, hipStream_t stream);
-hipError_t edk_debug_halve(uint8_t* out /* 48 bytes per item, device */, const uint8_t* t /* 32 per item, device */, size_t n, hipStream_t stream);
+hipError_t edk_debug_halve(uint8_t* out /* 48 bytes per item, device */, const uint8_t* t /* 32 per item, device */, size_t n, int wide, hipStream_t stream);
 hipError_t edk_pk_to_x(uint8_t* out, const uint8_t* in, size_t n, hipStream_t stream);
 hipError_t edk_sk_to_x(uint8_t* out, const uint8_t* in, size_t n, hipStream_t stream);
 

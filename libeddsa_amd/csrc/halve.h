@@ -30,7 +30,8 @@ inline long halve_counters[2];
 
 constexpr int HALF_WINDOWS = 34;                 // 4-bit signed windows of v and |u|: values < 2^134
 constexpr int HALF_BITS = 134;
-constexpr int HALF_RETRY_MIN_BITS = 122;         // an even u is retried one step later only if r >= 2^122: |u'| <= 8l / r < 2^134
+constexpr int HALF_BITS_SMALL = 138;             // the bound for passes whose main kernel is shorter than the exact path: 35 windows
+constexpr int HALF_WINDOWS_SMALL = 35;
 
 // 8 l, little-endian words
 ED_DEV constexpr uint32_t halve_N(int i) {
@@ -132,7 +133,7 @@ ED_DEV void halve_combine(uint32_t out[W], uint32_t a, const uint32_t x[W], uint
   ED_CHECK(W != 8 || c + (int64_t)ca - (int64_t)cb == 0);
 }
 
-constexpr int HALF_LEHMER_MIN_BITS = 148;        // rounds run while both remainders have more bits than this
+constexpr int HALF_LEHMER_MIN_BITS = 151;        // rounds run while both remainders have more bits than this
 // One round of Lehmer's acceleration: many Euclidean half-steps on the remainders as doubles, then ONE exact update
 // of the long numbers.  With nonnegative integers a0, b0, a1, b1 (kept below 2^24 as doubles)
 //     R0' = a0 R0 - b0 R1,   R1' = b1 R1 - a1 R0      (and the same combinations of U0, U1)
@@ -140,8 +141,8 @@ constexpr int HALF_LEHMER_MIN_BITS = 148;        // rounds run while both remain
 // y0, y1 that track R0', R1' are off by less than (a + b) max(d0, d1) 2^-50 < E := max(d0, d1) 2^-24; every
 // quotient is taken as floor((y0 - E) / (y1 + E)), which cannot exceed the true one, so each half-step applied is a
 // legitimate (possibly partial) Euclidean step and the true remainders stay nonnegative.  A half-step is refused
-// when it cannot be shown to leave its remainder above 2^138 - nothing that halve_scalar_lane's rule would have
-// to examine (remainders below 2^134) is ever produced here; the plain loop does the last bits.
+// when it cannot be shown to leave its remainder above 2^141 - nothing that halve_scalar_lane's rule would have
+// to examine (remainders below 2^134, or 2^138) is ever produced here; the plain loop does the last bits.
 // Returns whether anything was applied.
 ED_DEV bool halve_lehmer_round(uint32_t r0[8], uint32_t r1[8], uint32_t u0[5], uint32_t u1[5], double& d0, double& d1) {
   const double E = (d0 > d1 ? d0 : d1) * 0x1p-24;
@@ -152,12 +153,12 @@ ED_DEV bool halve_lehmer_round(uint32_t r0[8], uint32_t r1[8], uint32_t u0[5], u
     {                                            // R0' by R1'
       const double q = __builtin_floor(halve_ratio(y0 - E, y1 + E) * (1.0 - 0x1p-40));
       const double na = __builtin_fma(q, a1, a0), nb = __builtin_fma(q, b1, b0), ny = __builtin_fma(-q, y1, y0);
-      if (q >= 1.0 && na < 0x1p24 && nb < 0x1p24 && ny - E >= 0x1p138) { a0 = na; b0 = nb; y0 = ny; any = true; }
+      if (q >= 1.0 && na < 0x1p24 && nb < 0x1p24 && ny - E >= 0x1p141) { a0 = na; b0 = nb; y0 = ny; any = true; }
     }
     {                                            // R1' by R0'
       const double q = __builtin_floor(halve_ratio(y1 - E, y0 + E) * (1.0 - 0x1p-40));
       const double na = __builtin_fma(q, a0, a1), nb = __builtin_fma(q, b0, b1), ny = __builtin_fma(-q, y0, y1);
-      if (q >= 1.0 && na < 0x1p24 && nb < 0x1p24 && ny - E >= 0x1p138) { a1 = na; b1 = nb; y1 = ny; any = true; }
+      if (q >= 1.0 && na < 0x1p24 && nb < 0x1p24 && ny - E >= 0x1p141) { a1 = na; b1 = nb; y1 = ny; any = true; }
     }
     live = any;
     progress = progress || any;
@@ -177,7 +178,8 @@ ED_DEV bool halve_lehmer_round(uint32_t r0[8], uint32_t r1[8], uint32_t u0[5], u
   return true;
 }
 
-// |u| < 2^134 for a 160-bit two's complement u; mag = |u|, neg = u < 0
+// |u| < 2^BITS for a 160-bit two's complement u; mag = |u|, neg = u < 0
+template <int BITS = HALF_BITS>
 ED_DEV bool halve_magnitude(uint32_t mag[5], bool& neg, const uint32_t u[5]) {
   neg = (u[4] >> 31) != 0;
   int64_t c = 0;
@@ -187,11 +189,13 @@ ED_DEV bool halve_magnitude(uint32_t mag[5], bool& neg, const uint32_t u[5]) {
     mag[k] = (uint32_t)c;
     c >>= 32;
   }
-  return (mag[4] >> (HALF_BITS - 128)) == 0;
+  return (mag[4] >> (BITS - 128)) == 0;
 }
 
-// t (< l, eight words) -> v (five words, 0 <= v < 2^134), |u| (five words, < 2^134, u odd), uneg = (u < 0)
-// with v = u t (mod 8 l).  Returns false when the item has to take the exact path instead.
+// t (< l, eight words) -> v (five words, 0 <= v < 2^BITS), |u| (five words, < 2^BITS, u odd), uneg = (u < 0)
+// with v = u t (mod 8 l).  Returns false when no such pair is among the candidates examined.  BITS = 134 (34 windows)
+// gives up on 8.5 t in 10^5, BITS = 138 (35 windows; an even u is retried when r >= 2^118) on 2 in 10^7.
+template <int BITS = HALF_BITS>
 ED_DEV bool halve_scalar_lane(uint32_t vw[5], uint32_t uw[5], bool& uneg, const uint32_t tw[8]) {
   uint32_t r0[8], r1[8], u0[5], u1[5];
 #pragma unroll
@@ -205,12 +209,12 @@ ED_DEV bool halve_scalar_lane(uint32_t vw[5], uint32_t uw[5], bool& uneg, const 
   // examine the candidate a completed step has produced (lanes with `fresh` set)
   auto examine = [&](const uint32_t r[8], const uint32_t u[5], bool fresh, int idx) {
     if (!fresh || done) return;
-    if (!halve_below(r, HALF_BITS)) return;
+    if (!halve_below(r, BITS)) return;
     if (u[0] & 1u) {
       uint32_t m[5]; bool ng;
-      good = halve_magnitude(m, ng, u);
+      good = halve_magnitude<BITS>(m, ng, u);
       done = true; which = idx;
-    } else if (tried || halve_below(r, HALF_RETRY_MIN_BITS)) {
+    } else if (tried || halve_below(r, 256 - BITS)) {   // |u'| <= 8l / r < 2^BITS needs r >= 2^(256 - BITS)
       done = true; good = false; which = idx;
     } else {
       tried = true;
@@ -252,7 +256,7 @@ ED_DEV bool halve_scalar_lane(uint32_t vw[5], uint32_t uw[5], bool& uneg, const 
     vw[k] = which ? r1[k] : r0[k];
     usel[k] = which ? u1[k] : u0[k];
   }
-  halve_magnitude(uw, uneg, usel);
+  halve_magnitude<BITS>(uw, uneg, usel);
   return good;
 }
 

@@ -271,6 +271,7 @@ k_verify_main(const uint32_t* digits, const uint32_t* table, const uint32_t* bas
 // Workspace beside the one above: hdigits [item][HALF_DIGIT_WORDS], rtable [item][entry 9][word 40];
 // flags bit 0: this path owns the verdict, bit 2: R is a canonical encoding of a curve point.
 // ---------------------------------------------------------------------------------------------
+template <int BITS>
 __global__ void __launch_bounds__(BLOCK, 2)
 k_verify_halve(const uint8_t* sigs, size_t sig_stride, size_t n, const uint32_t* digits, uint32_t* hdigits,
                uint32_t* rtable, uint8_t* flags, uint32_t* offlist, uint32_t* offcount) {
@@ -284,7 +285,7 @@ k_verify_halve(const uint8_t* sigs, size_t sig_stride, size_t n, const uint32_t*
     tdig[0] = a.x; tdig[1] = a.y; tdig[2] = a.z; tdig[3] = a.w; tdig[4] = b.x; tdig[5] = b.y; tdig[6] = b.z; tdig[7] = b.w;
     sdig[0] = c.x; sdig[1] = c.y; sdig[2] = c.z; sdig[3] = c.w; sdig[4] = e.x; sdig[5] = e.y; sdig[6] = e.z; sdig[7] = e.w;
   }
-  verify_half_scalars_lane(hd, tdig, sdig);
+  verify_half_scalars_lane<BITS>(hd, tdig, sdig);
   uint4* o = reinterpret_cast<uint4*>(hdigits + HALF_DIGIT_WORDS * i);
 #pragma unroll
   for (int q = 0; q < HALF_DIGIT_WORDS / 4; q++) o[q] = make_uint4(hd[4 * q], hd[4 * q + 1], hd[4 * q + 2], hd[4 * q + 3]);
@@ -301,12 +302,13 @@ k_verify_halve(const uint8_t* sigs, size_t sig_stride, size_t n, const uint32_t*
   if ((fl & 1) != 0 && !mine && i < n) offlist[atomicAdd(offcount, 1u)] = (uint32_t)i;
 }
 
+template <int WINDOWS>
 __global__ void __launch_bounds__(BLOCK, 2)
 k_verify_main_half(uint8_t* ok, const uint32_t* hdigits, const uint32_t* table, const uint32_t* rtable,
                    const uint32_t* base16, const uint8_t* flags, size_t n, int exact_offcurve) {
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;   // < workspace capacity
   const uint32_t* hd = hdigits + HALF_DIGIT_WORDS * i;
-  const bool neutral = verify_half_main_lane<false>(hd, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
+  const bool neutral = verify_half_main_lane<false, WINDOWS>(hd, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
                                              rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16, false);
   if (i >= n) return;
   const uint8_t fl = flags[i];
@@ -451,6 +453,7 @@ constexpr size_t QUAD_MAIN_MAX_N = (size_t)1 << 14;   // measured: 0.57 vs 0.86 
 // k_verify_prepare_pair + k_verify_main_half_quad up to here.  Measured (tools/verify_small.py, valid signatures, ms per pass):
 // 2^15 items 0.74 against 1.12 with one lane per item, 2^16 items 1.15 against 1.30 but 1.59 against 1.27 on the config-2 mix
 constexpr size_t HALF_QUAD_MAX_N = (size_t)1 << HALF_QUAD_LOG2;
+constexpr size_t HALF_WIDE_MIN_N = (size_t)1 << 18;   // one-lane passes below this search pairs up to 2^138 (see edk_verify)
 __global__ void __launch_bounds__(QUAD_BLOCK, 2)
 k_verify_main_quad(const uint32_t* digits, const uint32_t* table, const uint32_t* base16, uint32_t* accout, size_t n) {
   const size_t i = ((size_t)blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;       // quads are all-or-nothing
@@ -759,13 +762,14 @@ k_verify_main_half_quad(uint8_t* ok, const uint32_t* hdigits, const uint32_t* ta
 
 // diagnostic (eddsa_amd_debug_halve): halve_scalar_lane on the device for given t; out = v (20 bytes) | |u| (20) |
 // u < 0 (1) | found (1) | 6 bytes of padding per item
+template <int BITS>
 __global__ void __launch_bounds__(BLOCK) k_debug_halve(uint8_t* out, const uint8_t* t, size_t n) {
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   uint32_t tw[8], vw[5], uw[5];
   load32(tw, t, i, 32);
   bool uneg;
-  const bool found = halve_scalar_lane(vw, uw, uneg, tw);
+  const bool found = halve_scalar_lane<BITS>(vw, uw, uneg, tw);
   uint32_t* o = reinterpret_cast<uint32_t*>(out + 48 * i);
 #pragma unroll
   for (int k = 0; k < 5; k++) { o[k] = vw[k]; o[5 + k] = uw[k]; }
@@ -803,9 +807,10 @@ hipError_t edk_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* point
   return hipGetLastError();
 }
 
-hipError_t edk_debug_halve(uint8_t* out, const uint8_t* t, size_t n, hipStream_t stream) {
+hipError_t edk_debug_halve(uint8_t* out, const uint8_t* t, size_t n, int wide, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_debug_halve, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, out, t, n);
+  if (wide) hipLaunchKernelGGL(k_debug_halve<HALF_BITS_SMALL>, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, out, t, n);
+  else hipLaunchKernelGGL(k_debug_halve<HALF_BITS>, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, out, t, n);
   return hipGetLastError();
 }
 
@@ -829,9 +834,16 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   else
     hipLaunchKernelGGL(k_verify_prepare, dim3(blocks), dim3(BLOCK), 0, stream, src, n, ws->digits, ws->table, ws->flags, ws->offlist, ws->offcount,
                        ws->exact_offcurve == 2);
-  if (half)
-    hipLaunchKernelGGL(k_verify_halve, dim3(blocks), dim3(BLOCK), 0, stream, src.sigs, src.sig_stride, n, ws->digits, ws->hdigits,
-                       ws->rtable, ws->flags, ws->offlist, ws->offcount);
+  // Below HALF_WIDE_MIN_N items the main kernel is shorter than the exact path's two (about 1 ms for however few items), so an
+  // item without a short pair would set the time of the pass: such passes search up to 2^138 and run 35 windows (2 t in
+  // 10^7 without a pair instead of 8.5 in 10^5; 3 % more instructions in the main kernel)
+  const bool wide = n < HALF_WIDE_MIN_N;
+  if (half && wide)
+    hipLaunchKernelGGL(k_verify_halve<HALF_BITS_SMALL>, dim3(blocks), dim3(BLOCK), 0, stream, src.sigs, src.sig_stride, n, ws->digits,
+                       ws->hdigits, ws->rtable, ws->flags, ws->offlist, ws->offcount);
+  else if (half)
+    hipLaunchKernelGGL(k_verify_halve<HALF_BITS>, dim3(blocks), dim3(BLOCK), 0, stream, src.sigs, src.sig_stride, n, ws->digits,
+                       ws->hdigits, ws->rtable, ws->flags, ws->offlist, ws->offcount);
   if (marks) (void)hipEventRecord(marks[1], stream);
   // the exact path depends only on what came before: both of its kernels run beside the main kernel on the side stream
   const size_t fast_items = (size_t)QUAD_MAX_ITEMS;
@@ -852,8 +864,12 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
                        ok, ws->hdigits, ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
     if (marks) { (void)hipEventRecord(marks[2], stream); (void)hipEventRecord(marks[3], stream); }
   } else if (half) {
-    hipLaunchKernelGGL(k_verify_main_half, dim3(blocks), dim3(BLOCK), MAIN_LDS_RESERVE, stream, ok, ws->hdigits, ws->table,
-                       ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
+    if (wide)
+      hipLaunchKernelGGL(k_verify_main_half<HALF_WINDOWS_SMALL>, dim3(blocks), dim3(BLOCK), MAIN_LDS_RESERVE, stream, ok, ws->hdigits,
+                         ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
+    else
+      hipLaunchKernelGGL(k_verify_main_half<HALF_WINDOWS>, dim3(blocks), dim3(BLOCK), MAIN_LDS_RESERVE, stream, ok, ws->hdigits,
+                         ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
     if (marks) { (void)hipEventRecord(marks[2], stream); (void)hipEventRecord(marks[3], stream); }
   } else {
     if (small)

@@ -361,7 +361,8 @@ ED_DEV bool verify_encode_lane(const fe& X, const fe& Y, const fe& zinv, const u
 #define HALF_DIGIT_WORDS 28
 constexpr int HALF_LONG_WINDOWS = 64;
 
-// tdig / sdig: the digit words k_verify_prepare wrote (t + 0x88.., S mod l + 0x8000..)
+// tdig / sdig: the digit words k_verify_prepare wrote (t + 0x88.., S mod l + 0x8000..); BITS: halve.h
+template <int BITS = HALF_BITS>
 ED_DEV void verify_half_scalars_lane(uint32_t hd[HALF_DIGIT_WORDS], const uint32_t tdig[8], const uint32_t sdig[8]) {
   uint32_t tw[8], sw[8], vw[5], uw[5], v8[8], u8[8];
 #pragma unroll
@@ -369,7 +370,7 @@ ED_DEV void verify_half_scalars_lane(uint32_t hd[HALF_DIGIT_WORDS], const uint32
   words_sub_pattern(tw, 0x88888888u);
   words_sub_pattern(sw, 0x80008000u);
   bool uneg;
-  const bool found = halve_scalar_lane(vw, uw, uneg, tw);
+  const bool found = halve_scalar_lane<BITS>(vw, uw, uneg, tw);
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     v8[k] = found ? (k < 5 ? vw[k] : 0u) : tw[k];
@@ -410,13 +411,13 @@ ED_DEV bool verify_half_point_lane(uint32_t* tab, const uint32_t rw[8]) {
 // long (wave-uniform; the caller's vote).  The two per-item table entries of a window are requested before the
 // window's four doublings and consumed after them (the kernel runs two waves per SIMD, which is not enough to hide a
 // miss to HBM per addition otherwise).
-template <bool WITH_LONG>
+template <bool WITH_LONG, int WINDOWS = HALF_WINDOWS>
 ED_DEV bool verify_half_main_lane(const uint32_t* hd, const uint32_t* tab_a, const uint32_t* tab_r, const uint32_t* base16,
                                   bool long_loop) {
   ge acc;
   ge_neutral(acc);
   const bool uneg = (hd[24] & 1u) != 0, is_long = WITH_LONG && (hd[24] & 2u) != 0;
-  const int top = (WITH_LONG && long_loop ? HALF_LONG_WINDOWS : HALF_WINDOWS) - 1;
+  const int top = (WITH_LONG && long_loop ? HALF_LONG_WINDOWS : WINDOWS) - 1;
 #pragma unroll 1
   for (int w = top; w >= 0; w--) {
     const int dv = (int)((hd[w >> 3] >> (4 * (w & 7))) & 15u) - 8;

@@ -98,6 +98,18 @@ int hc_verify_half(const uint8_t sig[64], const uint8_t pub[32], const uint8_t* 
   return (neutral && rvalid ? 1 : 0) + (is_long ? 4 : 0);
 }
 
+// the wide form (pairs up to 2^138, 35 windows) that one-lane passes below 2^18 items use
+int hc_verify_half_wide(const uint8_t sig[64], const uint8_t pub[32], const uint8_t* msg, size_t len) {
+  alignas(16) uint32_t tab[VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS], rtab[VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS];
+  uint32_t rw[8], sw[8], aw[8], tw[8], hd[HALF_DIGIT_WORDS];
+  rd(rw, sig); rd(sw, sig + 32); rd(aw, pub);
+  const bool oncurve = verify_prepare_lane(tw, sw, tab, rw, aw, msg, len);
+  verify_half_scalars_lane<HALF_BITS_SMALL>(hd, tw, sw);
+  const bool rvalid = verify_half_point_lane(rtab, rw);
+  if (!oncurve || (hd[24] & 2u) != 0) return 2;   // the exact path
+  return verify_half_main_lane<false, HALF_WINDOWS_SMALL>(hd, tab, rtab, tables().b16(), false) && rvalid ? 1 : 0;
+}
+
 // the same with the long loop forced, as a short item runs it in a wave that contains a long one
 int hc_verify_half_in_long_wave(const uint8_t sig[64], const uint8_t pub[32], const uint8_t* msg, size_t len) {
   alignas(16) uint32_t tab[VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS], rtab[VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS];
@@ -111,11 +123,11 @@ int hc_verify_half_in_long_wave(const uint8_t sig[64], const uint8_t pub[32], co
 }
 
 // halve_scalar_lane: v (20 bytes), |u| (20 bytes), sign of u; returns whether a pair was found
-int hc_halve(uint8_t v[20], uint8_t u[20], int* uneg, const uint8_t t[32]) {
+int hc_halve(uint8_t v[20], uint8_t u[20], int* uneg, const uint8_t t[32], int wide) {
   uint32_t tw[8], vw[5], uw[5];
   rd(tw, t);
   bool ng;
-  const bool good = halve_scalar_lane(vw, uw, ng, tw);
+  const bool good = wide ? halve_scalar_lane<HALF_BITS_SMALL>(vw, uw, ng, tw) : halve_scalar_lane<HALF_BITS>(vw, uw, ng, tw);
   memcpy(v, vw, 20); memcpy(u, uw, 20);
   *uneg = ng ? 1 : 0;
   return good ? 1 : 0;

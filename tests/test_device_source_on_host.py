@@ -363,11 +363,20 @@ def test_halved_scalar_pairs(hostcheck):
     ts += [((1 << 127) * k + 1) % L for k in (2, 6, 10)]
     ts += [int.from_bytes(bytes(rng.integers(0, 256, 32, dtype=np.uint8)), "little") % L for _ in range(3000)]
     found = 0
+    # the wide form (passes below 2^18 items): bound 2^138, retry from 2^118
+    for t in ts[:600]:
+        v, u, neg = ctypes.create_string_buffer(20), ctypes.create_string_buffer(20), ctypes.c_int(0)
+        good = hostcheck.hc_halve(v, u, ctypes.byref(neg), le(t), 1)
+        want, mu, mv = halve_model(t, 138, 118)
+        assert bool(good) == want, hex(t)
+        if good:
+            ui = int.from_bytes(u.raw, "little") * (-1 if neg.value else 1)
+            assert (ui, int.from_bytes(v.raw, "little")) == (mu, mv) and ui & 1 and abs(ui) < 1 << 138 and (ui * t - mv) % N8L == 0
     counters = (ctypes.c_long * 2)()
     hostcheck.hc_halve_counters(counters, 1)
     for t in ts:
         v, u, neg = ctypes.create_string_buffer(20), ctypes.create_string_buffer(20), ctypes.c_int(0)
-        good = hostcheck.hc_halve(v, u, ctypes.byref(neg), le(t))
+        good = hostcheck.hc_halve(v, u, ctypes.byref(neg), le(t), 0)
         want, mu, mv = halve_model(t)
         assert bool(good) == want, hex(t)
         if good:
@@ -398,6 +407,8 @@ def test_verify_half_length_edges_and_torsion(hostcheck, golden):
             assert got & 1 == int(c["accept"]), c["name"]
             # the same item as a short lane of a wave that runs the long loop (neutral additions from window 34 on)
             assert hostcheck.hc_verify_half_in_long_wave(H(c["sig"]), H(c["pub"]), msg, SZ(len(msg))) == int(c["accept"]), c["name"]
+            # and in the wide form of mid-size passes (35 windows)
+            assert hostcheck.hc_verify_half_wide(H(c["sig"]), H(c["pub"]), msg, SZ(len(msg))) in (2, int(c["accept"])), c["name"]
     assert kept > 350
     no_violations(hostcheck)
 

@@ -161,6 +161,13 @@ def test_device_pair_search_against_integers(engine):
             a, b = q * a + b, a
             ts.append(N * b // a % L)
     ts += [int.from_bytes(bytes(rng.integers(0, 256, 32, dtype=np.uint8)), "little") % L for _ in range(20000)]
+    # the wide form of passes below 2^18 items
+    for t, (ok, u, v) in zip(ts[:3000], engine.debug_halve(ts[:3000], wide=True)):
+        want, mu, mv, qmax = model(t, 138, 118)
+        if qmax < (1 << 31) - (1 << 28):
+            assert ok == want, hex(t)
+        if ok:
+            assert want and (u, v) == (mu, mv) and u & 1 and abs(u) < 1 << 138 and (u * t - v) % N == 0, hex(t)
     got = engine.debug_halve(ts)
     found = 0
     for t, (ok, u, v) in zip(ts, got):
