@@ -77,6 +77,7 @@ EDDSA_AMD_DECL void eddsa_amd_shutdown(void);
  * balanced (shards differ by at most one item). */
 EDDSA_AMD_DECL int eddsa_amd_init_devices(const int *devices, int n);
 EDDSA_AMD_DECL int eddsa_amd_device_count(void);
+EDDSA_AMD_DECL int eddsa_amd_device_at(int index);   /* the HIP device that owns shard `index` of the set, or -1 */
 EDDSA_AMD_DECL void eddsa_amd_shard_bounds(size_t n, int rank, int world, size_t *lo, size_t *hi);
 /* host pointers, whole batch in host memory: one host thread per device runs that device's streaming
  * pipeline on its shard and copies the results straight into the caller's buffer (no collective) */
@@ -123,6 +124,15 @@ EDDSA_AMD_DECL void eddsa_amd_set_rlc_min_items(size_t items);   /* see ed25519_
  * t < l (32 bytes each, host memory); out48 per item: v (20 bytes, little-endian) | |u| (20) | u < 0 (1) | found (1) |
  * 6 bytes of padding.  wide != 0: |u|, v < 2^138 (what passes below 2^18 items use) instead of 2^134. */
 EDDSA_AMD_DECL int eddsa_amd_debug_halve(uint8_t *out48, const uint8_t *t32, size_t n, int wide);
+
+/* diagnostic for the tests: the half-length route re-verifies every pair with integers before it is used (u t = v mod 8 l)
+ * and falls back to (u, v) = (1, t) when the check fails; *count = how often that has happened on the default device since
+ * its workspaces were allocated.  Waits for the device.  Expected, and observed over the 2^24-item batch: 0. */
+EDDSA_AMD_DECL int eddsa_amd_halve_refused(uint64_t *count);
+
+/* test hook: the next host-pointer call fails with hipErrorUnknown after its inputs were staged and its kernels launched
+ * (exercises the error path: the staging copies of secrets are wiped there as on success) */
+EDDSA_AMD_DECL void eddsa_amd_debug_fail_next_host_call(void);
 
 /* measurement aid: when on, HIP events are recorded on the launch stream around the kernels
  * of every verify pass (up to 256 passes); eddsa_amd_verify_phase_ms() waits for them and returns

@@ -126,6 +126,13 @@ def debug_halve(ts, wide=False):
     return res
 
 
+def halve_refused():
+    """diagnostic: half-length pairs refused by the exact integer check on the default device (expected 0)"""
+    out = ctypes.c_uint64(0)
+    _check(library().eddsa_amd_halve_refused(ctypes.byref(out)), "eddsa_amd_halve_refused")
+    return int(out.value)
+
+
 def set_rlc_min_items(items):
     """ed25519_verify_batch_rlc calls with fewer items go straight to the per-item kernels (default 3 x 2^17,
     the measured break-even; 0 = always try the combination)"""
@@ -469,8 +476,18 @@ def ed25519_verify_batch_multi_dev(sigs, pubs, msgs, msg_len, n_total):
     if not (len(sigs) == len(pubs) == len(msgs) == g):
         raise ValueError(f"expected one shard per device of the set ({g})")
     outs, streams = [], []
+    from .sharding import shard_bounds
     for d in range(g):
         _torch_check(sigs[d], 64, "sigs"); _torch_check(pubs[d], 32, "pubs"); _torch_check(msgs[d], 0, "msgs")
+        # the C entry point trusts its pointers: a short shard would be read out of bounds on the device, a shard on
+        # another device than the set's d-th would be launched on the wrong stream
+        lo, hi = shard_bounds(n_total, d, g)
+        if sigs[d].numel() != 64 * (hi - lo) or pubs[d].numel() != 32 * (hi - lo) or msgs[d].numel() != int(msg_len) * (hi - lo):
+            raise ValueError(f"shard {d}: expected {hi - lo} items (shard_bounds({n_total}, {d}, {g})) in sigs, pubs and msgs")
+        want_dev = int(library().eddsa_amd_device_at(d))
+        for t, nm in ((sigs[d], "sigs"), (pubs[d], "pubs"), (msgs[d], "msgs")):
+            if t.device.index != want_dev:
+                raise ValueError(f"shard {d}: {nm} lives on cuda:{t.device.index}, the set's device {d} is cuda:{want_dev}")
         outs.append(torch.empty((n_total,), dtype=torch.uint8, device=sigs[d].device))
         streams.append(torch.cuda.current_stream(sigs[d].device).cuda_stream)
     P = ctypes.c_void_p * g

@@ -51,6 +51,7 @@ struct vslot {
     hipEvent_t free;                  /* recorded after the last kernel that touches ws, fws or rws */
     hipStream_t last_stream;
     unsigned long stamp;              /* for least-recently-used */
+    int busy;                         /* held by a batch-verification pass that has left e->lk to wait for its stream */
 };
 
 /* host-pointer entry points: staging buffers and streams of the streaming pipeline (pipe_run) */
@@ -68,6 +69,7 @@ struct pipe {
 struct engine {
     int device;
     pthread_mutex_t lk, pipe_lk;
+    pthread_cond_t slot_cv;            /* signalled (under lk) when a busy workspace slot is released */
     uint32_t *base16, *comb;           /* generated base-point tables (HBM) */
     uint32_t *comb_img;                /* the comb as the point kernels stage it in LDS (lanes.h: comb_select) */
     struct vslot vs[VERIFY_SLOTS];
@@ -83,6 +85,7 @@ static int g_default = -1;            /* device of the host-pointer entry points
 static int g_verify_algo = 0;         /* eddsa_amd_set_verify_algo: 0 by pass size (default), 1 full-length windows, 2 half-length scalars */
 static int g_offcurve_mode = 1;       /* eddsa_amd_set_offcurve_mode: 0 reject, 1 exact (default), 2 all exact */
 static int g_profiling;               /* record marks around the three verify kernels */
+static int g_fail_next_host_call;      /* eddsa_amd_debug_fail_next_host_call: test hook for the error path of pipe_run_on */
 static size_t g_rlc_min_items = (size_t)3 << 17;   /* eddsa_amd_set_rlc_min_items: smaller calls go to the per-item kernels */
 
 /* the device set of the *_multi entry points (eddsa_amd_init_devices) */
@@ -205,6 +208,8 @@ static int ws_reserve(struct vslot *v, size_t items)
     TRY(hipMalloc((void **)&v->ws.flags, cap));
     TRY(hipMalloc((void **)&v->ws.offlist, cap * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&v->ws.offcount, 256));
+    TRY(hipMemset(v->ws.offcount, 0, 256));
+    TRY(hipStreamSynchronize(NULL));      /* the pass's stream does not wait for the null stream */
     TRY(hipMalloc((void **)&v->ws.exact_pad, EDK_EXACT_PAD_BYTES));
     v->ws.capacity = cap;
 out:
@@ -228,21 +233,27 @@ out:
     return rc;
 }
 
-/* caller holds e->lk: the slot a pass on stream `st` uses */
+/* caller holds e->lk: the slot a pass on stream `st` uses.  Slots marked busy (rlc_on, while it waits for its
+ * stream outside the lock) are not handed out; when all are, the caller waits for one to be released. */
 static struct vslot *ws_pick(struct engine *e, hipStream_t st)
 {
-    struct vslot *idle = NULL, *lru = &e->vs[0];
-    for (int i = 0; i < VERIFY_SLOTS; i++) {
-        struct vslot *v = &e->vs[i];
-        if (v->stamp && v->last_stream == st) { lru = v; idle = NULL; goto found; }
-        if (!idle && (v->stamp == 0 || hipEventQuery(v->free) == hipSuccess)) idle = v;
-        if (v->stamp < lru->stamp) lru = v;
+    for (;;) {
+        struct vslot *idle = NULL, *lru = NULL;
+        for (int i = 0; i < VERIFY_SLOTS; i++) {
+            struct vslot *v = &e->vs[i];
+            if (v->busy) continue;
+            if (v->stamp && v->last_stream == st) { lru = v; idle = NULL; break; }
+            if (!idle && (v->stamp == 0 || hipEventQuery(v->free) == hipSuccess)) idle = v;
+            if (!lru || v->stamp < lru->stamp) lru = v;
+        }
+        if (idle) lru = idle;
+        if (lru) {
+            lru->last_stream = st;
+            lru->stamp = ++e->clock;
+            return lru;
+        }
+        pthread_cond_wait(&e->slot_cv, &e->lk);
     }
-found:
-    if (idle) lru = idle;
-    lru->last_stream = st;
-    lru->stamp = ++e->clock;
-    return lru;
 }
 
 static void pipe_release(struct pipe *p);
@@ -270,6 +281,7 @@ static void engine_destroy(struct engine *e)
         for (int i = 0; i < 4; i++) if (e->marks[s][i]) (void)hipEventDestroy(e->marks[s][i]);
     pthread_mutex_destroy(&e->lk);
     pthread_mutex_destroy(&e->pipe_lk);
+    pthread_cond_destroy(&e->slot_cv);
     free(e);
 }
 
@@ -286,6 +298,7 @@ static int engine_create(int device)
     e->device = device;
     pthread_mutex_init(&e->lk, NULL);
     pthread_mutex_init(&e->pipe_lk, NULL);
+    pthread_cond_init(&e->slot_cv, NULL);
     (void)hipGetDevice(&saved);
     TRY(hipSetDevice(device));
     TRY(hipGetDeviceProperties(&prop, device));
@@ -449,6 +462,37 @@ int eddsa_amd_debug_halve(uint8_t *out48, const uint8_t *t32, size_t n, int wide
 out:
     if (d_t) (void)hipFree(d_t);
     if (d_o) (void)hipFree(d_o);
+    leave(&c);
+    return rc;
+}
+
+/* test hook: the next host-pointer call fails (hipErrorUnknown) after its inputs were staged and its kernels launched,
+ * so that the error path's clean-up (tests: the staging copies of secrets are wiped there too) can be exercised */
+void eddsa_amd_debug_fail_next_host_call(void)
+{
+    pthread_rwlock_wrlock(&g_table);
+    g_fail_next_host_call = 1;
+    pthread_rwlock_unlock(&g_table);
+}
+
+/* diagnostic for the tests: how many half-length pairs the exact integer check (csrc/lanes.h: verify_half_scalars_lane)
+ * has refused on the default device since its workspaces were allocated.  Waits for the device.  Expected: 0. */
+int eddsa_amd_halve_refused(uint64_t *count)
+{
+    struct call c;
+    int rc = enter(&c, -1);
+    if (rc) return rc;
+    *count = 0;
+    pthread_mutex_lock(&c.e->lk);
+    TRY(hipDeviceSynchronize());
+    for (int i = 0; i < VERIFY_SLOTS; i++) {
+        uint32_t w = 0;
+        if (!c.e->vs[i].ws.offcount) continue;
+        TRY(hipMemcpy(&w, c.e->vs[i].ws.offcount + EDK_REFUSED_WORD, sizeof(w), hipMemcpyDeviceToHost));
+        *count += w;
+    }
+out:
+    pthread_mutex_unlock(&c.e->lk);
     leave(&c);
     return rc;
 }
@@ -645,11 +689,15 @@ static int rlc_on(struct engine *e, uint8_t *ok, uint32_t *stats, const edk_veri
         if (!rc) { hipError_t er = edk_rlc_note_per_item(stats, n, st); if (er != hipSuccess) rc = -(int)er; }
         return rc;
     }
+    /* The combination's group verdicts are read by the host, once per pass.  The wait for the stream happens OUTSIDE
+     * e->lk (other threads keep enqueueing on this engine meanwhile); the workspace slot stays reserved through its
+     * busy mark, which ws_pick honours. */
     pthread_mutex_lock(&e->lk);
     struct vslot *v = ws_pick(e, st);
+    v->busy = 1;
     rc = ws_reserve(v, n < CHUNK_MAX ? n : CHUNK_MAX);
     if (!rc) rc = rws_reserve(v, n < CHUNK_MAX ? n : CHUNK_MAX);
-    if (rc) goto unlock;
+    if (rc) goto release;
     v->ws.exact_offcurve = g_offcurve_mode ? g_offcurve_mode : 1;
     v->ws.algo = g_verify_algo;
     TRY(hipStreamWaitEvent(st, v->free, 0));
@@ -660,11 +708,18 @@ static int rlc_on(struct engine *e, uint8_t *ok, uint32_t *stats, const edk_veri
         src.pubs += done * all->pub_stride;
         if (all->msg_off) src.msg_off += done; else src.msgs += done * all->msg_stride;
         TRY(edk_verify_rlc(ok + done, stats, &src, m, e->base16, &v->ws, &v->rws, st));
+        pthread_mutex_unlock(&e->lk);
+        hipError_t er = hipStreamSynchronize(st);
+        pthread_mutex_lock(&e->lk);
+        TRY(er);
+        TRY(edk_verify_rlc_fallback(ok + done, &src, m, e->base16, &v->ws, &v->rws, st));
     }
     TRY(hipEventRecord(v->free, st));
 out:
     if (rc) slot_quiesce(v, st);
-unlock:
+release:
+    v->busy = 0;
+    pthread_cond_broadcast(&e->slot_cv);
     pthread_mutex_unlock(&e->lk);
     return rc;
 }
@@ -903,6 +958,7 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
                             (const uint8_t *)p->d_msgs[s], ragged ? (const uint64_t *)p->d_off : NULL,
                             j->msg_len, m, p->exec);
             }
+            if (!rc && g_fail_next_host_call) { g_fail_next_host_call = 0; rc = -(int)hipErrorUnknown; }
             if (rc) goto out;
             if (!single) TRY(hipEventRecord(p->exec_done[s], p->exec));
             /* download chunk k-1 (its kernels were launched one iteration ago) */
@@ -929,7 +985,14 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
         if (!single) TRY(hipStreamSynchronize(up));
     }
 out:
-    if (rc && p->ready) { (void)hipStreamSynchronize(p->up); (void)hipStreamSynchronize(p->exec); (void)hipStreamSynchronize(p->down); }
+    if (rc && p->ready) {
+        (void)hipStreamSynchronize(p->up); (void)hipStreamSynchronize(p->exec); (void)hipStreamSynchronize(p->down);
+        /* a failed call must not leave its secrets behind either (best effort: whatever was staged, whole buffers) */
+        if (j->wipe & WIPE_IN0)
+            for (int s = 0; s < 2; s++) if (p->d_in[s][0]) (void)hipMemsetAsync(p->d_in[s][0], 0, p->in_cap[s][0], p->exec);
+        if ((j->wipe & WIPE_OUT) && p->d_out) (void)hipMemsetAsync(p->d_out, 0, p->out_cap, p->exec);
+        if (j->wipe) (void)hipStreamSynchronize(p->exec);
+    }
     pthread_mutex_unlock(&e->pipe_lk);
     return rc;
 }
@@ -1159,6 +1222,15 @@ int eddsa_amd_device_count(void)
     const int n = g_multi.n;
     pthread_rwlock_unlock(&g_table);
     return n;
+}
+
+/* the HIP device that owns shard `index` of the set (the order given to eddsa_amd_init_devices), or -1 */
+int eddsa_amd_device_at(int index)
+{
+    pthread_rwlock_rdlock(&g_table);
+    const int dev = index >= 0 && index < g_multi.n ? g_multi.dev[index] : -1;
+    pthread_rwlock_unlock(&g_table);
+    return dev;
 }
 
 /* host-pointer forms: thread d runs the ordinary streaming pipeline of device d on shard d; results

@@ -22,6 +22,7 @@
 #define VERIFY_TABLE_WORDS_PER_TILE (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS * 256)
 #define VERIFY_TILE 256            /* items per tile = threads per block */
 #define EDK_HALF_DIGIT_WORDS 28     /* = HALF_DIGIT_WORDS of lanes.h */
+#define EDK_REFUSED_WORD 8
 #define ACC_WORDS 40               /* point workspace per item: X, Y, Z and one slot for the finish kernels' prefix products */
 
 #ifdef __cplusplus
@@ -42,7 +43,8 @@ typedef struct edk_verify_ws {
   uint32_t* rtable;   /* like table: 0..8 times -R' */
   uint8_t* flags;     /* capacity bytes */
   uint32_t* offlist;  /* capacity words: the exact path's work list (keys off the curve; large passes: items without a short pair) */
-  uint32_t* offcount; /* 1 word */
+  uint32_t* offcount; /* 64 words, zeroed at allocation: [0] the length of offlist (zeroed by every pass), [EDK_REFUSED_WORD] half-length
+                         pairs that the exact check of lanes.h: verify_half_scalars_lane refused since allocation (diagnostic) */
   uint32_t* exact_pad;/* EDK_EXACT_PAD_BYTES: per-lane scratchpad of k_verify_exact */
   hipStream_t side;   /* the exact path runs here, beside the main kernel */
   hipEvent_t ev_prepared, ev_exact;
@@ -80,8 +82,12 @@ typedef struct edk_rlc_ws {
 #define EDK_RLC_HOST_BYTES 4096
 size_t edk_rlc_ws_bytes(size_t capacity);
 hipError_t edk_rlc_note_per_item(uint32_t* stats, size_t n, hipStream_t stream);
+/* one pass in two halves: edk_verify_rlc enqueues the combination and the copy of the group verdicts to rws->host_gok;
+ * the caller synchronises `stream`; edk_verify_rlc_fallback hands the groups that did not pass to the per-item kernels */
 hipError_t edk_verify_rlc(uint8_t* ok, uint32_t* stats, const edk_verify_src* src, size_t n, const uint32_t* base16,
                           const edk_verify_ws* ws, const edk_rlc_ws* rws, hipStream_t stream);
+hipError_t edk_verify_rlc_fallback(uint8_t* ok, const edk_verify_src* src, size_t n, const uint32_t* base16,
+                                   const edk_verify_ws* ws, const edk_rlc_ws* rws, hipStream_t stream);
 
 hipError_t edk_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* points, size_t n,
                       const edk_fixed_ws* ws, hipStream_t stream);

@@ -24,8 +24,18 @@ namespace ed {
 #ifdef ED_HOST_CHECK
 inline long halve_counters[2];
 #define HALVE_COUNT(i) (++::ed::halve_counters[i])
+// fault injection (tests only): n > 0 makes the n-th working half-step from now on take a quotient that is one too
+// large - the failure the floating-point margins exist to exclude (the remainder wraps; the search then usually runs
+// into its own give-up rules) - and n < 0 makes the |n|-th working half-step update the COFACTOR with a quotient one
+// too large (remainders, hence the choice of the pair, stay right; the pair's congruence is broken).  Whatever comes
+// out, lanes.h: verify_half_scalars_lane must not let a wrong pair through.
+inline int halve_fault;
+#define HALVE_FAULT(q, active) do { if ((active) && ::ed::halve_fault > 0 && --::ed::halve_fault == 0) (q) += 1u; } while (0)
+#define HALVE_FAULT_COFACTOR(q, active) do { if ((active) && ::ed::halve_fault < 0 && ++::ed::halve_fault == 0) (q) += 1u; } while (0)
 #else
 #define HALVE_COUNT(i) ((void)0)
+#define HALVE_FAULT(q, active) ((void)0)
+#define HALVE_FAULT_COFACTOR(q, active) ((void)0)
 #endif
 
 constexpr int HALF_WINDOWS = 34;                 // 4-bit signed windows of v and |u|: values < 2^134
@@ -90,6 +100,7 @@ ED_DEV bool halve_reduce(uint32_t ra[8], uint32_t ua[5], const uint32_t rb[8], c
   uint32_t q = (uint32_t)qd;
   q = q < 1u ? 1u : q;
   q = active && !big ? q : 0u;
+  HALVE_FAULT(q, active && !big);
   uint64_t carry = 0;
   int64_t c = 0;
 #pragma unroll
@@ -101,6 +112,7 @@ ED_DEV bool halve_reduce(uint32_t ra[8], uint32_t ua[5], const uint32_t rb[8], c
     carry >>= 32;
   }
   ED_CHECK(c == 0 && carry == 0);                // q <= floor(ra / rb): no borrow out
+  HALVE_FAULT_COFACTOR(q, active && !big);
   carry = 0;
   c = 0;
 #pragma unroll

@@ -286,6 +286,7 @@ k_verify_halve(const uint8_t* sigs, size_t sig_stride, size_t n, const uint32_t*
     sdig[0] = c.x; sdig[1] = c.y; sdig[2] = c.z; sdig[3] = c.w; sdig[4] = e.x; sdig[5] = e.y; sdig[6] = e.z; sdig[7] = e.w;
   }
   verify_half_scalars_lane<BITS>(hd, tdig, sdig);
+  if ((hd[24] & 4u) != 0 && i < n) atomicAdd(offcount + EDK_REFUSED_WORD, 1u);   // a pair the exact check refused: never seen (diagnostic)
   uint4* o = reinterpret_cast<uint4*>(hdigits + HALF_DIGIT_WORDS * i);
 #pragma unroll
   for (int q = 0; q < HALF_DIGIT_WORDS / 4; q++) o[q] = make_uint4(hd[4 * q], hd[4 * q + 1], hd[4 * q + 2], hd[4 * q + 3]);
@@ -720,6 +721,7 @@ k_verify_prepare_pair(edk_verify_src src, size_t n, uint32_t* digits, uint32_t* 
     uint4* o = reinterpret_cast<uint4*>(hdigits + HALF_DIGIT_WORDS * i);
 #pragma unroll
     for (int q = 0; q < HALF_DIGIT_WORDS / 4; q++) o[q] = make_uint4(hd[4 * q], hd[4 * q + 1], hd[4 * q + 2], hd[4 * q + 3]);
+    if ((hd[24] & 4u) != 0) atomicAdd(offcount + EDK_REFUSED_WORD, 1u);
   }
   // lane 0: -A permissively (ed.c:100-149), lane 1: -R' strictly (lanes.h: verify_half_point_lane)
   uint32_t pw[8];

@@ -356,7 +356,7 @@ ED_DEV bool verify_encode_lane(const fe& X, const fe& Y, const fe& zinv, const u
 // read over 64 windows ("long"; f_j*B then for every j < 16 and no g); its wave runs the long loop, in which the
 // short items of the wave add neutral elements from window 34 on.  About one wave in 180 is long.
 // hd (HALF_DIGIT_WORDS per item): v + 0x88.. [0,8) | |u| + 0x88.. [8,16) | s' + 0x8000.. [16,24) |
-// [24]: bit 0 = (u < 0), bit 1 = long.
+// [24]: bit 0 = (u < 0), bit 1 = long, bit 2 = the search returned a pair that failed the exact check (diagnostic: never seen).
 // ---------------------------------------------------------------------------------------------
 #define HALF_DIGIT_WORDS 28
 constexpr int HALF_LONG_WINDOWS = 64;
@@ -370,7 +370,45 @@ ED_DEV void verify_half_scalars_lane(uint32_t hd[HALF_DIGIT_WORDS], const uint32
   words_sub_pattern(tw, 0x88888888u);
   words_sub_pattern(sw, 0x80008000u);
   bool uneg;
-  const bool found = halve_scalar_lane<BITS>(vw, uw, uneg, tw);
+  bool found = halve_scalar_lane<BITS>(vw, uw, uneg, tw);
+  // The pair search takes its quotients from doubles under hand-derived error margins (halve.h); a wrong pair would be
+  // a silent wrong verdict, so the congruence it promises is re-verified here with integers before anything depends
+  // on it:  u t = v (mod 8 l)  <=>  W := |u| t - sign(u) v  is divisible by l and by 8 (l is odd).  W (13 words, >= 0
+  // for a correct pair: v < 8 l) by a 5 x 8-word schoolbook product, W mod l by the Barrett reduction every scalar
+  // goes through, W mod 8 from its low word.  A pair that fails is dropped like a give-up: the item keeps
+  // (u, v) = (1, t), the reference's own equation.
+  bool mismatch;
+  {
+    uint32_t W[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) W[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      uint64_t c = 0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        c += (uint64_t)uw[i] * tw[j] + W[i + j];  // < 2^64: (2^32 - 1)^2 + 2 (2^32 - 1)
+        W[i + j] = (uint32_t)c;
+        c >>= 32;
+      }
+      W[i + 8] = (uint32_t)c;
+    }
+    int64_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+      c += (int64_t)W[k] + (k < 5 ? (uneg ? (int64_t)vw[k] : -(int64_t)vw[k]) : 0);
+      W[k] = (uint32_t)c;
+      c >>= 32;
+    }
+    sc wl;
+    sc_from_words<16>(wl, W);                    // W mod l (meaningless when W < 0: c != 0 then)
+    uint32_t nz = 0;
+#pragma unroll
+    for (int k = 0; k < 10; k++) nz |= wl.v[k];
+    const bool holds = c == 0 && nz == 0 && (W[0] & 7u) == 0 && (uw[0] & 1u) != 0;
+    mismatch = found && !holds;
+    found = found && holds;
+  }
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     v8[k] = found ? (k < 5 ? vw[k] : 0u) : tw[k];
@@ -387,7 +425,7 @@ ED_DEV void verify_half_scalars_lane(uint32_t hd[HALF_DIGIT_WORDS], const uint32
   words_add_pattern(u8, 0x88888888u);
 #pragma unroll
   for (int k = 0; k < 8; k++) { hd[k] = v8[k]; hd[8 + k] = u8[k]; hd[16 + k] = sw[k]; }
-  hd[24] = (uneg ? 1u : 0u) | (found ? 0u : 2u);
+  hd[24] = (uneg ? 1u : 0u) | (found ? 0u : 2u) | (mismatch ? 4u : 0u);
   hd[25] = 0; hd[26] = 0; hd[27] = 0;
 }
 

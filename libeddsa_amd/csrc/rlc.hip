@@ -19,11 +19,17 @@
 // and an encoding produced by ed_export is always canonical); A that does not decode to a curve point
 // (lib/ed.c:100-149 never fails) or has small order, and R of small order, send their group to the
 // per-item kernels.
-// CAVEAT (why this is opt-in): for crafted inputs whose A or R carry a small-order component the terms
-// above are computed with scalars reduced mod l and small-order parts of several items can cancel, so a
-// group may pass although the reference's cofactorless per-item check would reject one of its items
-// (or fail although all pass; that case only costs time).  z_i is odd, so a single such item in a group
-// never passes.
+// The key's scalar z_i t_i is taken mod 8 l, not mod l (rlc_lanes.h: rlc_key_scalar_mod_8l; z_i itself is an
+// integer on R_i and B has order l), so every term is exactly z_i Q_i with Q_i = S_i B - t_i A_i - R_i also
+// when A_i or R_i carries a component of order dividing 8 (the reference checks neither subgroup membership
+// nor small order).  z_i is odd and below l, hence coprime to the group order 8 l: a combination
+// of ONE item passes exactly when the per-item check accepts it.
+// CAVEAT (why this is opt-in): the small-order parts D_i of the Q_i live in a group of eight elements, where
+// no choice of coefficients separates them: TWO OR MORE crafted items in one group can cancel -- equal
+// defects of order 2 always do (odd z_1 + odd z_2 is even), of order 4 with probability 1/2, of order 8
+// with 1/4, and whoever controls two items of a group can grind the deterministic coefficients -- so a group
+// may pass although the reference's cofactorless per-item check rejects those items (or fail although all
+// pass; that case only costs time).  tests/test_device_source_on_host.py pins both statements.
 //
 // The multi-scalar multiplication is a bucket method laid out for the wavefront: one workgroup of 128
 // lanes per (group, byte-window), 128 buckets for the signed 8-bit digits: the workgroup counting-sorts
@@ -32,7 +38,7 @@
 // (mixed additions, ed_add_pc's 7 M), and the weighted sum of the 128 buckets is two log-step scans
 // through LDS; k_rlc_final then runs Horner over the 48 window points of each group (four lanes per
 // point, quad_lanes.h: 248 dependent doublings are pure latency).
-// -A_i has 32 windows (z_i t_i mod l), -R_i 16 (z_i), B one entry per group and window: 48 mixed
+// -A_i has 32 windows (z_i t_i mod 8 l, centred: |.| <= 4 l), -R_i 16 (z_i), B one entry per group and window: 48 mixed
 // additions per item instead of the per-item kernel's 252 doublings + 80 additions.  Algorithmic HBM
 // bytes: the same 129 per item as verify.  The per-lane arithmetic (decoding and routing flags,
 // coefficients, digit recoding) is in rlc_lanes.h, which the host-check build also compiles.
@@ -401,11 +407,12 @@ k_rlc_final(size_t n, const uint32_t* segpts, const uint32_t* gflags, uint8_t* g
     if (sgm >= RLC_SEGS_A - RLC_SEGS_R)
       quad_add_entry(r, pts + (RLC_SEGS_A + sgm - (RLC_SEGS_A - RLC_SEGS_R)) * VERIFY_ENTRY_WORDS, false, true, q);
   }
-  // neutral element: X = 0 and Y = Z (lane 0 holds X, lane 1 Y, lane 3 Z)
+  // neutral element: X = 0, Y = Z and Z != 0 (lane 0 holds X, lane 1 Y, lane 3 Z), as verify_half_main_quad tests it:
+  // (0, 0, *, 0) is no point, and is unreachable only while every combined point is on the curve
   fe z, d;
   fe_quad_perm<3, 3, 3, 3>(z, r);
   fe_sub(d, r, z);                               // lane 1: Y - Z
-  const bool mine = q == 0 ? fe_iszero(r) : q == 1 ? fe_iszero(d) : true;
+  const bool mine = q == 0 ? fe_iszero(r) : q == 1 ? fe_iszero(d) : q == 3 ? !fe_iszero(r) : true;
   const int all = (int)mine & __shfl_xor((int)mine, 1) ;
   const bool neutral = (all & __shfl_xor(all, 2)) != 0;
   if (q != 0) return;
@@ -447,6 +454,8 @@ extern "C" hipError_t edk_rlc_note_per_item(uint32_t* stats, size_t n, hipStream
 
 extern "C" size_t edk_rlc_ws_bytes(size_t capacity) { return capacity ? rlc_carve(capacity).total : 0; }
 
+// First half of a pass: everything the combination itself needs, and the copy of the group verdicts to the
+// host (pinned).  The caller synchronises `stream` and then calls edk_verify_rlc_fallback.
 extern "C" hipError_t edk_verify_rlc(uint8_t* ok, uint32_t* stats, const edk_verify_src* srcp, size_t n,
                                      const uint32_t* base16, const edk_verify_ws* ws, const edk_rlc_ws* rws,
                                      hipStream_t stream) {
@@ -498,11 +507,19 @@ extern "C" hipError_t edk_verify_rlc(uint8_t* ok, uint32_t* stats, const edk_ver
   hipLaunchKernelGGL(k_rlc_verdicts, dim3(blocks), dim3(RLC_BLOCK), 0, stream, n, gok, flags, ok);
   if ((e = hipGetLastError()) != hipSuccess) return e;
 
-  // groups the combination did not accept: the per-item kernels decide (this is the one place where the
-  // host looks at a result: the call synchronises the stream once)
-  uint8_t* h_gok = static_cast<uint8_t*>(rws->host_gok);
-  if ((e = hipMemcpyAsync(h_gok, gok, groups, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+  // groups the combination did not accept: the per-item kernels decide (edk_verify_rlc_fallback).  This is the
+  // one place where the host looks at a result: the caller synchronises the stream once per pass.
+  return hipMemcpyAsync(rws->host_gok, gok, groups, hipMemcpyDeviceToHost, stream);
+}
+
+// Second half, once the stream has been synchronised: runs of groups that did not pass go to the per-item kernels
+extern "C" hipError_t edk_verify_rlc_fallback(uint8_t* ok, const edk_verify_src* srcp, size_t n, const uint32_t* base16,
+                                              const edk_verify_ws* ws, const edk_rlc_ws* rws, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const edk_verify_src src = *srcp;
+  const size_t groups = (n + RLC_G - 1) / RLC_G;
+  const uint8_t* h_gok = static_cast<const uint8_t*>(rws->host_gok);
+  hipError_t e;
   for (size_t g = 0; g < groups;) {
     if (h_gok[g]) { g++; continue; }
     size_t g1 = g;

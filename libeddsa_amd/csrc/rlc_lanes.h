@@ -91,9 +91,41 @@ ED_DEV void rlc_hash_lane(uint32_t tw[8], uint32_t sw[8], uint32_t leaf[8], cons
   for (int k = 0; k < 8; k++) leaf[k] = lf[k];
 }
 
-// The coefficient z_i = the low 126 bits of SHA-512(seed || i || "rlc"), made odd; a = z t mod l and
-// zs = z S mod l (9 words, the top one 0); the signed byte digits of a (32) and z (16): digit j =
-// byte j of (x + 0x80...80) - 128, the recoding of ed.c:407-409 with 8-bit windows.
+// l as eight little-endian words
+ED_DEV constexpr uint32_t rlc_L(int i) {
+  constexpr uint32_t Lw[8] = {0x5cf5d3edu, 0x5812631au, 0xa2f79cd6u, 0x14def9deu, 0x00000000u, 0x00000000u, 0x00000000u, 0x10000000u};
+  return Lw[i];
+}
+
+// The key's scalar as an integer a' with |a'| <= 4 l and a' = z t (mod 8 l), from a0 = z t mod l: A may carry a
+// component of order dividing 8 (the reference checks neither subgroup membership nor small order), on
+// which z t and z t mod l act differently, so the class mod l alone does not determine a'*A.  z t = a0 + k l with
+// k = (z t - a0) / l, and l = 5 (mod 8) is its own inverse there: k mod 8 = 5 (z t - a0) mod 8, which needs the
+// low words only.  Centred, k' in [-4, 3]: a' = a0 + k' l is negative exactly when k' is (a0 < l).  mag = |a'|
+// (below 2^255: no carry out of the recoding), returns a' < 0.
+ED_DEV bool rlc_key_scalar_mod_8l(uint32_t mag[8], const uint32_t a0[8], uint32_t z_lo, uint32_t t_lo) {
+  const uint32_t k = (((z_lo * t_lo - a0[0]) & 7u) * 5u) & 7u;
+  const bool neg = k >= 4u;
+  const uint32_t kk = neg ? 8u - k : k;          // |k'| <= 4
+  uint64_t p = 0;
+  int64_t c = 0;
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    p += (uint64_t)kk * rlc_L(q);
+    c += (int64_t)(uint32_t)p + (neg ? -(int64_t)a0[q] : (int64_t)a0[q]);
+    mag[q] = (uint32_t)c;
+    c >>= 32;
+    p >>= 32;
+  }
+  ED_CHECK(c + (int64_t)p == 0);                 // 0 <= |a'| <= 4 l < 2^255
+  return neg;
+}
+
+// The coefficient z_i = the low 126 bits of SHA-512(seed || i || "rlc"), made odd; a' = z t mod 8 l, centred
+// (rlc_key_scalar_mod_8l), and zs = z S mod l (9 words, the top one 0; B has order l); the signed byte digits of
+// a' (32) and z (16): for a value x >= 0 digit j = byte j of (x + 0x80...80) - 128, the recoding of ed.c:407-409
+// with 8-bit windows; a negative a' = -m takes the negated digits of m under the mirrored recoding (byte j of
+// (m + 0x7f...7f) - 127, in [-127, 128]), so that every digit stays in [-128, 127].
 ED_DEV void rlc_scalars_lane(int8_t dig_a[RLC_WINDOWS_A], int8_t dig_r[RLC_WINDOWS_R], uint32_t zs[9],
                              const uint32_t seed[8], uint64_t i, const uint32_t tw[8], const uint32_t sw[8]) {
   uint32_t pre[16], h[16], zw[8], aw[8];
@@ -114,14 +146,23 @@ ED_DEV void rlc_scalars_lane(int8_t dig_a[RLC_WINDOWS_A], int8_t dig_r[RLC_WINDO
   sc_mul(s, z, s);
   sc_to_words(zs, s);
   zs[8] = 0;
-  words_add_pattern(aw, 0x80808080u);            // a < 2^253: no carry out of bit 255
+  uint32_t tr[8];
+  sc_to_words(tr, t);                            // t mod l as the per-item check takes it (sc.c:191-214); tw already is
+  uint32_t m[8];
+  const bool a_neg = rlc_key_scalar_mod_8l(m, aw, zw[0], tr[0]);
+#pragma unroll
+  for (int q = 0; q < 8; q++) aw[q] = m[q];
+  words_add_pattern(aw, a_neg ? 0x7f7f7f7fu : 0x80808080u);   // |a'| < 2^255: no carry out of bit 255
   {
     uint64_t c = 0;                              // z < 2^126: no carry out of bit 127
 #pragma unroll
     for (int q = 0; q < 4; q++) { c += (uint64_t)zw[q] + 0x80808080u; zw[q] = (uint32_t)c; c >>= 32; }
   }
 #pragma unroll
-  for (int wd = 0; wd < RLC_WINDOWS_A; wd++) dig_a[wd] = (int8_t)((int)((aw[wd >> 2] >> (8 * (wd & 3))) & 0xffu) - 128);
+  for (int wd = 0; wd < RLC_WINDOWS_A; wd++) {
+    const int byte = (int)((aw[wd >> 2] >> (8 * (wd & 3))) & 0xffu);
+    dig_a[wd] = (int8_t)(a_neg ? 127 - byte : byte - 128);
+  }
 #pragma unroll
   for (int wd = 0; wd < RLC_WINDOWS_R; wd++) dig_r[wd] = (int8_t)((int)((zw[wd >> 2] >> (8 * (wd & 3))) & 0xffu) - 128);
 }

@@ -81,8 +81,9 @@ int hc_verify(const uint8_t sig[64], const uint8_t pub[32], const uint8_t* msg, 
 }
 
 // the half-length path (halve.h; k_verify_prepare + k_verify_halve + k_verify_main_half) for one item:
-// 0 / 1 = its verdict (+ 4 when no short pair was found and the item ran the long loop), 2 = the item is handed
-// to the exact path (key off the curve)
+// 0 / 1 = its verdict (+ 4 when no short pair was found and the item ran the long loop, + 8 when the search returned
+// a pair that the exact integer check of verify_half_scalars_lane refused), 2 = the item is handed to the exact path
+// (key off the curve)
 int hc_verify_half(const uint8_t sig[64], const uint8_t pub[32], const uint8_t* msg, size_t len) {
   alignas(16) uint32_t tab[VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS], rtab[VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS];
   uint32_t rw[8], sw[8], aw[8], tw[8], hd[HALF_DIGIT_WORDS];
@@ -95,8 +96,11 @@ int hc_verify_half(const uint8_t sig[64], const uint8_t pub[32], const uint8_t* 
   // short items as k_verify_main_half evaluates them, long ones as their wave of k_verify_main_half_quad does
   const bool neutral = is_long ? verify_half_main_lane<true>(hd, tab, rtab, tables().b16(), true)
                                : verify_half_main_lane<false>(hd, tab, rtab, tables().b16(), false);
-  return (neutral && rvalid ? 1 : 0) + (is_long ? 4 : 0);
+  return (neutral && rvalid ? 1 : 0) + (is_long ? 4 : 0) + ((hd[24] & 4u) ? 8 : 0);   // + 8: the pair failed the exact check
 }
+
+// fault injection into the pair search (halve.h: HALVE_FAULT): the n-th working half-step takes a quotient one too large
+void hc_halve_fault(int n) { halve_fault = n; }
 
 // the wide form (pairs up to 2^138, 35 windows) that one-lane passes below 2^18 items use
 int hc_verify_half_wide(const uint8_t sig[64], const uint8_t pub[32], const uint8_t* msg, size_t len) {

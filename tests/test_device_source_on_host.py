@@ -295,9 +295,74 @@ def test_rlc_coefficients_and_digits(hostcheck):
         z = (int.from_bytes(h[:16], "little") & (2**126 - 1)) | 1
         assert all(-128 <= d <= 127 for d in list(da) + list(dr))
         assert sum(d << (8 * j) for j, d in enumerate(dr)) == z
-        assert sum(d << (8 * j) for j, d in enumerate(da)) == z * t % L
+        # the key's scalar: z t mod 8 l, centred (a torsion component of A must see z t itself, not z t mod l)
+        av = sum(d << (8 * j) for j, d in enumerate(da))
+        assert (av - z * t) % (8 * L) == 0 and abs(av) <= 4 * L and (av < 0) == ((z * t // L) % 8 >= 4)
         assert int.from_bytes(zs.raw, "little") == z * s % L
     assert hostcheck.hc_violations() == 0, hostcheck.hc_first_violation()
+
+
+def _mixed_order_signatures(oracle, count, tors_index, seed):
+    """signatures whose prime-order part is honest under keys A' = a B + T, T = small_order_points()[tors_index]: the
+    reference's sign takes the public key as an argument without checking it (lib/ed25519-sha512.c:84-123), so
+    sign(sk, A', M) is R = r B, S = r + H(R | A' | M) a, and S B - t A' - R = -t T: accepted iff ord(T) divides t"""
+    from gen_golden import ed_add_affine, ed_dec, ed_enc, small_order_points
+    rng = np.random.default_rng(seed)
+    T = ed_dec(small_order_points()[tors_index])
+    out = []
+    for _ in range(count):
+        sk = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+        msg = bytes(rng.integers(0, 256, 24, dtype=np.uint8))
+        a1 = ed_enc(ed_add_affine(ed_dec(oracle.genpub(sk)), T))
+        out.append((oracle.sign(sk, a1, msg), a1, msg))
+    return out
+
+
+def _torsion_order(index):
+    from gen_golden import ed_add_affine, ed_dec, small_order_points
+    T = ed_dec(small_order_points()[index])
+    acc, k = T, 1
+    while acc != (0, 1):
+        acc, k = ed_add_affine(acc, T), k + 1
+    return k
+
+
+def test_rlc_single_item_groups_are_exact_on_mixed_order_points(hostcheck, oracle, golden):
+    """A ONE-item combination z (S B - t A - R) with z odd, z < l decides exactly what the reference's per-item check
+    decides, whatever small-order components A and R carry - provided the key's scalar is z t mod 8 l and not
+    z t mod l (with the latter 51 of 400 such signatures passed that the reference rejects).  Checked
+    on the 192 reference-pinned vectors of verify_torsion.json and on 400 fresh signatures under A = a B + T8."""
+    import ctypes
+    valid = (ctypes.c_uint8 * 1)()
+    for c in golden("verify_torsion.json"):
+        msg = H(c["msg"])
+        got = hostcheck.hc_rlc_group(valid, H(c["sig"]), H(c["pub"]), msg, SZ(len(msg)), 1)
+        assert got == int(c["accept"]) and valid[0] == 1, c["name"]
+    idx8 = [i for i in range(8) if _torsion_order(i) == 8][0]
+    accepted = 0
+    for sig, pub, msg in _mixed_order_signatures(oracle, 400, idx8, 31):
+        want = int(oracle.verify(sig, pub, msg))
+        t = int.from_bytes(hashlib.sha512(sig[:32] + pub + msg).digest(), "little") % L
+        assert want == (t % 8 == 0)
+        assert hostcheck.hc_rlc_group(valid, sig, pub, msg, SZ(len(msg)), 1) == want
+        accepted += want
+    assert 25 <= accepted <= 80                                    # about one in eight
+    assert hostcheck.hc_violations() == 0, hostcheck.hc_first_violation()
+
+
+def test_rlc_documented_caveat_two_crafted_items_can_cancel(hostcheck, oracle):
+    """What the opt-in mode does NOT promise (include/eddsa_amd.h): two or more crafted items in ONE group.  Two items
+    whose defects -t T are the same point of order 2 always cancel (the coefficients are odd), so the group passes
+    although the reference rejects both; this pins the documented statement, it is not a goal."""
+    import ctypes
+    idx2 = [i for i in range(8) if _torsion_order(i) == 2][0]
+    items = [x for x in _mixed_order_signatures(oracle, 40, idx2, 32) if not oracle.verify(*x)][:2]
+    assert len(items) == 2                                         # t odd: the reference rejects each
+    sig = b"".join(x[0] for x in items); pub = b"".join(x[1] for x in items); msg = b"".join(x[2] for x in items)
+    valid = (ctypes.c_uint8 * 2)()
+    assert hostcheck.hc_rlc_group(valid, sig, pub, msg, SZ(24), 2) == 1
+    for k in range(2):                                             # alone, each is rejected
+        assert hostcheck.hc_rlc_group(valid, items[k][0], items[k][1], items[k][2], SZ(24), 1) == 0
 
 
 def test_rlc_whole_group_by_double_and_add(hostcheck, oracle):
@@ -463,4 +528,37 @@ def test_items_without_a_short_pair_run_the_long_loop(hostcheck, oracle):
         assert hostcheck.hc_verify_half(bad, pk, msg, SZ(len(msg))) == 4
         bad = bytes([sig[0] ^ 2]) + sig[1:]
         assert hostcheck.hc_verify_half(bad, pk, msg, SZ(len(msg))) & 1 == 0
+    no_violations(hostcheck)
+
+
+def test_a_wrong_quotient_in_the_pair_search_is_caught_by_the_exact_check(hostcheck, oracle):
+    """the pair search takes its quotients from doubles; verify_half_scalars_lane re-verifies
+    u t = v (mod 8 l) with integers and drops a pair that fails (the item then keeps (u, v) = (1, t)).  Two injected
+    faults (halve.h: HALVE_FAULT): a quotient one too large at the n-th half-step of the plain loop - the failure the
+    margins exclude; the remainder wraps and the search usually ends in one of its own give-ups - and the same
+    quotient reaching only the cofactor update, which leaves a plausible pair with a broken congruence.  Required:
+    the verdict is the reference's every time, and every broken pair that the search returns is refused (+ 8)."""
+    sk = bytes(range(1, 33))
+    pk = oracle.genpub(sk)
+    refused = {1: 0, -1: 0}
+    for i in range(40):
+        msg = b"fault injection %d" % i
+        sig = oracle.sign(sk, pk, msg)
+        bad = sig[:45] + bytes([sig[45] ^ 4]) + sig[46:]
+        for s_, want in ((sig, 1), (bad, 0)):
+            for sign in (1, -1):
+                hostcheck.hc_halve_fault(sign * (1 + i % 7))
+                got = hostcheck.hc_verify_half(s_, pk, msg, SZ(len(msg)))
+                hostcheck.hc_halve_fault(0)
+                assert got & 1 == want, (i, sign, got)
+                if got & 8:
+                    assert got & 4                          # a refused pair means the long loop
+                    refused[sign] += 1
+    assert refused[-1] >= 70, refused                       # a wrong cofactor always leaves a pair to refuse
+    hostcheck.hc_reset()                                    # the injected faults tripped the no-borrow assertions, as they must
+    # and without injection nothing is ever refused
+    for i in range(200):
+        msg = b"no fault %d" % i
+        sig = oracle.sign(sk, pk, msg)
+        assert hostcheck.hc_verify_half(sig, pk, msg, SZ(len(msg))) in (1, 5)
     no_violations(hostcheck)

@@ -57,6 +57,29 @@ def test_config4_full_2_24_on_one_gpu(engine, golden):
     # the record form and the host-pointer pipeline on one 2^21 shard (config 4's per-GPU share)
     lo, hi = 3 * (n // 8), 4 * (n // 8)
     assert np.array_equal(engine.ed25519_verify_batch(sig[lo:hi], pk[lo:hi], msg[lo:hi], msg_len=32), expect[lo:hi])
+    # every pair of the half-length route passed its exact integer check (lanes.h: verify_half_scalars_lane)
+    assert engine.halve_refused() == 0
+    # SURVEY 8(e) as the C-ABI does it: one process, EVERY visible device, shard d resident on device d, one RCCL
+    # all-gather of the verdict bytes (grouped broadcasts when the shards differ in length).  One device on the
+    # round's box (world size 1); on a multi-GPU node the same assertions cover the real gather: the reference's
+    # digest in EVERY device's buffer, once with even shards (2^24) and once with uneven ones (2^24 - 3).
+    g = engine.init_devices()
+    assert g == torch.cuda.device_count()
+    to = lambda a, d: torch.from_numpy(np.ascontiguousarray(a)).to(f"cuda:{d}")  # noqa: E731
+    for total in (n, n - 3):
+        shards = [engine.shard_bounds(total, d, g) for d in range(g)]
+        assert total != n or g not in (1, 2, 4, 8) or all(hi - lo == n // g for lo, hi in shards)
+        outs = engine.ed25519_verify_batch_multi_dev([to(sig[lo:hi], d) for d, (lo, hi) in enumerate(shards)],
+                                                     [to(pk[lo:hi], d) for d, (lo, hi) in enumerate(shards)],
+                                                     [to(msg[lo:hi], d) for d, (lo, hi) in enumerate(shards)], 32, total)
+        for d, o in enumerate(outs):
+            torch.cuda.synchronize(d)
+            got = o.cpu().numpy()
+            assert np.array_equal(got, expect[:total]), (total, d)
+            if total == n:
+                assert hashlib.sha512(got.tobytes()).hexdigest() == v["verdicts_sha512"], d
+        del outs
+        torch.cuda.empty_cache()
 
 
 def _bench(args, env_extra=None, timeout=1500):
@@ -216,6 +239,13 @@ def test_secrets_do_not_outlive_the_call_in_hbm(engine):
     engine.shutdown()
     engine.x25519_batch(dev(sk), dev(pt)); torch.cuda.synchronize()
     assert engine.secret_residue() == (0, 0, 0, 0)
+    # a call that FAILS after staging its inputs wipes them as well (one chunk, and two)
+    for m in (1000, n):
+        engine.library().eddsa_amd_debug_fail_next_host_call()
+        with pytest.raises(engine.EddsaAmdError):
+            engine.x25519_batch(sk[:m], pt[:m])
+        assert engine.secret_residue() == (0, 0, 0, 0), m
+    assert np.array_equal(engine.x25519_batch(sk[:64], pt[:64]), engine.x25519_batch(dev(sk[:64]), dev(pt[:64])).cpu().numpy())
     engine.shutdown()
     msgs = rng.integers(0, 256, (n, 32), dtype=np.uint8)
     pk = engine.ed25519_genpub_batch(sk)

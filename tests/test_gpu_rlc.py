@@ -175,3 +175,83 @@ def test_coefficients_depend_on_the_whole_batch(engine):
     perm = np.random.default_rng(0).permutation(n)
     c = engine.ed25519_verify_batch_rlc(sig[perm], pk[perm], msg[perm], msg_len=32)
     assert np.array_equal(c, want[perm])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# mixed-order keys and commitments (VERDICT r02 / ADVICE r02): A = a B + T, R = r B + T' with T, T' of order dividing 8.
+# The key's scalar of the combination is z t mod 8 l (rlc_lanes.h: rlc_key_scalar_mod_8l), so a ONE-item combination is
+# exactly the per-item check; with z t mod l one such item in eight passed that the reference rejects.
+# ---------------------------------------------------------------------------------------------------------
+def _torsion_cases(golden):
+    cases = golden("verify_torsion.json")
+    sig = np.array([list(bytes.fromhex(c["sig"])) for c in cases], np.uint8)
+    pub = np.array([list(bytes.fromhex(c["pub"])) for c in cases], np.uint8)
+    msgs = [bytes.fromhex(c["msg"]) for c in cases]
+    want = np.array([c["accept"] for c in cases], np.uint8)
+    return sig, pub, msgs, want
+
+
+def test_torsion_fixture_as_one_item_combinations(engine, golden):
+    """each of the 192 reference-pinned vectors as its own call (a group of one): the fixture's verdict, and decided by the
+    combination itself whenever that verdict is 'accept' (a rejected one falls to the per-item kernels, same verdict)"""
+    sig, pub, msgs, want = _torsion_cases(golden)
+    by_combination = 0
+    for i in range(len(msgs)):
+        m = np.frombuffer(msgs[i], np.uint8)
+        ok, st = engine.ed25519_verify_batch_rlc(sig[i:i + 1], pub[i:i + 1], m, msg_len=len(msgs[i]), return_stats=True)
+        assert ok.tolist() == [want[i]], i
+        assert st == ((1, 0, 0, 1) if want[i] else (0, 1, 1, 0)), (i, st)
+        by_combination += st[3]
+    assert by_combination == int(want.sum()) == 27
+
+
+def test_torsion_fixture_one_vector_per_group_in_valid_traffic(engine, golden):
+    """the same vectors, one in each of 192 groups of otherwise genuine signatures (two passes): a group passes by
+    combination exactly when its vector is one the reference accepts, and every verdict byte is the fixture's"""
+    sig, pub, msgs, want = _torsion_cases(golden)
+    k, mlen = len(msgs), len(msgs[0])
+    assert all(len(m) == mlen for m in msgs)
+    n = k * G
+    gs, gp, gm = _signed(engine, n, 41, mlen=mlen)
+    slots = np.arange(k) * G + (np.arange(k) * 37 + 11) % G
+    gs[slots], gp[slots] = sig, pub
+    gm[slots] = np.array([list(m) for m in msgs], np.uint8)
+    expect = np.ones(n, np.uint8)
+    expect[slots] = want
+    ok, st = engine.ed25519_verify_batch_rlc(dev(gs), dev(gp), dev(gm), msg_len=mlen, return_stats=True)
+    assert np.array_equal(ok.cpu().numpy(), expect)
+    acc = int(want.sum())
+    assert st == (acc * G, (k - acc) * G, k - acc, acc)
+
+
+def test_mixed_order_keys_never_pass_a_combination_the_reference_rejects(engine, oracle):
+    """400 signatures with an honest prime-order part under keys A' = a B + T8 (sign takes the key unchecked,
+    lib/ed25519-sha512.c:84-123): S B - t A' - R = -t T8, accepted by the reference iff 8 | t.  One-item combinations
+    and one-per-group in valid traffic: no accept the oracle rejects (it was 51 of 400 with the scalar mod l)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gen_golden import ed_add_affine, ed_dec, ed_enc, small_order_points
+    t8 = ed_dec(small_order_points()[4])
+    assert ed_add_affine(ed_add_affine(t8, t8), ed_add_affine(t8, t8)) == (0, P - 1)     # 4 T8 = (0, -1): order 8
+    k, mlen = 400, 24
+    rng = np.random.default_rng(31)
+    sk = rng.integers(0, 256, (k, 32), dtype=np.uint8)
+    msg = rng.integers(0, 256, (k, mlen), dtype=np.uint8)
+    pk = engine.ed25519_genpub_batch(dev(sk)).cpu().numpy()
+    pk1 = np.array([list(ed_enc(ed_add_affine(ed_dec(pk[i].tobytes()), t8))) for i in range(k)], np.uint8)
+    sig = engine.ed25519_sign_batch(dev(sk), dev(pk1), dev(msg)).cpu().numpy()
+    want = oracle.verify_batch(sig, pk1, msg, mlen)
+    assert 25 <= int(want.sum()) <= 80                                   # about one in eight
+    assert np.array_equal(engine.ed25519_verify_batch(sig, pk1, msg, msg_len=mlen), want)
+    for i in range(k):
+        ok, st = engine.ed25519_verify_batch_rlc(sig[i:i + 1], pk1[i:i + 1], msg[i], msg_len=mlen, return_stats=True)
+        assert ok.tolist() == [want[i]] and st[3] == want[i], i
+    groups = 64
+    gs, gp, gm = _signed(engine, groups * G, 43, mlen=mlen)
+    slots = np.arange(groups) * G + 5
+    gs[slots], gp[slots], gm[slots] = sig[:groups], pk1[:groups], msg[:groups]
+    expect = np.ones(groups * G, np.uint8)
+    expect[slots] = want[:groups]
+    ok, st = engine.ed25519_verify_batch_rlc(dev(gs), dev(gp), dev(gm), msg_len=mlen, return_stats=True)
+    assert np.array_equal(ok.cpu().numpy(), expect)
+    assert st[3] == int(want[:groups].sum()) and st[2] == groups - st[3]
