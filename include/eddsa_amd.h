@@ -128,7 +128,7 @@ EDDSA_AMD_DECL int eddsa_amd_debug_halve(uint8_t *out48, const uint8_t *t32, siz
 /* diagnostic for the tests: the half-length route re-verifies every pair with integers before it is used (u t = v mod 8 l)
  * and falls back to (u, v) = (1, t) when the check fails; *count = how often that has happened on the default device since
  * its workspaces were allocated.  Waits for the device.  Expected, and observed over the 2^24-item batch: 0. */
-EDDSA_AMD_DECL int eddsa_amd_halve_refused(uint64_t *count);
+EDDSA_AMD_DECL int eddsa_amd_halve_rejected(uint64_t *count);
 
 /* test hook: the next host-pointer call fails with hipErrorUnknown after its inputs were staged and its kernels launched
  * (exercises the error path: the staging copies of secrets are wiped there as on success) */

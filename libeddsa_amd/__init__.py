@@ -11,7 +11,7 @@ from .api import (  # noqa: F401
     EddsaAmdError,
     DH,
     debug_halve,
-    halve_refused,
+    halve_rejected,
     ed25519_genpub,
     ed25519_genpub_batch,
     ed25519_sign,

@@ -126,10 +126,10 @@ def debug_halve(ts, wide=False):
     return res
 
 
-def halve_refused():
+def halve_rejected():
     """diagnostic: half-length pairs refused by the exact integer check on the default device (expected 0)"""
     out = ctypes.c_uint64(0)
-    _check(library().eddsa_amd_halve_refused(ctypes.byref(out)), "eddsa_amd_halve_refused")
+    _check(library().eddsa_amd_halve_rejected(ctypes.byref(out)), "eddsa_amd_halve_rejected")
     return int(out.value)
 
 

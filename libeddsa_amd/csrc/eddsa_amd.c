@@ -477,7 +477,7 @@ void eddsa_amd_debug_fail_next_host_call(void)
 
 /* diagnostic for the tests: how many half-length pairs the exact integer check (csrc/lanes.h: verify_half_scalars_lane)
  * has refused on the default device since its workspaces were allocated.  Waits for the device.  Expected: 0. */
-int eddsa_amd_halve_refused(uint64_t *count)
+int eddsa_amd_halve_rejected(uint64_t *count)
 {
     struct call c;
     int rc = enter(&c, -1);

@@ -58,7 +58,7 @@ def test_config4_full_2_24_on_one_gpu(engine, golden):
     lo, hi = 3 * (n // 8), 4 * (n // 8)
     assert np.array_equal(engine.ed25519_verify_batch(sig[lo:hi], pk[lo:hi], msg[lo:hi], msg_len=32), expect[lo:hi])
     # every pair of the half-length route passed its exact integer check (lanes.h: verify_half_scalars_lane)
-    assert engine.halve_refused() == 0
+    assert engine.halve_rejected() == 0
     # SURVEY 8(e) as the C-ABI does it: one process, EVERY visible device, shard d resident on device d, one RCCL
     # all-gather of the verdict bytes (grouped broadcasts when the shards differ in length).  One device on the
     # round's box (world size 1); on a multi-GPU node the same assertions cover the real gather: the reference's
