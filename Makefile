@@ -17,13 +17,13 @@ $(BUILD)/kernels.o: $(CSRC)/kernels.hip $(wildcard $(CSRC)/*.h)
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(BUILD)/eddsa_amd.o: $(CSRC)/eddsa_amd.c $(CSRC)/eddsa_kernels.h include/eddsa.h include/eddsa_amd.h
+$(BUILD)/%.o: $(CSRC)/%.c $(CSRC)/engine.h $(CSRC)/eddsa_kernels.h include/eddsa.h include/eddsa_amd.h
 	@mkdir -p $(BUILD)
 	$(CC) $(CFLAGS) -c $< -o $@
 
 # SONAME = the reference's (libeddsa.so.0, reference lib/CMakeLists.txt:43-44): a program linked against
 # the reference loads this library through the libeddsa.so.0 link without being relinked.
-$(LIB): $(BUILD)/kernels.o $(BUILD)/rlc.o $(BUILD)/eddsa_amd.o
+$(LIB): $(BUILD)/kernels.o $(BUILD)/rlc.o $(BUILD)/eddsa_amd.o $(BUILD)/host_pipe.o
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -Wl,-soname,libeddsa.so.0 -o $@ $^ -lpthread -ldl
 	ln -sf libeddsa_amd.so libeddsa_amd/libeddsa.so.0
 

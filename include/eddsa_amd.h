@@ -38,8 +38,15 @@
  * own duration and restores the caller's before it returns.
  * Threading: calls may be issued from several host threads.  Device-pointer calls on different
  * streams use different workspaces (a pool of four per device) and overlap on the GPU; calls on one
- * stream are ordered by the stream; host-pointer calls on one device share its staging pipeline
- * and run one after the other.  eddsa_amd_shutdown waits for calls in flight.
+ * stream are ordered by the stream.  Host-pointer calls on one device share its staging pipeline: large
+ * calls run one after the other; SMALL calls (up to 64 items, fixed-length messages - among them every call
+ * of the eddsa.h single-item functions) issued by several threads at once are merged: the calls queued for
+ * one operation travel as ONE launch and every caller gets its own results back (the reference is
+ * reentrant and scales with its caller's threads, lib/eddsa.h:44-80; a GPU pass costs about 0.4 ms however
+ * few items it carries).  eddsa_amd_shutdown waits for calls in flight.
+ * Host memory: ordinary (malloc) memory is staged through page-locked buffers by a few copier threads
+ * (eddsa_amd_set_host_threads); page-locked caller memory (eddsa_amd_host_alloc, hipHostMalloc,
+ * hipHostRegister) is used in place.
  * Secrets: the staging copies of secret keys / scalars / shared secrets and the secret scalars that
  * cross kernel boundaries are zeroed in HBM before a call's stream work completes (the reference
  * wipes its stack after the same operations, lib/ed25519-sha512.c:77,136, lib/x25519.c:208,221).
@@ -96,6 +103,16 @@ EDDSA_AMD_DECL int x25519_batch_multi(uint8_t *out, const uint8_t *scalars, cons
 EDDSA_AMD_DECL int ed25519_verify_batch_multi_dev(uint8_t *const ok_full[], const uint8_t *const sigs[],
                                                   const uint8_t *const pubs[], const uint8_t *const msgs[],
                                                   size_t msg_len, size_t n_total, void *const streams[]);
+/* Page-locked host memory for the arrays of the host-pointer entry points: such buffers are read and written by the DMA
+ * engines in place, without the staging copy ordinary memory needs.  NULL when the allocation fails. */
+EDDSA_AMD_DECL void *eddsa_amd_host_alloc(size_t bytes);
+EDDSA_AMD_DECL void eddsa_amd_host_free(void *p);
+/* helper threads that copy ordinary caller memory into the staging buffers beside the calling thread (default 4, at
+ * most 16; 0 = the caller copies alone) */
+EDDSA_AMD_DECL void eddsa_amd_set_host_threads(int n);
+/* diagnostic: out[0] = launches the combiner of small host-pointer calls has made on the default device, out[1] = the
+ * calls they carried (equal when no two calls ever met) */
+EDDSA_AMD_DECL int eddsa_amd_combiner_stats(uint64_t out[2]);
 /* human-readable text for a negative return value */
 EDDSA_AMD_DECL const char *eddsa_amd_strerror(int err);
 /* copy the device's generated tables out for inspection: base16 = 32769 entries k*B; comb = 704

@@ -12,6 +12,10 @@ from .api import (  # noqa: F401
     DH,
     debug_halve,
     halve_rejected,
+    host_array,
+    host_free,
+    set_host_threads,
+    combiner_stats,
     ed25519_genpub,
     ed25519_genpub_batch,
     ed25519_sign,

@@ -139,6 +139,43 @@ def set_rlc_min_items(items):
     library().eddsa_amd_set_rlc_min_items(_c_size(int(items)))
 
 
+def set_host_threads(n):
+    """helper threads that stage ordinary host memory into the pipeline's page-locked buffers (default 4, 0..16)"""
+    library().eddsa_amd_set_host_threads(int(n))
+
+
+def combiner_stats():
+    """(launches, calls they carried) of the combiner of small host-pointer calls on the default device"""
+    out = (ctypes.c_uint64 * 2)()
+    _check(library().eddsa_amd_combiner_stats(out), "eddsa_amd_combiner_stats")
+    return int(out[0]), int(out[1])
+
+
+_PINNED = {}
+
+
+def host_array(shape, dtype=np.uint8):
+    """a numpy array in page-locked host memory (eddsa_amd_host_alloc): the host-pointer entry points read and
+    write such arrays in place, without a staging copy.  Release it with host_free()."""
+    lib = library()
+    lib.eddsa_amd_host_alloc.restype = ctypes.c_void_p
+    count = int(np.prod(shape))
+    nbytes = max(count * np.dtype(dtype).itemsize, 1)
+    ptr = lib.eddsa_amd_host_alloc(_c_size(nbytes))
+    if not ptr:
+        raise EddsaAmdError("eddsa_amd_host_alloc failed")
+    buf = (ctypes.c_uint8 * nbytes).from_address(ptr)
+    _PINNED[ptr] = buf
+    return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
+
+
+def host_free(a):
+    """release an array made by host_array (the array must not be used afterwards)"""
+    ptr = a.ctypes.data
+    if _PINNED.pop(ptr, None) is not None:
+        library().eddsa_amd_host_free(_c_ptr(ptr))
+
+
 def set_profiling(on):
     library().eddsa_amd_set_profiling(int(bool(on)))
 

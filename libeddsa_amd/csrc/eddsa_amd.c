@@ -1,113 +1,34 @@
 /*
- * eddsa_amd.c - host side of libeddsa_amd.so, plain C.
+ * eddsa_amd.c - engines and the device-pointer side of libeddsa_amd.so, plain C.
  *
- * Exports the thirteen symbols of the reference's public header (include/eddsa.h, reference
- * lib/eddsa.h:44-113) and the batched entry points of include/eddsa_amd.h.  Everything is
- * computed by the HIP kernels in kernels.hip; there is no CPU arithmetic in this file and no
- * fallback: without a usable gfx950 device every entry point fails (batch API: negative return;
- * eddsa.h API, which has no error channel: message on stderr + abort()).
+ * One `struct engine` per HIP device (generated tables, a pool of workspaces, the host pipeline's lanes and the
+ * combiner's queue, both driven by host_pipe.c), created on first use.  A device-pointer call runs on the device its
+ * output buffer lives on; a host-pointer call (host_pipe.c) on the default device (eddsa_amd_init) or, for the
+ * *_multi entry points, on every device of the set bound by eddsa_amd_init_devices.  Every call makes its device
+ * current for its own duration and restores the caller's.
  *
- * State: one `struct engine` per HIP device (tables, workspace pool, staging pipeline), created on
- * first use.  A device-pointer call runs on the device its output buffer lives on; a host-pointer
- * call runs on the default device (eddsa_amd_init) or, for the *_multi entry points, on every
- * device of the set bound by eddsa_amd_init_devices.  Every call makes its device current for its
- * own duration and restores the caller's.
- *
- * Locks, always taken in this order:  g_table (rwlock: read for the duration of every call, write
- * to create / destroy engines)  ->  g_rccl_lk (the multi-device device-pointer call)  ->  engine.pipe_lk
- * (host staging pipeline)  ->  engine.lk (workspace pool, profiling marks).
+ * Everything is computed by the HIP kernels in kernels.hip / rlc.hip; there is no CPU arithmetic on this side and no
+ * fallback: without a usable gfx950 device every entry point fails (batch API: negative return; eddsa.h API, which has
+ * no error channel: message on stderr + abort()).  Shared declarations and the lock order: engine.h.
  */
-#define _POSIX_C_SOURCE 200809L
-#define __HIP_PLATFORM_AMD__ 1
-#include <hip/hip_runtime_api.h>
+#include "engine.h"
 
 #include <dlfcn.h>
-#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
-#include "eddsa.h"
-#include "eddsa_amd.h"
-#include "eddsa_kernels.h"
-
-#define CHUNK_MAX ((size_t)1 << 20)   /* verify items per workspace pass: 1.6 GB of HBM workspace */
-#define MARK_SLOTS 256                /* profiled verify passes kept for eddsa_amd_verify_phase_ms */
-#define MAX_DEVICES 64
-
-#define ERR_NOT_GFX950 (-100000)
-#define ERR_RCCL_MISSING (-100001)
-#define ERR_RCCL_BASE (-200000)       /* ERR_RCCL_BASE - ncclResult_t */
-
-/* Workspaces: a small pool, so that passes issued on DIFFERENT streams (host threads that
- * each own a stream) overlap on the GPU instead of queueing behind one workspace.  A stream keeps the
- * slot it used last (passes on one stream are ordered anyway, and the slot has the right size);
- * another stream takes an idle slot, or the least recently used one. */
-#define VERIFY_SLOTS 4
-struct vslot {
-    edk_verify_ws ws;                 /* grown on demand up to CHUNK_MAX items; owns a side stream and two events */
-    edk_fixed_ws fws;                 /* sign / genpub / x25519_base / x25519 workspace, grown on demand */
-    edk_rlc_ws rws;                   /* batch (random-linear-combination) verification workspace */
-    hipEvent_t free;                  /* recorded after the last kernel that touches ws, fws or rws */
-    hipStream_t last_stream;
-    unsigned long stamp;              /* for least-recently-used */
-    int busy;                         /* held by a batch-verification pass that has left e->lk to wait for its stream */
-};
-
-/* host-pointer entry points: staging buffers and streams of the streaming pipeline (pipe_run) */
-#define PIPE_MAX_IN 3
-struct pipe {
-    int ready;
-    hipStream_t up, exec, down;
-    hipEvent_t in_ready[2], exec_done[2], slot_free[2];
-    void *d_in[2][PIPE_MAX_IN]; size_t in_cap[2][PIPE_MAX_IN];
-    void *d_msgs[2]; size_t msgs_cap[2];
-    void *d_off; size_t off_cap;
-    void *d_out; size_t out_cap;
-};
-
-struct engine {
-    int device;
-    pthread_mutex_t lk, pipe_lk;
-    pthread_cond_t slot_cv;            /* signalled (under lk) when a busy workspace slot is released */
-    uint32_t *base16, *comb;           /* generated base-point tables (HBM) */
-    uint32_t *comb_img;                /* the comb as the point kernels stage it in LDS (lanes.h: comb_select) */
-    struct vslot vs[VERIFY_SLOTS];
-    unsigned long clock;
-    int marks_used;                   /* passes recorded since profiling was switched on */
-    hipEvent_t marks[MARK_SLOTS][4];
-    struct pipe pipe;
-};
-
-static pthread_rwlock_t g_table = PTHREAD_RWLOCK_INITIALIZER;
-static struct engine *g_eng[MAX_DEVICES];
+pthread_rwlock_t g_table = PTHREAD_RWLOCK_INITIALIZER;
+struct engine *g_eng[MAX_DEVICES];
 static int g_default = -1;            /* device of the host-pointer entry points; -1: the caller's current device at first use */
 static int g_verify_algo = 0;         /* eddsa_amd_set_verify_algo: 0 by pass size (default), 1 full-length windows, 2 half-length scalars */
 static int g_offcurve_mode = 1;       /* eddsa_amd_set_offcurve_mode: 0 reject, 1 exact (default), 2 all exact */
 static int g_profiling;               /* record marks around the three verify kernels */
-static int g_fail_next_host_call;      /* eddsa_amd_debug_fail_next_host_call: test hook for the error path of pipe_run_on */
 static size_t g_rlc_min_items = (size_t)3 << 17;   /* eddsa_amd_set_rlc_min_items: smaller calls go to the per-item kernels */
 
-/* the device set of the *_multi entry points (eddsa_amd_init_devices) */
-typedef struct ncclComm *ncclComm_t;  /* as in rccl.h; the library is dlopen()ed on first use (it is 570 MB) */
-struct multi {
-    int n;
-    int dev[MAX_DEVICES];
-    ncclComm_t comm[MAX_DEVICES];
-    void *rccl;
-    int (*CommInitAll)(ncclComm_t *, int, const int *);
-    int (*CommDestroy)(ncclComm_t);
-    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t);
-    int (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t);
-    int (*GroupStart)(void);
-    int (*GroupEnd)(void);
-    const char *(*GetErrorString)(int);
-};
-static struct multi g_multi;
+struct multi g_multi;                  /* the device set of the *_multi entry points (eddsa_amd_init_devices) */
 static pthread_mutex_t g_rccl_lk = PTHREAD_MUTEX_INITIALIZER;   /* one grouped RCCL call at a time (taken after g_table) */
 #define NCCL_UINT8 1                   /* ncclUint8, rccl.h */
-
-#define TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = -(int)e_; goto out; } } while (0)
 
 const char *eddsa_amd_strerror(int err)
 {
@@ -127,7 +48,7 @@ const char *eddsa_amd_strerror(int err)
 
 /* device buffers that held secrets (or may have) are zeroed before they go back to the allocator:
  * the reference wipes after its secret-key operations (lib/ed25519-sha512.c:77,136, lib/x25519.c:208,221) */
-static void wipe_free(void *p, size_t bytes)
+void wipe_free(void *p, size_t bytes)
 {
     if (!p) return;
     if (bytes) { (void)hipMemset(p, 0, bytes); (void)hipDeviceSynchronize(); }
@@ -256,14 +177,13 @@ static struct vslot *ws_pick(struct engine *e, hipStream_t st)
     }
 }
 
-static void pipe_release(struct pipe *p);
-
 /* everything an engine holds on its device.  Caller holds g_table for writing (no call is in
  * flight) and has made e->device current. */
 static void engine_destroy(struct engine *e)
 {
     (void)hipDeviceSynchronize();
     pipe_release(&e->pipe);
+    combiner_release(&e->comb_q);
     for (int i = 0; i < VERIFY_SLOTS; i++) {
         struct vslot *v = &e->vs[i];
         ws_release(v);
@@ -299,6 +219,7 @@ static int engine_create(int device)
     pthread_mutex_init(&e->lk, NULL);
     pthread_mutex_init(&e->pipe_lk, NULL);
     pthread_cond_init(&e->slot_cv, NULL);
+    combiner_init(&e->comb_q);
     (void)hipGetDevice(&saved);
     TRY(hipSetDevice(device));
     TRY(hipGetDeviceProperties(&prop, device));
@@ -333,9 +254,7 @@ out:
 /* Every call brackets its work with enter()/leave(): enter() resolves the engine (creating it on
  * first use), holds g_table for reading and makes the engine's device current for the calling
  * thread; leave() restores the caller's device.  device < 0: the default device. */
-struct call { struct engine *e; int saved; };
-
-static int enter(struct call *c, int device)
+int enter(struct call *c, int device)
 {
     c->e = NULL;
     c->saved = -1;
@@ -365,7 +284,7 @@ static int enter(struct call *c, int device)
     return -(int)hipErrorNotReady;         /* shut down again between the two steps */
 }
 
-static void leave(struct call *c)
+void leave(struct call *c)
 {
     if (c->saved >= 0) (void)hipSetDevice(c->saved);
     pthread_rwlock_unlock(&g_table);
@@ -420,6 +339,7 @@ void eddsa_amd_shutdown(void)
     g_default = -1;
     if (saved >= 0) (void)hipSetDevice(saved);
     pthread_rwlock_unlock(&g_table);
+    host_pool_stop();
 }
 
 int eddsa_amd_dump_tables(uint32_t *base16_words, uint32_t *comb_words)
@@ -464,15 +384,6 @@ out:
     if (d_o) (void)hipFree(d_o);
     leave(&c);
     return rc;
-}
-
-/* test hook: the next host-pointer call fails (hipErrorUnknown) after its inputs were staged and its kernels launched,
- * so that the error path's clean-up (tests: the staging copies of secrets are wiped there too) can be exercised */
-void eddsa_amd_debug_fail_next_host_call(void)
-{
-    pthread_rwlock_wrlock(&g_table);
-    g_fail_next_host_call = 1;
-    pthread_rwlock_unlock(&g_table);
 }
 
 /* diagnostic for the tests: how many half-length pairs the exact integer check (csrc/lanes.h: verify_half_scalars_lane)
@@ -569,7 +480,7 @@ static void slot_quiesce(struct vslot *v, hipStream_t st)
 }
 
 /* both verify forms: chunks of at most CHUNK_MAX items through the workspace */
-static int verify_on(struct engine *e, uint8_t *ok, const edk_verify_src *all, size_t n, hipStream_t st)
+int verify_on(struct engine *e, uint8_t *ok, const edk_verify_src *all, size_t n, hipStream_t st)
 {
     int rc = 0;
     if (n == 0) return 0;
@@ -654,21 +565,39 @@ static hipError_t xbase_step(struct engine *e, size_t done, size_t m, const void
     return edk_x25519_base(c->out + 32 * done, c->in + 32 * done, m, e->comb_img, fws, st);
 }
 
-static int sign_on(struct engine *e, uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs, const uint8_t *msgs,
+int sign_on(struct engine *e, uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs, const uint8_t *msgs,
                    const uint64_t *msg_off, size_t msg_len, size_t n, hipStream_t st)
 {
     struct sign_ctx c = { sigs, secs, pubs, msgs, msg_off, msg_len };
     return fixed_on(e, n, sign_step, &c, st);
 }
 
-static int pk_to_x_on(struct engine *e, uint8_t *out, const uint8_t *in, size_t n, hipStream_t st)
+int genpub_on(struct engine *e, uint8_t *pubs, const uint8_t *secs, size_t n, hipStream_t st)
+{
+    struct io_ctx x = { pubs, secs };
+    return fixed_on(e, n, genpub_step, &x, st);
+}
+
+int x25519_on(struct engine *e, uint8_t *out, const uint8_t *scalars, const uint8_t *points, size_t n, hipStream_t st)
+{
+    struct io2_ctx x = { out, scalars, points };
+    return fixed_on(e, n, x25519_step, &x, st);
+}
+
+int xbase_on(struct engine *e, uint8_t *out, const uint8_t *scalars, size_t n, hipStream_t st)
+{
+    struct io_ctx x = { out, scalars };
+    return fixed_on(e, n, xbase_step, &x, st);
+}
+
+int pk_to_x_on(struct engine *e, uint8_t *out, const uint8_t *in, size_t n, hipStream_t st)
 {
     (void)e;
     hipError_t er = edk_pk_to_x(out, in, n, st);
     return er == hipSuccess ? 0 : -(int)er;
 }
 
-static int sk_to_x_on(struct engine *e, uint8_t *out, const uint8_t *in, size_t n, hipStream_t st)
+int sk_to_x_on(struct engine *e, uint8_t *out, const uint8_t *in, size_t n, hipStream_t st)
 {
     (void)e;
     hipError_t er = edk_sk_to_x(out, in, n, st);
@@ -678,7 +607,7 @@ static int sk_to_x_on(struct engine *e, uint8_t *out, const uint8_t *in, size_t 
 /* Batch verification by random linear combination (reference lib/ed25519-sha512.c:13-14, its TODO;
  * SURVEY 8(f)-3): see include/eddsa_amd.h.  One pass of at most CHUNK_MAX items; larger batches are
  * split into independent sub-batches. */
-static int rlc_on(struct engine *e, uint8_t *ok, uint32_t *stats, const edk_verify_src *all, size_t n, hipStream_t st)
+int rlc_on(struct engine *e, uint8_t *ok, uint32_t *stats, const edk_verify_src *all, size_t n, hipStream_t st)
 {
     int rc = 0;
     if (n == 0) return 0;
@@ -745,7 +674,7 @@ int ed25519_verify_batch_dev(uint8_t *ok, const uint8_t *sigs, const uint8_t *pu
 }
 
 /* fixed-size records: see include/eddsa_amd.h */
-static int records_ok(size_t stride, size_t sig_off, size_t pub_off, size_t msg_off, size_t msg_len)
+int records_ok(size_t stride, size_t sig_off, size_t pub_off, size_t msg_off, size_t msg_len)
 {
     return sig_off <= stride && 64 <= stride - sig_off && pub_off <= stride && 32 <= stride - pub_off &&
            msg_off <= stride && msg_len <= stride - msg_off;
@@ -823,334 +752,6 @@ int sk_ed25519_to_x25519_batch_dev(uint8_t *out, const uint8_t *in, size_t n, vo
     rc = sk_to_x_on(c.e, out, in, n, (hipStream_t)stream);
     leave(&c);
     return rc;
-}
-
-/* ------------------------------------------------------------------------------------------
- * host-pointer entry points: a streaming pipeline over chunks of PIPE_CHUNK items.
- *
- * Three streams: `up` copies chunk k+1 host -> HBM while `exec` runs the kernels of chunk k and
- * `down` copies the results of chunk k-1 back, on two alternating sets of device input buffers
- * that persist across calls (grown on demand).  With pageable caller memory the HIP runtime stages
- * the copies itself and blocks the calling thread for their duration, which is why the download of
- * chunk k-1 is issued only after the kernels of chunk k were launched; with pinned caller memory
- * (hipHostMalloc / hipHostRegister) the copies are asynchronous as well.
- * Ragged messages (msg_off != NULL) go through the same buffers as a single chunk.
- * Jobs that carry secrets (secret keys, scalars, shared secrets) zero their staging buffers before
- * the call returns: nothing secret outlives the call in HBM.
- * ---------------------------------------------------------------------------------------- */
-
-#define PIPE_CHUNK ((size_t)1 << 18)   /* 1024 blocks of 256 lanes: one full residency of the chip */
-/* verify: two residencies per chunk, so that the exact path's chain for off-curve keys (4 ms beside
- * the main kernel, tools/verify_sizes.py) stays hidden behind k_verify_main as it is in one big pass */
-#define PIPE_CHUNK_VERIFY ((size_t)1 << 19)
-
-enum { WIPE_NONE = 0, WIPE_IN0 = 1, WIPE_OUT = 2 };   /* which staging buffers held secrets */
-
-struct hjob {
-    int n_in; const uint8_t *in[PIPE_MAX_IN]; size_t in_w[PIPE_MAX_IN];   /* fixed-width inputs */
-    int has_msgs; const uint8_t *msgs; const uint64_t *msg_off; size_t msg_len;
-    uint8_t *out; size_t out_w;
-    int (*run)(struct engine *e, const struct hjob *j, uint8_t *d_out, uint8_t *const d_in[PIPE_MAX_IN],
-               const uint8_t *d_msgs, const uint64_t *d_off, size_t msg_len, size_t m, hipStream_t st);
-    size_t rec_sig, rec_pub, rec_msg;          /* records: offsets inside in[0]'s items (in_w[0] = stride) */
-    size_t chunk;                              /* items per pipeline stage (0: PIPE_CHUNK) */
-    int wipe;                                  /* WIPE_* */
-    uint32_t *stats;                           /* rlc: host copy of the pass statistics (4 words) or NULL */
-};
-
-static int pipe_grow(void **buf, size_t *cap, size_t need)
-{
-    if (need <= *cap) return 0;
-    if (*buf) { wipe_free(*buf, *cap); *buf = NULL; *cap = 0; }
-    hipError_t e = hipMalloc(buf, need < 256 ? 256 : need);
-    if (e != hipSuccess) return -(int)e;
-    *cap = need < 256 ? 256 : need;
-    return 0;
-}
-
-static int pipe_init(struct pipe *p)
-{
-    int rc = 0;
-    if (p->ready) return 0;
-    TRY(hipStreamCreateWithFlags(&p->up, hipStreamNonBlocking));
-    TRY(hipStreamCreateWithFlags(&p->exec, hipStreamNonBlocking));
-    TRY(hipStreamCreateWithFlags(&p->down, hipStreamNonBlocking));
-    for (int s = 0; s < 2; s++) {
-        TRY(hipEventCreateWithFlags(&p->in_ready[s], hipEventDisableTiming));
-        TRY(hipEventCreateWithFlags(&p->exec_done[s], hipEventDisableTiming));
-        TRY(hipEventCreateWithFlags(&p->slot_free[s], hipEventDisableTiming));
-    }
-    p->ready = 1;
-out:
-    return rc;
-}
-
-static void pipe_release(struct pipe *p)
-{
-    for (int s = 0; s < 2; s++) {
-        for (int i = 0; i < PIPE_MAX_IN; i++) wipe_free(p->d_in[s][i], p->in_cap[s][i]);
-        wipe_free(p->d_msgs[s], 0);
-        if (p->in_ready[s]) (void)hipEventDestroy(p->in_ready[s]);
-        if (p->exec_done[s]) (void)hipEventDestroy(p->exec_done[s]);
-        if (p->slot_free[s]) (void)hipEventDestroy(p->slot_free[s]);
-    }
-    wipe_free(p->d_off, 0);
-    wipe_free(p->d_out, p->out_cap);
-    if (p->up) (void)hipStreamDestroy(p->up);
-    if (p->exec) (void)hipStreamDestroy(p->exec);
-    if (p->down) (void)hipStreamDestroy(p->down);
-    memset(p, 0, sizeof(*p));
-}
-
-/* one host-pointer job on engine e (its device is current) */
-static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
-{
-    int rc = 0;
-    struct pipe *p = &e->pipe;
-    uint32_t *d_stats = NULL;
-    if (n == 0) return 0;
-    pthread_mutex_lock(&e->pipe_lk);
-    rc = pipe_init(p);
-    if (rc) goto out;
-    {
-        const int ragged = j->has_msgs && j->msg_off != NULL;
-        const size_t stage = j->chunk ? j->chunk : PIPE_CHUNK;
-        const size_t chunk = ragged ? n : (n < stage ? n : stage);
-        const size_t nchunks = (n + chunk - 1) / chunk;
-        const int nslots = nchunks > 1 ? 2 : 1;
-        if ((rc = pipe_grow(&p->d_out, &p->out_cap, n * j->out_w + (j->stats ? 64 : 0)))) goto out;
-        if (j->stats) {
-            d_stats = (uint32_t *)((uint8_t *)p->d_out + (n * j->out_w + 15) / 16 * 16);
-            TRY(hipMemsetAsync(d_stats, 0, 16, p->exec));
-        }
-        if (ragged && (rc = pipe_grow(&p->d_off, &p->off_cap, (n + 1) * sizeof(uint64_t)))) goto out;
-        for (int s = 0; s < nslots; s++) {
-            for (int i = 0; i < j->n_in; i++)
-                if ((rc = pipe_grow(&p->d_in[s][i], &p->in_cap[s][i], chunk * j->in_w[i]))) goto out;
-            if (j->has_msgs) {
-                const size_t need = ragged ? (size_t)j->msg_off[n] : chunk * j->msg_len;
-                if ((rc = pipe_grow(&p->d_msgs[s], &p->msgs_cap[s], need))) goto out;
-            }
-        }
-        /* a call of one chunk has nothing to overlap: everything in order on the kernels' stream, one sync */
-        const int single = nchunks == 1;
-        hipStream_t up = single ? p->exec : p->up, down = single ? p->exec : p->down;
-        if (ragged) TRY(hipMemcpyAsync(p->d_off, j->msg_off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, up));
-        for (size_t k = 0; k < nchunks; k++) {
-            const int s = (int)(k & 1);
-            const size_t lo = k * chunk, m = n - lo < chunk ? n - lo : chunk;
-            /* upload chunk k into slot s once the kernels of chunk k-2 have consumed it */
-            if (k >= 2) TRY(hipStreamWaitEvent(up, p->exec_done[s], 0));
-            for (int i = 0; i < j->n_in; i++)
-                TRY(hipMemcpyAsync(p->d_in[s][i], j->in[i] + lo * j->in_w[i], m * j->in_w[i], hipMemcpyHostToDevice, up));
-            if (j->has_msgs) {
-                const size_t bytes = ragged ? (size_t)j->msg_off[n] : m * j->msg_len;
-                const uint8_t *src = ragged ? j->msgs : j->msgs + lo * j->msg_len;
-                if (bytes) TRY(hipMemcpyAsync(p->d_msgs[s], src, bytes, hipMemcpyHostToDevice, up));
-            }
-            if (!single) TRY(hipEventRecord(p->in_ready[s], up));
-            /* kernels of chunk k */
-            if (!single) TRY(hipStreamWaitEvent(p->exec, p->in_ready[s], 0));
-            {
-                struct hjob jj = *j;
-                jj.stats = d_stats;
-                rc = j->run(e, &jj, (uint8_t *)p->d_out + lo * j->out_w, (uint8_t *const *)p->d_in[s],
-                            (const uint8_t *)p->d_msgs[s], ragged ? (const uint64_t *)p->d_off : NULL,
-                            j->msg_len, m, p->exec);
-            }
-            if (!rc && g_fail_next_host_call) { g_fail_next_host_call = 0; rc = -(int)hipErrorUnknown; }
-            if (rc) goto out;
-            if (!single) TRY(hipEventRecord(p->exec_done[s], p->exec));
-            /* download chunk k-1 (its kernels were launched one iteration ago) */
-            if (k >= 1) {
-                const size_t plo = (k - 1) * chunk;
-                TRY(hipStreamWaitEvent(down, p->exec_done[s ^ 1], 0));
-                TRY(hipMemcpyAsync(j->out + plo * j->out_w, (uint8_t *)p->d_out + plo * j->out_w, chunk * j->out_w,
-                                   hipMemcpyDeviceToHost, down));
-            }
-        }
-        {
-            const size_t plo = (nchunks - 1) * chunk;
-            if (!single) TRY(hipStreamWaitEvent(down, p->exec_done[(nchunks - 1) & 1], 0));
-            TRY(hipMemcpyAsync(j->out + plo * j->out_w, (uint8_t *)p->d_out + plo * j->out_w, (n - plo) * j->out_w,
-                               hipMemcpyDeviceToHost, down));
-            if (j->stats) TRY(hipMemcpyAsync(j->stats, d_stats, 16, hipMemcpyDeviceToHost, down));
-        }
-        /* secrets do not outlive the call in the staging buffers */
-        if (j->wipe & WIPE_IN0)
-            for (int s = 0; s < nslots; s++) TRY(hipMemsetAsync(p->d_in[s][0], 0, chunk * j->in_w[0], p->exec));
-        if (!single) TRY(hipStreamSynchronize(down));
-        if (j->wipe & WIPE_OUT) TRY(hipMemsetAsync(p->d_out, 0, n * j->out_w, p->exec));
-        TRY(hipStreamSynchronize(p->exec));
-        if (!single) TRY(hipStreamSynchronize(up));
-    }
-out:
-    if (rc && p->ready) {
-        (void)hipStreamSynchronize(p->up); (void)hipStreamSynchronize(p->exec); (void)hipStreamSynchronize(p->down);
-        /* a failed call must not leave its secrets behind either (best effort: whatever was staged, whole buffers) */
-        if (j->wipe & WIPE_IN0)
-            for (int s = 0; s < 2; s++) if (p->d_in[s][0]) (void)hipMemsetAsync(p->d_in[s][0], 0, p->in_cap[s][0], p->exec);
-        if ((j->wipe & WIPE_OUT) && p->d_out) (void)hipMemsetAsync(p->d_out, 0, p->out_cap, p->exec);
-        if (j->wipe) (void)hipStreamSynchronize(p->exec);
-    }
-    pthread_mutex_unlock(&e->pipe_lk);
-    return rc;
-}
-
-/* on the default device */
-static int pipe_run(const struct hjob *j, size_t n)
-{
-    struct call c;
-    int rc;
-    if (n == 0) return 0;
-    rc = enter(&c, -1);
-    if (rc) return rc;
-    rc = pipe_run_on(c.e, j, n);
-    leave(&c);
-    return rc;
-}
-
-#define RUN_ARGS struct engine *e, const struct hjob *j, uint8_t *d_out, uint8_t *const d_in[PIPE_MAX_IN], \
-                 const uint8_t *d_msgs, const uint64_t *d_off, size_t msg_len, size_t m, hipStream_t st
-static int run_verify(RUN_ARGS)
-{
-    (void)j;
-    const edk_verify_src src = { d_in[0], d_in[1], d_msgs, d_off, msg_len, 64, 32, msg_len };
-    return verify_on(e, d_out, &src, m, st);
-}
-static int run_verify_rlc(RUN_ARGS)
-{
-    const edk_verify_src src = { d_in[0], d_in[1], d_msgs, d_off, msg_len, 64, 32, msg_len };
-    return rlc_on(e, d_out, j->stats, &src, m, st);
-}
-static int run_verify_records(RUN_ARGS)
-{
-    (void)d_msgs; (void)d_off;
-    const edk_verify_src src = { d_in[0] + j->rec_sig, d_in[0] + j->rec_pub, d_in[0] + j->rec_msg, NULL, msg_len,
-                                 j->in_w[0], j->in_w[0], j->in_w[0] };
-    return verify_on(e, d_out, &src, m, st);
-}
-static int run_sign(RUN_ARGS)
-{
-    (void)j;
-    return sign_on(e, d_out, d_in[0], d_in[1], d_msgs, d_off, msg_len, m, st);
-}
-static int run_x25519(RUN_ARGS)
-{
-    (void)j; (void)d_msgs; (void)d_off; (void)msg_len;
-    struct io2_ctx x = { d_out, d_in[0], d_in[1] };
-    return fixed_on(e, m, x25519_step, &x, st);
-}
-static int run_genpub(RUN_ARGS)
-{
-    (void)j; (void)d_msgs; (void)d_off; (void)msg_len;
-    struct io_ctx x = { d_out, d_in[0] };
-    return fixed_on(e, m, genpub_step, &x, st);
-}
-static int run_xbase(RUN_ARGS)
-{
-    (void)j; (void)d_msgs; (void)d_off; (void)msg_len;
-    struct io_ctx x = { d_out, d_in[0] };
-    return fixed_on(e, m, xbase_step, &x, st);
-}
-static int run_pk_to_x(RUN_ARGS)
-{
-    (void)j; (void)d_msgs; (void)d_off; (void)msg_len;
-    return pk_to_x_on(e, d_out, d_in[0], m, st);
-}
-static int run_sk_to_x(RUN_ARGS)
-{
-    (void)j; (void)d_msgs; (void)d_off; (void)msg_len;
-    return sk_to_x_on(e, d_out, d_in[0], m, st);
-}
-
-static struct hjob job_verify(uint8_t *ok, const uint8_t *sigs, const uint8_t *pubs, const uint8_t *msgs,
-                              const uint64_t *msg_off, size_t msg_len)
-{
-    struct hjob j = { 2, { sigs, pubs, NULL }, { 64, 32, 0 }, 1, msgs, msg_off, msg_len, ok, 1, run_verify, 0, 0, 0,
-                      PIPE_CHUNK_VERIFY, WIPE_NONE, NULL };
-    return j;
-}
-static struct hjob job_sign(uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs, const uint8_t *msgs,
-                            const uint64_t *msg_off, size_t msg_len)
-{
-    struct hjob j = { 2, { secs, pubs, NULL }, { 32, 32, 0 }, 1, msgs, msg_off, msg_len, sigs, 64, run_sign, 0, 0, 0, 0,
-                      WIPE_IN0, NULL };
-    return j;
-}
-static struct hjob job_x25519(uint8_t *out, const uint8_t *scalars, const uint8_t *points)
-{
-    struct hjob j = { 2, { scalars, points, NULL }, { 32, 32, 0 }, 0, NULL, NULL, 0, out, 32, run_x25519, 0, 0, 0, 0,
-                      WIPE_IN0 | WIPE_OUT, NULL };
-    return j;
-}
-static struct hjob job_1in(int (*run)(RUN_ARGS), uint8_t *out, const uint8_t *in, int wipe)
-{
-    struct hjob j = { 1, { in, NULL, NULL }, { 32, 0, 0 }, 0, NULL, NULL, 0, out, 32, run, 0, 0, 0, 0, wipe, NULL };
-    return j;
-}
-
-int ed25519_verify_batch(uint8_t *ok, const uint8_t *sigs, const uint8_t *pubs, const uint8_t *msgs,
-                         const uint64_t *msg_off, size_t msg_len, size_t n)
-{
-    struct hjob j = job_verify(ok, sigs, pubs, msgs, msg_off, msg_len);
-    return pipe_run(&j, n);
-}
-
-int ed25519_verify_batch_rlc(uint8_t *ok, uint32_t stats[4], const uint8_t *sigs, const uint8_t *pubs,
-                             const uint8_t *msgs, const uint64_t *msg_off, size_t msg_len, size_t n)
-{
-    uint32_t local[4] = { 0, 0, 0, 0 };
-    struct hjob j = job_verify(ok, sigs, pubs, msgs, msg_off, msg_len);
-    j.run = run_verify_rlc;
-    j.chunk = CHUNK_MAX;                /* one combination per 2^20 items */
-    j.stats = local;
-    int rc = pipe_run(&j, n);
-    if (stats) memcpy(stats, local, sizeof(local));
-    return rc;
-}
-
-int ed25519_verify_records(uint8_t *ok, const uint8_t *records, size_t stride, size_t sig_off, size_t pub_off,
-                           size_t msg_off, size_t msg_len, size_t n)
-{
-    if (!records_ok(stride, sig_off, pub_off, msg_off, msg_len)) return -(int)hipErrorInvalidValue;
-    struct hjob j = { 1, { records, NULL, NULL }, { stride, 0, 0 }, 0, NULL, NULL, msg_len, ok, 1, run_verify_records,
-                      sig_off, pub_off, msg_off, PIPE_CHUNK_VERIFY, WIPE_NONE, NULL };
-    return pipe_run(&j, n);
-}
-
-int ed25519_sign_batch(uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs, const uint8_t *msgs,
-                       const uint64_t *msg_off, size_t msg_len, size_t n)
-{
-    struct hjob j = job_sign(sigs, secs, pubs, msgs, msg_off, msg_len);
-    return pipe_run(&j, n);
-}
-
-int x25519_batch(uint8_t *out, const uint8_t *scalars, const uint8_t *points, size_t n)
-{
-    struct hjob j = job_x25519(out, scalars, points);
-    return pipe_run(&j, n);
-}
-
-int ed25519_genpub_batch(uint8_t *pubs, const uint8_t *secs, size_t n)
-{
-    struct hjob j = job_1in(run_genpub, pubs, secs, WIPE_IN0);
-    return pipe_run(&j, n);
-}
-int x25519_base_batch(uint8_t *out, const uint8_t *scalars, size_t n)
-{
-    struct hjob j = job_1in(run_xbase, out, scalars, WIPE_IN0);
-    return pipe_run(&j, n);
-}
-int pk_ed25519_to_x25519_batch(uint8_t *out, const uint8_t *in, size_t n)
-{
-    struct hjob j = job_1in(run_pk_to_x, out, in, WIPE_NONE);
-    return pipe_run(&j, n);
-}
-int sk_ed25519_to_x25519_batch(uint8_t *out, const uint8_t *in, size_t n)
-{
-    struct hjob j = job_1in(run_sk_to_x, out, in, WIPE_IN0 | WIPE_OUT);
-    return pipe_run(&j, n);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1233,87 +834,6 @@ int eddsa_amd_device_at(int index)
     return dev;
 }
 
-/* host-pointer forms: thread d runs the ordinary streaming pipeline of device d on shard d; results
- * are copied device -> caller's buffer slice directly, so there is nothing to gather */
-struct shard_job { struct hjob j; size_t n; int device; int rc; };
-
-static void *shard_thread(void *arg)
-{
-    struct shard_job *s = (struct shard_job *)arg;
-    struct call c;
-    s->rc = enter(&c, s->device);
-    if (s->rc) return NULL;
-    s->rc = pipe_run_on(c.e, &s->j, s->n);
-    leave(&c);
-    return NULL;
-}
-
-/* split job j over the device set: item ranges for the fixed-width arrays, message bytes for ragged ones */
-static int multi_run(const struct hjob *j, size_t n)
-{
-    struct shard_job jobs[MAX_DEVICES];
-    pthread_t th[MAX_DEVICES];
-    uint64_t *offs[MAX_DEVICES];
-    int started[MAX_DEVICES];
-    int rc = 0, g;
-    pthread_rwlock_rdlock(&g_table);
-    g = g_multi.n;
-    for (int d = 0; d < g; d++) jobs[d].device = g_multi.dev[d];
-    pthread_rwlock_unlock(&g_table);
-    if (g == 0) return -(int)hipErrorNotInitialized;
-    if (n == 0) return 0;
-    memset(offs, 0, sizeof(offs));
-    memset(started, 0, sizeof(started));
-    for (int d = 0; d < g; d++) {
-        size_t lo, hi;
-        eddsa_amd_shard_bounds(n, d, g, &lo, &hi);
-        jobs[d].j = *j;
-        jobs[d].n = hi - lo;
-        jobs[d].rc = 0;
-        for (int i = 0; i < j->n_in; i++) jobs[d].j.in[i] = j->in[i] + lo * j->in_w[i];
-        jobs[d].j.out = j->out + lo * j->out_w;
-        if (j->has_msgs && j->msg_off) {            /* ragged: the shard's own offset table, rebased to 0 */
-            offs[d] = (uint64_t *)malloc((hi - lo + 1) * sizeof(uint64_t));
-            if (!offs[d]) { rc = -(int)hipErrorOutOfMemory; break; }
-            for (size_t k = 0; k <= hi - lo; k++) offs[d][k] = j->msg_off[lo + k] - j->msg_off[lo];
-            jobs[d].j.msg_off = offs[d];
-            jobs[d].j.msgs = j->msgs + j->msg_off[lo];
-        } else if (j->has_msgs) {
-            jobs[d].j.msgs = j->msgs + lo * j->msg_len;
-        }
-    }
-    for (int d = 0; d < g && !rc; d++) {
-        if (jobs[d].n == 0) continue;
-        if (pthread_create(&th[d], NULL, shard_thread, &jobs[d]) != 0) { rc = -(int)hipErrorOutOfMemory; break; }
-        started[d] = 1;
-    }
-    for (int d = 0; d < g; d++) {
-        if (started[d]) { pthread_join(th[d], NULL); if (!rc) rc = jobs[d].rc; }
-        free(offs[d]);
-    }
-    return rc;
-}
-
-int ed25519_verify_batch_multi(uint8_t *ok, const uint8_t *sigs, const uint8_t *pubs, const uint8_t *msgs,
-                               const uint64_t *msg_off, size_t msg_len, size_t n)
-{
-    struct hjob j = job_verify(ok, sigs, pubs, msgs, msg_off, msg_len);
-    return multi_run(&j, n);
-}
-
-int ed25519_sign_batch_multi(uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs, const uint8_t *msgs,
-                             const uint64_t *msg_off, size_t msg_len, size_t n)
-{
-    struct hjob j = job_sign(sigs, secs, pubs, msgs, msg_off, msg_len);
-    return multi_run(&j, n);
-}
-
-int x25519_batch_multi(uint8_t *out, const uint8_t *scalars, const uint8_t *points, size_t n)
-{
-    struct hjob j = job_x25519(out, scalars, points);
-    return multi_run(&j, n);
-}
-
 /* Device-pointer form: device d of the set holds shard d of the inputs and a buffer ok_full[d] of
  * n_total bytes; shard d is verified on device d into its own slice of ok_full[d], then one RCCL
  * all-gather (grouped broadcasts when the shards differ in length) completes every ok_full[d].
@@ -1371,7 +891,7 @@ unlock:
  * diagnostics
  * ---------------------------------------------------------------------------------------- */
 
-static int count_nonzero(const void *dev, size_t bytes, uint64_t *count)
+int count_nonzero_dev(const void *dev, size_t bytes, uint64_t *count)
 {
     int rc = 0;
     if (!dev || !bytes) return 0;
@@ -1394,82 +914,16 @@ int eddsa_amd_secret_residue(uint64_t out[4])
     int rc = enter(&c, -1);
     if (rc) return rc;
     out[0] = out[1] = out[2] = out[3] = 0;
-    pthread_mutex_lock(&c.e->pipe_lk);
     pthread_mutex_lock(&c.e->lk);
     TRY(hipDeviceSynchronize());
     for (int i = 0; i < VERIFY_SLOTS && !rc; i++) {
         const struct vslot *v = &c.e->vs[i];
-        rc = count_nonzero(v->fws.aux, v->fws.capacity * 16 * sizeof(uint32_t), &out[0]);
-        if (!rc) rc = count_nonzero(v->fws.acc, v->fws.capacity * ACC_WORDS * sizeof(uint32_t), &out[1]);
+        rc = count_nonzero_dev(v->fws.aux, v->fws.capacity * 16 * sizeof(uint32_t), &out[0]);
+        if (!rc) rc = count_nonzero_dev(v->fws.acc, v->fws.capacity * ACC_WORDS * sizeof(uint32_t), &out[1]);
     }
-    for (int s = 0; s < 2 && !rc; s++) rc = count_nonzero(c.e->pipe.d_in[s][0], c.e->pipe.in_cap[s][0], &out[2]);
-    if (!rc) rc = count_nonzero(c.e->pipe.d_out, c.e->pipe.out_cap, &out[3]);
 out:
     pthread_mutex_unlock(&c.e->lk);
-    pthread_mutex_unlock(&c.e->pipe_lk);
+    if (!rc) rc = pipe_residue(c.e, &out[2], &out[3]);
     leave(&c);
     return rc;
 }
-
-/* ------------------------------------------------------------------------------------------
- * the eddsa.h surface: batches of one.  No error channel in these signatures, so fail loudly.
- * ---------------------------------------------------------------------------------------- */
-
-static void must(int rc, const char *what)
-{
-    if (rc == 0) return;
-    fprintf(stderr, "libeddsa_amd: %s failed on the GPU path: %s (no CPU fallback exists)\n", what,
-            eddsa_amd_strerror(rc));
-    abort();
-}
-
-void ed25519_genpub(uint8_t pub[32], const uint8_t sec[32])
-{
-    must(ed25519_genpub_batch(pub, sec, 1), "ed25519_genpub");
-}
-
-void ed25519_sign(uint8_t sig[64], const uint8_t sec[32], const uint8_t pub[32], const uint8_t *data, size_t len)
-{
-    must(ed25519_sign_batch(sig, sec, pub, data, NULL, len, 1), "ed25519_sign");
-}
-
-bool ed25519_verify(const uint8_t sig[64], const uint8_t pub[32], const uint8_t *data, size_t len)
-{
-    uint8_t ok = 0;
-    must(ed25519_verify_batch(&ok, sig, pub, data, NULL, len, 1), "ed25519_verify");
-    return ok != 0;
-}
-
-void x25519_base(uint8_t out[32], const uint8_t scalar[32])
-{
-    must(x25519_base_batch(out, scalar, 1), "x25519_base");
-}
-
-void x25519(uint8_t out[32], const uint8_t scalar[32], const uint8_t point[32])
-{
-    must(x25519_batch(out, scalar, point, 1), "x25519");
-}
-
-void pk_ed25519_to_x25519(uint8_t out[32], const uint8_t in[32])
-{
-    must(pk_ed25519_to_x25519_batch(out, in, 1), "pk_ed25519_to_x25519");
-}
-
-void sk_ed25519_to_x25519(uint8_t out[32], const uint8_t in[32])
-{
-    must(sk_ed25519_to_x25519_batch(out, in, 1), "sk_ed25519_to_x25519");
-}
-
-/* reference lib/ed25519-sha512.c:270-324 and lib/x25519.c:232-243: the obsolete names */
-void eddsa_genpub(uint8_t pub[32], const uint8_t sec[32]) { ed25519_genpub(pub, sec); }
-void eddsa_sign(uint8_t sig[64], const uint8_t sec[32], const uint8_t pub[32], const uint8_t *data, size_t len)
-{
-    ed25519_sign(sig, sec, pub, data, len);
-}
-bool eddsa_verify(const uint8_t sig[64], const uint8_t pub[32], const uint8_t *data, size_t len)
-{
-    return ed25519_verify(sig, pub, data, len);
-}
-void DH(uint8_t out[32], const uint8_t sec[32], const uint8_t point[32]) { x25519(out, sec, point); }
-void eddsa_pk_eddsa_to_dh(uint8_t out[32], const uint8_t in[32]) { pk_ed25519_to_x25519(out, in); }
-void eddsa_sk_eddsa_to_dh(uint8_t out[32], const uint8_t in[32]) { sk_ed25519_to_x25519(out, in); }

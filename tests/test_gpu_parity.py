@@ -380,6 +380,35 @@ def test_c_program_against_eddsa_h(engine, golden, tmp_path):
     assert "selftest_dropin: ok" in r.stdout
 
 
+def test_threaded_c_application_on_the_single_item_functions(engine, golden, tmp_path):
+    """VERDICT r02 missing #4: tests/c/threaded_callers.c, 64 pthreads looping over ed25519_verify (then a mix of
+    verify / sign / x25519 / genpub) through eddsa.h only.  Every result must be the golden table's, and the calls must
+    not run one GPU pass each: the combiner (host_pipe.c) merges what is queued for one operation into one launch -
+    round 2 gave such a program about 2.4 k verifies/s in total, the reference about 20 k/s per core"""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "threaded_callers"
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-pthread", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c", "threaded_callers.c"), "-L" + os.path.join(root, "libeddsa_amd"),
+                           "-leddsa_amd", "-Wl,-rpath," + os.path.join(root, "libeddsa_amd"), "-o", str(exe)])
+    msgs = tmp_path / "msgs.bin"
+    msgs.write_bytes(b"".join(golden_msg(i) for i in range(1024)))
+    r = subprocess.run([str(exe), os.path.join(root, "tests", "golden", "ed25519_table.bin"), str(msgs),
+                        os.path.join(root, "tests", "golden", "x25519_table.bin"), "64", "100"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "threaded_callers: ok" in r.stdout
+    print(r.stdout)
+    rates = [float(x) for x in re.findall(r"= (\d+) calls/s", r.stdout)]
+    assert len(rates) == 3
+    # one caller is latency-bound (a pass per call); 64 callers must get far more than that in total
+    assert rates[1] > 8 * rates[0] and rates[1] > 30000, r.stdout
+    launches, calls = [int(x) for x in re.findall(r"(\d+) launches carried (\d+) calls", r.stdout)[-1]]
+    assert calls > 4 * launches
+
+
 def test_concurrent_host_threads(engine, oracle):
     """several host threads issue batched calls at once (host-pointer pipeline and device-pointer
     entry points on different torch streams): calls serialise on the engine's workspaces and every
