@@ -110,6 +110,9 @@ EDDSA_AMD_DECL void eddsa_amd_host_free(void *p);
 /* helper threads that copy ordinary caller memory into the staging buffers beside the calling thread (default 4, at
  * most 16; 0 = the caller copies alone) */
 EDDSA_AMD_DECL void eddsa_amd_set_host_threads(int n);
+/* tuning (a measurement aid): items of the first chunk of a host-pointer call and of its later stages; 0 = the defaults
+ * (2^17, then doubling up to 2^19 for verify and 2^18 for the other operations) */
+EDDSA_AMD_DECL void eddsa_amd_set_pipeline(size_t first_chunk, size_t stage_chunk);
 /* diagnostic: out[0] = launches the combiner of small host-pointer calls has made on the default device, out[1] = the
  * calls they carried (equal when no two calls ever met) */
 EDDSA_AMD_DECL int eddsa_amd_combiner_stats(uint64_t out[2]);

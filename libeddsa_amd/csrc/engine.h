@@ -58,6 +58,7 @@ struct vslot {
 #define PIPE_LANES 3
 struct lane {
     hipStream_t st;                   /* upload, kernels and download of the chunk this lane carries, in order */
+    hipEvent_t kdone;                 /* the chunk's chip-filling kernels are queued up to here: the next chunk's kernels start behind it */
     void *d_in[PIPE_MAX_IN]; size_t d_in_cap[PIPE_MAX_IN];     /* HBM */
     void *d_msgs; size_t d_msgs_cap;
     void *d_out; size_t d_out_cap;
@@ -66,6 +67,7 @@ struct lane {
     void *h_out; size_t h_out_cap;
     /* the chunk in flight on this lane: where its results go once the lane's stream has drained */
     uint8_t *pend_dst; const uint8_t *pend_src; size_t pend_bytes;
+    size_t used_in0;                  /* bytes of h_in[0] the chunk staged (zeroed after the chunk when they were secret) */
 };
 struct pipe {
     int ready;
@@ -137,7 +139,8 @@ void wipe_free(void *p, size_t bytes);
 
 /* device-pointer work on one engine (the engine's device is current); all asynchronous on `st` except rlc_on,
  * which waits for the stream once per pass */
-int verify_on(struct engine *e, uint8_t *ok, const edk_verify_src *all, size_t n, hipStream_t st);
+/* bulk_done (or NULL): see edk_verify */
+int verify_on(struct engine *e, uint8_t *ok, const edk_verify_src *all, size_t n, hipStream_t st, hipEvent_t bulk_done);
 int rlc_on(struct engine *e, uint8_t *ok, uint32_t *stats, const edk_verify_src *all, size_t n, hipStream_t st);
 int sign_on(struct engine *e, uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs, const uint8_t *msgs,
             const uint64_t *msg_off, size_t msg_len, size_t n, hipStream_t st);

@@ -97,46 +97,67 @@ void host_pool_stop(void)
     pthread_mutex_unlock(&g_pool.lk);
 }
 
-/* dst[0..bytes) = src[0..bytes) (src == NULL: zeros), split over the pool; returns when all of it is done.  The
- * caller takes the first slice itself (and whatever the task queue has no room for). */
-static void par_copy(void *dst, const void *src, size_t bytes)
+/* Queue dst[0..bytes) = src[0..bytes) (src == NULL: zeros) for the pool, in slices; *pending counts the slices still
+ * to be done (read and written under the pool's lock only; pool_wait).  What the pool cannot take - no helper threads,
+ * no room in the queue - is done here and now.  Returns the bytes queued. */
+static size_t pool_submit(int *pending, uint8_t *d, const uint8_t *s, size_t bytes, size_t slice)
 {
-    uint8_t *d = (uint8_t *)dst;
-    const uint8_t *s = (const uint8_t *)src;
-    int pending = 0, queued = 0;                 /* pending: under the pool's lock only */
-    size_t own_end = bytes, tail_from = bytes;   /* the caller copies [0, own_end) and [tail_from, bytes) */
-    if (bytes >= 2 * POOL_MIN_SLICE) {
+    size_t off = 0;
+    if (bytes >= POOL_MIN_SLICE) {
         pthread_mutex_lock(&g_pool.lk);
         while (g_pool.started < g_pool.want && !g_pool.stop) {
             if (pthread_create(&g_pool.th[g_pool.started], NULL, pool_worker, NULL) != 0) break;
             g_pool.started++;
         }
         if (g_pool.started > 0) {
-            size_t parts = bytes / POOL_MIN_SLICE;
-            if (parts > (size_t)g_pool.started + 1) parts = (size_t)g_pool.started + 1;
-            const size_t slice = ((bytes + parts - 1) / parts + 4095) & ~(size_t)4095;
-            size_t off = slice < bytes ? slice : bytes;
-            own_end = off;
+            if (slice == 0) {
+                size_t parts = bytes / POOL_MIN_SLICE;
+                if (parts > (size_t)g_pool.started) parts = (size_t)g_pool.started;
+                slice = ((bytes + parts - 1) / parts + 4095) & ~(size_t)4095;
+            }
+            int added = 0;
             while (off < bytes && g_pool.tail - g_pool.head < POOL_QUEUE) {
                 const size_t b = bytes - off < slice ? bytes - off : slice;
-                const struct ptask t = { d + off, s ? s + off : NULL, b, &pending };
+                const struct ptask t = { d + off, s ? s + off : NULL, b, pending };
                 g_pool.q[g_pool.tail++ % POOL_QUEUE] = t;
-                pending++;
+                ++*pending;
+                added++;
                 off += b;
             }
-            tail_from = off;
-            queued = pending;
-            if (pending) pthread_cond_broadcast(&g_pool.work_cv);
+            if (added) pthread_cond_broadcast(&g_pool.work_cv);
         }
         pthread_mutex_unlock(&g_pool.lk);
     }
-    if (own_end) { const struct ptask t = { d, s, own_end, NULL }; ptask_run(&t); }
-    if (tail_from < bytes) { const struct ptask t = { d + tail_from, s ? s + tail_from : NULL, bytes - tail_from, NULL }; ptask_run(&t); }
-    if (queued) {
+    if (off < bytes) { const struct ptask t = { d + off, s ? s + off : NULL, bytes - off, NULL }; ptask_run(&t); }
+    return off;
+}
+
+static void pool_wait(int *pending)
+{
+    pthread_mutex_lock(&g_pool.lk);
+    while (*pending) pthread_cond_wait(&g_pool.done_cv, &g_pool.lk);
+    pthread_mutex_unlock(&g_pool.lk);
+}
+
+/* dst[0..bytes) = src[0..bytes) (src == NULL: zeros) on the caller and the pool together; returns when all of it is done */
+static void par_copy(void *dst, const void *src, size_t bytes)
+{
+    uint8_t *d = (uint8_t *)dst;
+    const uint8_t *s = (const uint8_t *)src;
+    int pending = 0;
+    size_t own = bytes;
+    if (bytes >= 2 * POOL_MIN_SLICE) {
         pthread_mutex_lock(&g_pool.lk);
-        while (pending) pthread_cond_wait(&g_pool.done_cv, &g_pool.lk);
+        const size_t helpers = (size_t)(g_pool.started > g_pool.want ? g_pool.started : g_pool.want);
         pthread_mutex_unlock(&g_pool.lk);
+        size_t parts = bytes / POOL_MIN_SLICE;
+        if (parts > helpers + 1) parts = helpers + 1;
+        const size_t slice = ((bytes + parts - 1) / parts + 4095) & ~(size_t)4095;
+        own = slice < bytes ? slice : bytes;
+        if (own < bytes) pool_submit(&pending, d + own, s ? s + own : NULL, bytes - own, slice);
     }
+    if (own) { const struct ptask t = { d, s, own, NULL }; ptask_run(&t); }
+    if (own < bytes) pool_wait(&pending);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -172,10 +193,21 @@ static int is_pinned(const void *p)
  * the pipeline
  * ---------------------------------------------------------------------------------------- */
 
-#define PIPE_FIRST_CHUNK ((size_t)1 << 16)   /* the first chunk of a call; later ones double up to the job's stage size */
-#define PIPE_CHUNK ((size_t)1 << 18)         /* stage size: 1024 blocks of 256 lanes, one full residency of the chip */
+#define PIPE_FIRST_CHUNK ((size_t)1 << 17)   /* the first chunk of a call (512 blocks: the chip is full 0.3 ms after the call); later ones double up to the job's stage size */
+#define PIPE_CHUNK ((size_t)1 << 18)         /* stage size: 1024 blocks of 256 lanes */
 #define PIPE_PIECE ((size_t)8 << 20)         /* staging granularity: a piece is handed to the DMA engine while the next is copied */
 #define PIN_CHECK_MIN ((size_t)1 << 20)      /* smaller arrays are staged without asking whether they are pinned */
+
+static size_t g_pipe_first, g_pipe_stage;   /* eddsa_amd_set_pipeline: 0 = the defaults above / the job's own stage size */
+
+/* tuning: items of the first chunk of a host-pointer call and of its later stages (0 = default).  A measurement aid. */
+void eddsa_amd_set_pipeline(size_t first_chunk, size_t stage_chunk)
+{
+    pthread_rwlock_wrlock(&g_table);
+    g_pipe_first = first_chunk;
+    g_pipe_stage = stage_chunk;
+    pthread_rwlock_unlock(&g_table);
+}
 
 enum { WIPE_NONE = 0, WIPE_IN0 = 1, WIPE_OUT = 2 };   /* which staging buffers held secrets */
 
@@ -184,7 +216,7 @@ struct hjob {
     int has_msgs; const uint8_t *msgs; const uint64_t *msg_off; size_t msg_len;
     uint8_t *out; size_t out_w;
     int (*run)(struct engine *e, const struct hjob *j, uint8_t *d_out, uint8_t *const d_in[PIPE_MAX_IN],
-               const uint8_t *d_msgs, const uint64_t *d_off, size_t msg_len, size_t m, hipStream_t st);
+               const uint8_t *d_msgs, const uint64_t *d_off, size_t msg_len, size_t m, hipStream_t st, hipEvent_t kdone);
     size_t rec_sig, rec_pub, rec_msg;          /* records: offsets inside in[0]'s items (in_w[0] = stride) */
     size_t chunk;                              /* items per pipeline stage (0: PIPE_CHUNK) */
     int wipe;                                  /* WIPE_* */
@@ -226,7 +258,10 @@ static int pipe_init(struct pipe *p)
 {
     int rc = 0;
     if (p->ready) return 0;
-    for (int l = 0; l < PIPE_LANES; l++) TRY(hipStreamCreateWithFlags(&p->lane[l].st, hipStreamNonBlocking));
+    for (int l = 0; l < PIPE_LANES; l++) {
+        TRY(hipStreamCreateWithFlags(&p->lane[l].st, hipStreamNonBlocking));
+        TRY(hipEventCreateWithFlags(&p->lane[l].kdone, hipEventDisableTiming));
+    }
     TRY(hipMalloc((void **)&p->d_stats, 256));
     TRY(hipHostMalloc((void **)&p->h_stats, 256, hipHostMallocDefault));
     p->ready = 1;
@@ -242,6 +277,7 @@ void pipe_release(struct pipe *p)
         wipe_free(L->d_msgs, 0); host_free_wiped(&L->h_msgs, &L->h_msgs_cap);
         wipe_free(L->d_out, L->d_out_cap); host_free_wiped(&L->h_out, &L->h_out_cap);
         if (L->st) (void)hipStreamDestroy(L->st);
+        if (L->kdone) (void)hipEventDestroy(L->kdone);
     }
     wipe_free(p->d_off, 0); host_free_wiped(&p->h_off, &p->h_off_cap);
     if (p->d_stats) (void)hipFree(p->d_stats);
@@ -283,12 +319,16 @@ out:
     return rc;
 }
 
-/* wait for the chunk the lane carries and deliver its results */
-static int lane_drain(struct lane *L)
+/* wait for the chunk the lane carries, deliver its results and zero its staging copies of secrets */
+static int lane_drain(struct lane *L, int wipe, int *wipes)
 {
     hipError_t er = hipStreamSynchronize(L->st);
     if (er == hipSuccess && L->pend_bytes) par_copy(L->pend_dst, L->pend_src, L->pend_bytes);
+    /* wipes == NULL: the lane is about to be reused, zero it now; otherwise queue the zeroing (end of the call) */
+    if ((wipe & 1) && L->used_in0) { if (wipes) pool_submit(wipes, (uint8_t *)L->h_in[0], NULL, L->used_in0, 0); else par_copy(L->h_in[0], NULL, L->used_in0); }
+    if ((wipe & 2) && L->pend_bytes) { if (wipes) pool_submit(wipes, (uint8_t *)L->h_out, NULL, L->pend_bytes, 0); else par_copy(L->h_out, NULL, L->pend_bytes); }
     L->pend_bytes = 0;
+    L->used_in0 = 0;
     return er == hipSuccess ? 0 : -(int)er;
 }
 
@@ -303,12 +343,17 @@ void eddsa_amd_debug_fail_next_host_call(void)
     pthread_rwlock_unlock(&g_table);
 }
 
-/* one host-pointer job on engine e (its device is current) */
+/* One host-pointer job on engine e (its device is current).
+ * Chunk k travels on lane k mod 3: [wait for the lane's previous chunk and deliver it] - stage and upload - kernels -
+ * download, all on the lane's stream.  The KERNELS of consecutive chunks run one after the other (each chunk's kernels
+ * wait for the previous lane's `kdone`): run side by side they would share the chip and finish together, and the
+ * pipeline would drain and refill in bursts (measured: x25519 84 M/s against 120 kernel-only).  Copies overlap freely.
+ * `kdone` is recorded before a verify pass waits for its exact path, so that those few latency-bound waves run beside
+ * the next chunk's kernels (each lane's stream has its own workspace). */
 static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
 {
-    int rc = 0;
+    int rc = 0, wipes = 0;
     struct pipe *p = &e->pipe;
-    size_t used_in0[PIPE_LANES] = { 0 }, used_out[PIPE_LANES] = { 0 };
     int staged_in[PIPE_MAX_IN] = { 0 }, staged_msgs = 0, staged_out = 0;
     if (n == 0) return 0;
     pthread_mutex_lock(&e->pipe_lk);
@@ -316,8 +361,10 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
     if (rc) goto out;
     {
         const int ragged = j->has_msgs && j->msg_off != NULL;
-        const size_t stage = j->chunk ? j->chunk : PIPE_CHUNK;
+        const size_t stage = j->first_chunk ? j->chunk : g_pipe_stage ? g_pipe_stage : j->chunk ? j->chunk : PIPE_CHUNK;
+        const size_t first = j->first_chunk ? j->first_chunk : g_pipe_first ? g_pipe_first : PIPE_FIRST_CHUNK;
         const size_t msg_total = !j->has_msgs ? 0 : ragged ? (size_t)j->msg_off[n] : n * j->msg_len;
+        struct lane *prev = NULL;
         for (int i = 0; i < j->n_in; i++)
             staged_in[i] = !j->src_pinned && !(n * j->in_w[i] >= PIN_CHECK_MIN && is_pinned(j->in[i]));
         staged_msgs = !j->src_pinned && !(msg_total >= PIN_CHECK_MIN && is_pinned(j->msgs));
@@ -329,16 +376,16 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
         size_t lo = 0;
         for (unsigned k = 0; lo < n; k++) {
             struct lane *L = &p->lane[k % PIPE_LANES];
-            size_t m = (j->first_chunk ? j->first_chunk : PIPE_FIRST_CHUNK) << (k < 8 ? k : 8);
+            size_t m = first << (k < 8 ? k : 8);
             if (m > stage) m = stage;
             if (ragged || m > n - lo) m = n - lo;
-            /* the lane's previous chunk (k - PIPE_LANES): the two chunks after it keep the GPU busy meanwhile */
-            if ((rc = lane_drain(L))) goto out;
+            /* the lane's previous chunk (k - 3): the two chunks after it keep the GPU busy meanwhile */
+            if ((rc = lane_drain(L, j->wipe, NULL))) goto out;
             for (int i = 0; i < j->n_in; i++) {
                 if ((rc = dev_grow(&L->d_in[i], &L->d_in_cap[i], m * j->in_w[i]))) goto out;
                 if ((rc = lane_upload(L, L->d_in[i], &L->h_in[i], &L->h_in_cap[i], j->in[i] + lo * j->in_w[i], m * j->in_w[i], staged_in[i]))) goto out;
             }
-            if (m * j->in_w[0] > used_in0[k % PIPE_LANES]) used_in0[k % PIPE_LANES] = m * j->in_w[0];
+            if (staged_in[0]) L->used_in0 = m * j->in_w[0];
             if (j->has_msgs) {
                 const size_t bytes = ragged ? msg_total : m * j->msg_len;
                 const uint8_t *src = ragged ? j->msgs : j->msgs + lo * j->msg_len;
@@ -351,19 +398,20 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
                                       !j->src_pinned))) goto out;
             }
             if ((rc = dev_grow(&L->d_out, &L->d_out_cap, m * j->out_w))) goto out;
+            if (prev) TRY(hipStreamWaitEvent(L->st, prev->kdone, 0));      /* kernels in chunk order */
             {
                 struct hjob jj = *j;
                 jj.stats = j->stats ? p->d_stats : NULL;
                 rc = j->run(e, &jj, (uint8_t *)L->d_out, (uint8_t *const *)L->d_in, (const uint8_t *)L->d_msgs,
-                            ragged ? (const uint64_t *)p->d_off : NULL, j->msg_len, m, L->st);
+                            ragged ? (const uint64_t *)p->d_off : NULL, j->msg_len, m, L->st, L->kdone);
             }
+            prev = L;
             if (!rc && g_fail_next_host_call) { g_fail_next_host_call = 0; rc = -(int)hipErrorUnknown; }
             if (rc) goto out;
             if (staged_out) {
                 if ((rc = host_grow(&L->h_out, &L->h_out_cap, m * j->out_w))) goto out;
                 TRY(hipMemcpyAsync(L->h_out, L->d_out, m * j->out_w, hipMemcpyDeviceToHost, L->st));
                 L->pend_dst = j->out + lo * j->out_w; L->pend_src = (const uint8_t *)L->h_out; L->pend_bytes = m * j->out_w;
-                if (m * j->out_w > used_out[k % PIPE_LANES]) used_out[k % PIPE_LANES] = m * j->out_w;
             } else {
                 TRY(hipMemcpyAsync(j->out + lo * j->out_w, L->d_out, m * j->out_w, hipMemcpyDeviceToHost, L->st));
             }
@@ -373,7 +421,7 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
             lo += m;
             if (lo >= n) {                     /* the chunks still in flight, oldest first */
                 for (unsigned t = 1; t <= PIPE_LANES; t++)
-                    if ((rc = lane_drain(&p->lane[(k + t) % PIPE_LANES]))) goto out;
+                    if ((rc = lane_drain(&p->lane[(k + t) % PIPE_LANES], j->wipe, &wipes))) goto out;
             }
         }
         if (j->stats) {
@@ -384,22 +432,18 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
     }
 out:
     if (rc && p->ready) {
-        for (int l = 0; l < PIPE_LANES; l++) { (void)hipStreamSynchronize(p->lane[l].st); p->lane[l].pend_bytes = 0; }
-        /* a failed call must not leave its secrets behind either (best effort: whole buffers) */
+        for (int l = 0; l < PIPE_LANES; l++) { (void)hipStreamSynchronize(p->lane[l].st); p->lane[l].pend_bytes = 0; p->lane[l].used_in0 = 0; }
+        /* a failed call must not leave its secrets behind either (best effort: whole buffers, HBM and pinned) */
         for (int l = 0; l < PIPE_LANES; l++) {
             struct lane *L = &p->lane[l];
             if ((j->wipe & WIPE_IN0) && L->d_in[0]) (void)hipMemsetAsync(L->d_in[0], 0, L->d_in_cap[0], L->st);
             if ((j->wipe & WIPE_OUT) && L->d_out) (void)hipMemsetAsync(L->d_out, 0, L->d_out_cap, L->st);
             if (j->wipe) (void)hipStreamSynchronize(L->st);
-            used_in0[l] = L->h_in_cap[0]; used_out[l] = L->h_out_cap;
+            if ((j->wipe & WIPE_IN0) && L->h_in[0]) pool_submit(&wipes, (uint8_t *)L->h_in[0], NULL, L->h_in_cap[0], 0);
+            if ((j->wipe & WIPE_OUT) && L->h_out) pool_submit(&wipes, (uint8_t *)L->h_out, NULL, L->h_out_cap, 0);
         }
     }
-    /* ... nor in the pinned staging buffers */
-    for (int l = 0; l < PIPE_LANES && p->ready; l++) {
-        struct lane *L = &p->lane[l];
-        if ((j->wipe & WIPE_IN0) && L->h_in[0] && used_in0[l]) par_copy(L->h_in[0], NULL, used_in0[l] < L->h_in_cap[0] ? used_in0[l] : L->h_in_cap[0]);
-        if ((j->wipe & WIPE_OUT) && L->h_out && used_out[l]) par_copy(L->h_out, NULL, used_out[l] < L->h_out_cap ? used_out[l] : L->h_out_cap);
-    }
+    if (j->wipe) pool_wait(&wipes);            /* nothing secret outlives the call in the pinned staging buffers */
     pthread_mutex_unlock(&e->pipe_lk);
     return rc;
 }
@@ -586,54 +630,56 @@ static int pipe_run(const struct hjob *j, size_t n)
 #define PIPE_CHUNK_VERIFY ((size_t)1 << 19)
 
 #define RUN_ARGS struct engine *e, const struct hjob *j, uint8_t *d_out, uint8_t *const d_in[PIPE_MAX_IN], \
-                 const uint8_t *d_msgs, const uint64_t *d_off, size_t msg_len, size_t m, hipStream_t st
+                 const uint8_t *d_msgs, const uint64_t *d_off, size_t msg_len, size_t m, hipStream_t st, hipEvent_t kdone
+/* record the lane's "kernels queued" event (verify does it itself, before its stream waits for the exact path) */
+#define RUN_DONE(rc_) do { int r_ = (rc_); if (!r_ && hipEventRecord(kdone, st) != hipSuccess) r_ = -(int)hipErrorUnknown; return r_; } while (0)
 static int run_verify(RUN_ARGS)
 {
     (void)j;
     const edk_verify_src src = { d_in[0], d_in[1], d_msgs, d_off, msg_len, 64, 32, msg_len };
-    return verify_on(e, d_out, &src, m, st);
+    return verify_on(e, d_out, &src, m, st, kdone);
 }
 static int run_verify_rlc(RUN_ARGS)
 {
     const edk_verify_src src = { d_in[0], d_in[1], d_msgs, d_off, msg_len, 64, 32, msg_len };
-    return rlc_on(e, d_out, j->stats, &src, m, st);
+    RUN_DONE(rlc_on(e, d_out, j->stats, &src, m, st));
 }
 static int run_verify_records(RUN_ARGS)
 {
     (void)d_msgs; (void)d_off;
     const edk_verify_src src = { d_in[0] + j->rec_sig, d_in[0] + j->rec_pub, d_in[0] + j->rec_msg, NULL, msg_len,
                                  j->in_w[0], j->in_w[0], j->in_w[0] };
-    return verify_on(e, d_out, &src, m, st);
+    return verify_on(e, d_out, &src, m, st, kdone);
 }
 static int run_sign(RUN_ARGS)
 {
     (void)j;
-    return sign_on(e, d_out, d_in[0], d_in[1], d_msgs, d_off, msg_len, m, st);
+    RUN_DONE(sign_on(e, d_out, d_in[0], d_in[1], d_msgs, d_off, msg_len, m, st));
 }
 static int run_x25519(RUN_ARGS)
 {
     (void)j; (void)d_msgs; (void)d_off; (void)msg_len;
-    return x25519_on(e, d_out, d_in[0], d_in[1], m, st);
+    RUN_DONE(x25519_on(e, d_out, d_in[0], d_in[1], m, st));
 }
 static int run_genpub(RUN_ARGS)
 {
     (void)j; (void)d_msgs; (void)d_off; (void)msg_len;
-    return genpub_on(e, d_out, d_in[0], m, st);
+    RUN_DONE(genpub_on(e, d_out, d_in[0], m, st));
 }
 static int run_xbase(RUN_ARGS)
 {
     (void)j; (void)d_msgs; (void)d_off; (void)msg_len;
-    return xbase_on(e, d_out, d_in[0], m, st);
+    RUN_DONE(xbase_on(e, d_out, d_in[0], m, st));
 }
 static int run_pk_to_x(RUN_ARGS)
 {
     (void)j; (void)d_msgs; (void)d_off; (void)msg_len;
-    return pk_to_x_on(e, d_out, d_in[0], m, st);
+    RUN_DONE(pk_to_x_on(e, d_out, d_in[0], m, st));
 }
 static int run_sk_to_x(RUN_ARGS)
 {
     (void)j; (void)d_msgs; (void)d_off; (void)msg_len;
-    return sk_to_x_on(e, d_out, d_in[0], m, st);
+    RUN_DONE(sk_to_x_on(e, d_out, d_in[0], m, st));
 }
 
 static struct hjob job_verify(uint8_t *ok, const uint8_t *sigs, const uint8_t *pubs, const uint8_t *msgs,
