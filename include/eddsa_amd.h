@@ -113,6 +113,14 @@ EDDSA_AMD_DECL void eddsa_amd_set_host_threads(int n);
 /* tuning (a measurement aid): items of the first chunk of a host-pointer call and of its later stages; 0 = the defaults
  * (2^17, then doubling up to 2^19 for verify and 2^18 for the other operations) */
 EDDSA_AMD_DECL void eddsa_amd_set_pipeline(size_t first_chunk, size_t stage_chunk);
+/* tuning (a measurement aid): how the kernels of consecutive chunks of a host-pointer call are ordered.  -1 (default):
+ * each operation's own setting; 0: side by side; 1: in chunk order; 2: in chunk order, a verify chunk starting beside the
+ * previous chunk's main kernel */
+EDDSA_AMD_DECL void eddsa_amd_set_pipeline_chain(int mode);
+/* measurement aid: host-side time stamps of the host-pointer pipeline (csrc/host_pipe.c); on != 0 switches recording on for
+ * the calls that follow; returns the stamps of the last call: tag (0 call start, 1 lane drained, 2 inputs staged and
+ * queued, 3 kernels queued, 4 download queued, 5 all lanes drained, 6 call end), chunk index, ms since the call started */
+EDDSA_AMD_DECL int eddsa_amd_debug_pipe_trace(int on, int *tags, unsigned *chunks, double *ms, int max);
 /* diagnostic: out[0] = launches the combiner of small host-pointer calls has made on the default device, out[1] = the
  * calls they carried (equal when no two calls ever met) */
 EDDSA_AMD_DECL int eddsa_amd_combiner_stats(uint64_t out[2]);

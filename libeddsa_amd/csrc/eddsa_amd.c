@@ -480,7 +480,7 @@ static void slot_quiesce(struct vslot *v, hipStream_t st)
 }
 
 /* both verify forms: chunks of at most CHUNK_MAX items through the workspace */
-int verify_on(struct engine *e, uint8_t *ok, const edk_verify_src *all, size_t n, hipStream_t st, hipEvent_t bulk_done)
+int verify_on(struct engine *e, uint8_t *ok, const edk_verify_src *all, size_t n, hipStream_t st, hipEvent_t bulk_done, int bulk_early)
 {
     int rc = 0;
     if (n == 0) return 0;
@@ -500,7 +500,7 @@ int verify_on(struct engine *e, uint8_t *ok, const edk_verify_src *all, size_t n
         if (all->msg_off) src.msg_off += done; else src.msgs += done * all->msg_stride;
         hipEvent_t *marks = NULL;
         if (g_profiling && e->marks_used < MARK_SLOTS) marks = e->marks[e->marks_used++];
-        TRY(edk_verify(ok + done, &src, m, e->base16, &v->ws, marks, done + CHUNK_MAX >= n ? bulk_done : NULL, st));
+        TRY(edk_verify(ok + done, &src, m, e->base16, &v->ws, marks, done + CHUNK_MAX >= n ? bulk_done : NULL, bulk_early, st));
     }
     TRY(hipEventRecord(v->free, st));
 out:
@@ -614,7 +614,7 @@ int rlc_on(struct engine *e, uint8_t *ok, uint32_t *stats, const edk_verify_src 
     if (n < g_rlc_min_items) {
         /* the combination has about 2 ms of latency of its own (hash tree, one serial Horner per group): below
          * ~3 x 2^17 items the per-item kernels are faster (tools/rlc_sizes.py), so such calls go straight to them */
-        rc = verify_on(e, ok, all, n, st, NULL);
+        rc = verify_on(e, ok, all, n, st, NULL, 0);
         if (!rc) { hipError_t er = edk_rlc_note_per_item(stats, n, st); if (er != hipSuccess) rc = -(int)er; }
         return rc;
     }
@@ -668,7 +668,7 @@ int ed25519_verify_batch_dev(uint8_t *ok, const uint8_t *sigs, const uint8_t *pu
 {
     const edk_verify_src src = { sigs, pubs, msgs, msg_off, msg_len, 64, 32, msg_len };
     DEV_ENTER(ok);
-    rc = verify_on(c.e, ok, &src, n, (hipStream_t)stream, NULL);
+    rc = verify_on(c.e, ok, &src, n, (hipStream_t)stream, NULL, 0);
     leave(&c);
     return rc;
 }
@@ -687,7 +687,7 @@ int ed25519_verify_records_dev(uint8_t *ok, const uint8_t *records, size_t strid
     const edk_verify_src src = { records + sig_off, records + pub_off, records + msg_off, NULL, msg_len,
                                  stride, stride, stride };
     DEV_ENTER(ok);
-    rc = verify_on(c.e, ok, &src, n, (hipStream_t)stream, NULL);
+    rc = verify_on(c.e, ok, &src, n, (hipStream_t)stream, NULL, 0);
     leave(&c);
     return rc;
 }
@@ -856,7 +856,7 @@ int ed25519_verify_batch_multi_dev(uint8_t *const ok_full[], const uint8_t *cons
         if (hi - lo != n_total / (size_t)g) even = 0;
         const edk_verify_src src = { sigs[d], pubs[d], msgs[d], NULL, msg_len, 64, 32, msg_len };
         TRY(hipSetDevice(g_multi.dev[d]));
-        rc = verify_on(g_eng[g_multi.dev[d]], ok_full[d] + lo, &src, hi - lo, (hipStream_t)streams[d], NULL);
+        rc = verify_on(g_eng[g_multi.dev[d]], ok_full[d] + lo, &src, hi - lo, (hipStream_t)streams[d], NULL, 0);
     }
     if (rc) goto out;
     /* the final result gather: the only exchange of the path */

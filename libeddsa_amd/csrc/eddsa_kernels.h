@@ -62,9 +62,10 @@ typedef struct {
 } edk_verify_src;
 
 /* bulk_done (or NULL): recorded on `stream` once every kernel that fills the chip has been queued, before the stream
- * waits for the exact path's side stream */
+ * waits for the exact path's side stream (bulk_early != 0: already before the main kernel, so that a following pass on
+ * another workspace starts beside it) */
 hipError_t edk_verify(uint8_t* ok, const edk_verify_src* src, size_t n, const uint32_t* base16,
-                      const edk_verify_ws* ws, hipEvent_t* marks /* 4 events or NULL */, hipEvent_t bulk_done,
+                      const edk_verify_ws* ws, hipEvent_t* marks /* 4 events or NULL */, hipEvent_t bulk_done, int bulk_early,
                       hipStream_t stream);
 
 /* workspace of the fixed-base operations for up to `capacity` items (a multiple of VERIFY_TILE) */

@@ -65,8 +65,9 @@ struct lane {
     void *h_in[PIPE_MAX_IN]; size_t h_in_cap[PIPE_MAX_IN];     /* pinned host staging */
     void *h_msgs; size_t h_msgs_cap;
     void *h_out; size_t h_out_cap;
-    /* the chunk in flight on this lane: where its results go once the lane's stream has drained */
-    uint8_t *pend_dst; const uint8_t *pend_src; size_t pend_bytes;
+    /* the chunk in flight on this lane: its results go from pend_dev (HBM) to pend_dst (the caller's memory), through
+     * pend_via (pinned staging) unless the caller's memory is page-locked itself, once the lane's kernels are done */
+    uint8_t *pend_dst, *pend_via, *pend_dev; size_t pend_bytes;
     size_t used_in0;                  /* bytes of h_in[0] the chunk staged (zeroed after the chunk when they were secret) */
 };
 struct pipe {
@@ -140,7 +141,7 @@ void wipe_free(void *p, size_t bytes);
 /* device-pointer work on one engine (the engine's device is current); all asynchronous on `st` except rlc_on,
  * which waits for the stream once per pass */
 /* bulk_done (or NULL): see edk_verify */
-int verify_on(struct engine *e, uint8_t *ok, const edk_verify_src *all, size_t n, hipStream_t st, hipEvent_t bulk_done);
+int verify_on(struct engine *e, uint8_t *ok, const edk_verify_src *all, size_t n, hipStream_t st, hipEvent_t bulk_done, int bulk_early);
 int rlc_on(struct engine *e, uint8_t *ok, uint32_t *stats, const edk_verify_src *all, size_t n, hipStream_t st);
 int sign_on(struct engine *e, uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs, const uint8_t *msgs,
             const uint64_t *msg_off, size_t msg_len, size_t n, hipStream_t st);

@@ -7,8 +7,8 @@
  *   1. A streaming pipeline over PIPE_LANES lanes.  A lane carries one chunk of the batch at a time on its own
  *      stream - upload, kernels, download, in order - so up to three chunks are in flight: one uploading, one
  *      computing, one downloading, and the kernels of consecutive chunks overlap on the GPU (each lane's stream
- *      draws its own workspace from the engine's pool).  Chunks start small (2^16 items: the GPU is working
- *      0.3 ms after the call) and double up to the job's stage size.
+ *      draws its own workspace from the engine's pool).  Chunks start small (2^16 or 2^17 items: the GPU is working
+ *      0.2 ms after the call) and double up to the job's stage size.
  *   2. Pinned staging.  hipMemcpyAsync from pageable memory is staged by the HIP runtime on one thread at about
  *      11 GB/s and blocks the caller (round 2: 86.8 M verifies/s host to host against 109.5 kernel-only, sign 113
  *      against 182 from pinned memory).  Here every lane owns pinned staging buffers; caller memory is copied into
@@ -199,6 +199,14 @@ static int is_pinned(const void *p)
 #define PIN_CHECK_MIN ((size_t)1 << 20)      /* smaller arrays are staged without asking whether they are pinned */
 
 static size_t g_pipe_first, g_pipe_stage;   /* eddsa_amd_set_pipeline: 0 = the defaults above / the job's own stage size */
+static int g_pipe_chain = -1;               /* -1: the job's own; 0: the lanes' kernels run side by side; 1: in chunk order; 2: verify's next chunk starts beside the main kernel */
+
+void eddsa_amd_set_pipeline_chain(int mode)
+{
+    pthread_rwlock_wrlock(&g_table);
+    g_pipe_chain = mode;
+    pthread_rwlock_unlock(&g_table);
+}
 
 /* tuning: items of the first chunk of a host-pointer call and of its later stages (0 = default).  A measurement aid. */
 void eddsa_amd_set_pipeline(size_t first_chunk, size_t stage_chunk)
@@ -221,7 +229,8 @@ struct hjob {
     size_t chunk;                              /* items per pipeline stage (0: PIPE_CHUNK) */
     int wipe;                                  /* WIPE_* */
     uint32_t *stats;                           /* rlc: host copy of the pass statistics (4 words) or NULL */
-    size_t first_chunk;                        /* items of the first stage (0: PIPE_FIRST_CHUNK); later stages double up to `chunk` */
+    size_t first_chunk;                        /* items of the first chunk (0: PIPE_FIRST_CHUNK); later ones double up to `chunk` */
+    int chain;                                 /* the kernels of consecutive chunks run in chunk order (else side by side) */
     int combinable;                            /* small calls of this job may be merged with other threads' (same `run`) */
     int src_pinned;                            /* every host array of the job is page-locked: no staging */
 };
@@ -319,20 +328,54 @@ out:
     return rc;
 }
 
-/* wait for the chunk the lane carries, deliver its results and zero its staging copies of secrets */
+/* Wait for the kernels of the chunk the lane carries, fetch its results, deliver them and zero the staging copies of
+ * secrets.  The download is queued only now, when it can run at once: a copy queued behind kernels still to run sits at
+ * the head of one of the DMA engines' queues, and the UPLOADS that the runtime later hands to the same engine wait
+ * behind it (measured: the last two pieces of a chunk's upload ran 5 ms late, the whole call 12.4 instead of 10 ms). */
 static int lane_drain(struct lane *L, int wipe, int *wipes)
 {
-    hipError_t er = hipStreamSynchronize(L->st);
-    if (er == hipSuccess && L->pend_bytes) par_copy(L->pend_dst, L->pend_src, L->pend_bytes);
+    int rc = 0;
+    TRY(hipStreamSynchronize(L->st));
+    if (L->pend_bytes) {
+        TRY(hipMemcpyAsync(L->pend_via ? L->pend_via : (void *)L->pend_dst, L->pend_dev, L->pend_bytes, hipMemcpyDeviceToHost, L->st));
+        if (wipe & 2) TRY(hipMemsetAsync(L->pend_dev, 0, L->pend_bytes, L->st));        /* shared secrets leave HBM with the call */
+        TRY(hipStreamSynchronize(L->st));
+        if (L->pend_via) par_copy(L->pend_dst, L->pend_via, L->pend_bytes);
+    }
     /* wipes == NULL: the lane is about to be reused, zero it now; otherwise queue the zeroing (end of the call) */
     if ((wipe & 1) && L->used_in0) { if (wipes) pool_submit(wipes, (uint8_t *)L->h_in[0], NULL, L->used_in0, 0); else par_copy(L->h_in[0], NULL, L->used_in0); }
-    if ((wipe & 2) && L->pend_bytes) { if (wipes) pool_submit(wipes, (uint8_t *)L->h_out, NULL, L->pend_bytes, 0); else par_copy(L->h_out, NULL, L->pend_bytes); }
+    if ((wipe & 2) && L->pend_bytes && L->pend_via) { if (wipes) pool_submit(wipes, (uint8_t *)L->pend_via, NULL, L->pend_bytes, 0); else par_copy(L->pend_via, NULL, L->pend_bytes); }
+out:
     L->pend_bytes = 0;
     L->used_in0 = 0;
-    return er == hipSuccess ? 0 : -(int)er;
+    return rc;
 }
 
 static int g_fail_next_host_call;      /* eddsa_amd_debug_fail_next_host_call */
+
+/* measurement aid: host-side time stamps of the last host-pointer call (eddsa_amd_debug_pipe_trace) */
+#define TRACE_MAX 512
+static struct { int on, n; int tag[TRACE_MAX]; unsigned chunk[TRACE_MAX]; double t[TRACE_MAX]; } g_trace;
+static double trace_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e3 + 1e-6 * (double)ts.tv_nsec;
+}
+#define TRACE(tag_, k_) do { if (g_trace.on && g_trace.n < TRACE_MAX) { g_trace.tag[g_trace.n] = (tag_); g_trace.chunk[g_trace.n] = (k_); g_trace.t[g_trace.n++] = trace_now(); } } while (0)
+
+/* on != 0: record host-side time stamps in every host-pointer call from now on; returns the number of stamps of the last
+ * call and copies up to `max` of them: tag (0 call start, 1 lane drained, 2 inputs staged and queued, 3 kernels queued,
+ * 4 download queued, 5 all lanes drained, 6 call end), chunk index, milliseconds since the call started */
+int eddsa_amd_debug_pipe_trace(int on, int *tags, unsigned *chunks, double *ms, int max)
+{
+    pthread_rwlock_wrlock(&g_table);
+    const int n = g_trace.n < max ? g_trace.n : max;
+    for (int i = 0; i < n; i++) { tags[i] = g_trace.tag[i]; chunks[i] = g_trace.chunk[i]; ms[i] = g_trace.t[i] - g_trace.t[0]; }
+    g_trace.on = on;
+    pthread_rwlock_unlock(&g_table);
+    return n;
+}
 
 /* test hook: the next host-pointer call fails (hipErrorUnknown) after its inputs were staged and its kernels launched,
  * so that the error path's clean-up (the staging copies of secrets are wiped there too) can be exercised */
@@ -344,12 +387,16 @@ void eddsa_amd_debug_fail_next_host_call(void)
 }
 
 /* One host-pointer job on engine e (its device is current).
- * Chunk k travels on lane k mod 3: [wait for the lane's previous chunk and deliver it] - stage and upload - kernels -
- * download, all on the lane's stream.  The KERNELS of consecutive chunks run one after the other (each chunk's kernels
- * wait for the previous lane's `kdone`): run side by side they would share the chip and finish together, and the
- * pipeline would drain and refill in bursts (measured: x25519 84 M/s against 120 kernel-only).  Copies overlap freely.
- * `kdone` is recorded before a verify pass waits for its exact path, so that those few latency-bound waves run beside
- * the next chunk's kernels (each lane's stream has its own workspace). */
+ * Chunk k travels on lane k mod 3: [wait for the lane's previous chunk, fetch and deliver its results] - stage and
+ * upload - kernels, all on the lane's stream; copies and kernels of different lanes overlap.  How the KERNELS of
+ * consecutive chunks are ordered is the job's choice (hjob.chain; tools/pipe_sweep.py has the measurements):
+ *   in chunk order (each chunk's kernels wait for the previous lane's `kdone`): x25519, sign and the other fixed-base
+ *     operations, whose chunk is one long kernel - side by side three of them share the chip, finish together, and the
+ *     pipeline drains and refills in bursts (x25519 84-93 M/s against 103-105 in order);
+ *   side by side: verify, whose three kernels per chunk leave ramps and tails that the neighbours fill (95.7 M/s
+ *     against 79-86 in order).
+ * `kdone` is recorded before a verify pass waits for its exact path, so that those few latency-bound waves never hold
+ * up the next chunk (each lane's stream has its own workspace). */
 static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
 {
     int rc = 0, wipes = 0;
@@ -357,12 +404,15 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
     int staged_in[PIPE_MAX_IN] = { 0 }, staged_msgs = 0, staged_out = 0;
     if (n == 0) return 0;
     pthread_mutex_lock(&e->pipe_lk);
+    g_trace.n = 0;
+    TRACE(0, 0);
     rc = pipe_init(p);
     if (rc) goto out;
     {
         const int ragged = j->has_msgs && j->msg_off != NULL;
-        const size_t stage = j->first_chunk ? j->chunk : g_pipe_stage ? g_pipe_stage : j->chunk ? j->chunk : PIPE_CHUNK;
-        const size_t first = j->first_chunk ? j->first_chunk : g_pipe_first ? g_pipe_first : PIPE_FIRST_CHUNK;
+        const int tunable = j->stats == NULL;                   /* (a combination covers a fixed number of items) */
+        const size_t stage = tunable && g_pipe_stage ? g_pipe_stage : j->chunk ? j->chunk : PIPE_CHUNK;
+        const size_t first = tunable && g_pipe_first ? g_pipe_first : j->first_chunk ? j->first_chunk : PIPE_FIRST_CHUNK;
         const size_t msg_total = !j->has_msgs ? 0 : ragged ? (size_t)j->msg_off[n] : n * j->msg_len;
         struct lane *prev = NULL;
         for (int i = 0; i < j->n_in; i++)
@@ -381,6 +431,7 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
             if (ragged || m > n - lo) m = n - lo;
             /* the lane's previous chunk (k - 3): the two chunks after it keep the GPU busy meanwhile */
             if ((rc = lane_drain(L, j->wipe, NULL))) goto out;
+            TRACE(1, k);
             for (int i = 0; i < j->n_in; i++) {
                 if ((rc = dev_grow(&L->d_in[i], &L->d_in_cap[i], m * j->in_w[i]))) goto out;
                 if ((rc = lane_upload(L, L->d_in[i], &L->h_in[i], &L->h_in_cap[i], j->in[i] + lo * j->in_w[i], m * j->in_w[i], staged_in[i]))) goto out;
@@ -398,7 +449,8 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
                                       !j->src_pinned))) goto out;
             }
             if ((rc = dev_grow(&L->d_out, &L->d_out_cap, m * j->out_w))) goto out;
-            if (prev) TRY(hipStreamWaitEvent(L->st, prev->kdone, 0));      /* kernels in chunk order */
+            TRACE(2, k);
+            if (prev && (g_pipe_chain < 0 ? j->chain : g_pipe_chain)) TRY(hipStreamWaitEvent(L->st, prev->kdone, 0));      /* kernels in chunk order */
             {
                 struct hjob jj = *j;
                 jj.stats = j->stats ? p->d_stats : NULL;
@@ -406,22 +458,24 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
                             ragged ? (const uint64_t *)p->d_off : NULL, j->msg_len, m, L->st, L->kdone);
             }
             prev = L;
+            TRACE(3, k);
             if (!rc && g_fail_next_host_call) { g_fail_next_host_call = 0; rc = -(int)hipErrorUnknown; }
             if (rc) goto out;
+            /* the download: queued by lane_drain, once the kernels are done */
+            L->pend_via = NULL;
             if (staged_out) {
                 if ((rc = host_grow(&L->h_out, &L->h_out_cap, m * j->out_w))) goto out;
-                TRY(hipMemcpyAsync(L->h_out, L->d_out, m * j->out_w, hipMemcpyDeviceToHost, L->st));
-                L->pend_dst = j->out + lo * j->out_w; L->pend_src = (const uint8_t *)L->h_out; L->pend_bytes = m * j->out_w;
-            } else {
-                TRY(hipMemcpyAsync(j->out + lo * j->out_w, L->d_out, m * j->out_w, hipMemcpyDeviceToHost, L->st));
+                L->pend_via = (uint8_t *)L->h_out;
             }
+            L->pend_dst = j->out + lo * j->out_w; L->pend_dev = (uint8_t *)L->d_out; L->pend_bytes = m * j->out_w;
             /* secrets do not outlive the call in HBM */
             if (j->wipe & WIPE_IN0) TRY(hipMemsetAsync(L->d_in[0], 0, m * j->in_w[0], L->st));
-            if (j->wipe & WIPE_OUT) TRY(hipMemsetAsync(L->d_out, 0, m * j->out_w, L->st));
             lo += m;
+            TRACE(4, k);
             if (lo >= n) {                     /* the chunks still in flight, oldest first */
                 for (unsigned t = 1; t <= PIPE_LANES; t++)
                     if ((rc = lane_drain(&p->lane[(k + t) % PIPE_LANES], j->wipe, &wipes))) goto out;
+                TRACE(5, k);
             }
         }
         if (j->stats) {
@@ -444,6 +498,7 @@ out:
         }
     }
     if (j->wipe) pool_wait(&wipes);            /* nothing secret outlives the call in the pinned staging buffers */
+    TRACE(6, 0);
     pthread_mutex_unlock(&e->pipe_lk);
     return rc;
 }
@@ -637,7 +692,7 @@ static int run_verify(RUN_ARGS)
 {
     (void)j;
     const edk_verify_src src = { d_in[0], d_in[1], d_msgs, d_off, msg_len, 64, 32, msg_len };
-    return verify_on(e, d_out, &src, m, st, kdone);
+    return verify_on(e, d_out, &src, m, st, kdone, g_pipe_chain == 2);
 }
 static int run_verify_rlc(RUN_ARGS)
 {
@@ -649,7 +704,7 @@ static int run_verify_records(RUN_ARGS)
     (void)d_msgs; (void)d_off;
     const edk_verify_src src = { d_in[0] + j->rec_sig, d_in[0] + j->rec_pub, d_in[0] + j->rec_msg, NULL, msg_len,
                                  j->in_w[0], j->in_w[0], j->in_w[0] };
-    return verify_on(e, d_out, &src, m, st, kdone);
+    return verify_on(e, d_out, &src, m, st, kdone, g_pipe_chain == 2);
 }
 static int run_sign(RUN_ARGS)
 {
@@ -685,26 +740,29 @@ static int run_sk_to_x(RUN_ARGS)
 static struct hjob job_verify(uint8_t *ok, const uint8_t *sigs, const uint8_t *pubs, const uint8_t *msgs,
                               const uint64_t *msg_off, size_t msg_len)
 {
+    /* Measured (tools/pipe_sweep.py, 2^20 items from malloc memory): the three kernels of a verify chunk leave ramps and
+     * tails that the neighbouring chunks' kernels fill when the lanes run side by side (95.7 M/s; in chunk order 79-86),
+     * and the small first chunk gets the chip working 0.2 ms after the call. */
     struct hjob j = { 2, { sigs, pubs, NULL }, { 64, 32, 0 }, 1, msgs, msg_off, msg_len, ok, 1, run_verify, 0, 0, 0,
-                      PIPE_CHUNK_VERIFY, WIPE_NONE, NULL, 0, 1, 0 };
+                      PIPE_CHUNK_VERIFY, WIPE_NONE, NULL, (size_t)1 << 16, 0, 1, 0 };
     return j;
 }
 static struct hjob job_sign(uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs, const uint8_t *msgs,
                             const uint64_t *msg_off, size_t msg_len)
 {
     struct hjob j = { 2, { secs, pubs, NULL }, { 32, 32, 0 }, 1, msgs, msg_off, msg_len, sigs, 64, run_sign, 0, 0, 0, 0,
-                      WIPE_IN0, NULL, 0, 1, 0 };
+                      WIPE_IN0, NULL, 0, 1, 1, 0 };
     return j;
 }
 static struct hjob job_x25519(uint8_t *out, const uint8_t *scalars, const uint8_t *points)
 {
     struct hjob j = { 2, { scalars, points, NULL }, { 32, 32, 0 }, 0, NULL, NULL, 0, out, 32, run_x25519, 0, 0, 0, 0,
-                      WIPE_IN0 | WIPE_OUT, NULL, 0, 1, 0 };
+                      WIPE_IN0 | WIPE_OUT, NULL, 0, 1, 1, 0 };
     return j;
 }
 static struct hjob job_1in(int (*run)(RUN_ARGS), uint8_t *out, const uint8_t *in, int wipe)
 {
-    struct hjob j = { 1, { in, NULL, NULL }, { 32, 0, 0 }, 0, NULL, NULL, 0, out, 32, run, 0, 0, 0, 0, wipe, NULL, 0, 1, 0 };
+    struct hjob j = { 1, { in, NULL, NULL }, { 32, 0, 0 }, 0, NULL, NULL, 0, out, 32, run, 0, 0, 0, 0, wipe, NULL, 0, 1, 1, 0 };
     return j;
 }
 
@@ -738,7 +796,7 @@ int ed25519_verify_records(uint8_t *ok, const uint8_t *records, size_t stride, s
 {
     if (!records_ok(stride, sig_off, pub_off, msg_off, msg_len)) return -(int)hipErrorInvalidValue;
     struct hjob j = { 1, { records, NULL, NULL }, { stride, 0, 0 }, 0, NULL, NULL, msg_len, ok, 1, run_verify_records,
-                      sig_off, pub_off, msg_off, PIPE_CHUNK_VERIFY, WIPE_NONE, NULL, 0, 0, 0 };
+                      sig_off, pub_off, msg_off, PIPE_CHUNK_VERIFY, WIPE_NONE, NULL, (size_t)1 << 16, 0, 0, 0 };
     return pipe_run(&j, n);
 }
 

@@ -817,7 +817,7 @@ hipError_t edk_debug_halve(uint8_t* out, const uint8_t* t, size_t n, int wide, h
 }
 
 hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const uint32_t* base16,
-                      const edk_verify_ws* ws, hipEvent_t* marks, hipEvent_t bulk_done, hipStream_t stream) {
+                      const edk_verify_ws* ws, hipEvent_t* marks, hipEvent_t bulk_done, int bulk_early, hipStream_t stream) {
   const edk_verify_src src = *srcp;
   if (n == 0) return hipSuccess;
   const unsigned blocks = (unsigned)((n + BLOCK - 1) / BLOCK);
@@ -847,6 +847,7 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
     hipLaunchKernelGGL(k_verify_halve<HALF_BITS>, dim3(blocks), dim3(BLOCK), 0, stream, src.sigs, src.sig_stride, n, ws->digits,
                        ws->hdigits, ws->rtable, ws->flags, ws->offlist, ws->offcount);
   if (marks) (void)hipEventRecord(marks[1], stream);
+  if (bulk_done && bulk_early) (void)hipEventRecord(bulk_done, stream);   // the next pass may start beside this one's main kernel
   // the exact path depends only on what came before: both of its kernels run beside the main kernel on the side stream
   const size_t fast_items = (size_t)QUAD_MAX_ITEMS;
   if (ws->exact_offcurve) {
@@ -886,7 +887,7 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   }
   // everything that fills the chip has been queued; what follows on this stream only waits for the exact path's few
   // latency-bound waves: a caller that pipelines passes over several workspaces starts the next pass from here
-  if (bulk_done) (void)hipEventRecord(bulk_done, stream);
+  if (bulk_done && !bulk_early) (void)hipEventRecord(bulk_done, stream);
   if (ws->exact_offcurve) {
     (void)hipStreamWaitEvent(stream, ws->ev_exact, 0);   // complete when both paths are
     if (n > fast_items)   // possibly more listed keys than the fast route takes: the rest, strided, one kernel

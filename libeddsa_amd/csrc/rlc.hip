@@ -529,7 +529,7 @@ extern "C" hipError_t edk_verify_rlc_fallback(uint8_t* ok, const edk_verify_src*
     sub.sigs += lo * src.sig_stride;
     sub.pubs += lo * src.pub_stride;
     if (src.msg_off) sub.msg_off += lo; else sub.msgs += lo * src.msg_stride;
-    if ((e = edk_verify(ok + lo, &sub, hi - lo, base16, ws, nullptr, nullptr, stream)) != hipSuccess) return e;
+    if ((e = edk_verify(ok + lo, &sub, hi - lo, base16, ws, nullptr, nullptr, 0, stream)) != hipSuccess) return e;
     g = g1;
   }
   return hipSuccess;

@@ -18,8 +18,16 @@ workload.corrupt_for_verify(sig, pk, msg)
 sc, pt = workload.x25519_inputs(n)
 fn = {"verify": lambda: ed.ed25519_verify_batch(sig, pk, msg), "x25519": lambda: ed.x25519_batch(sc, pt),
       "sign": lambda: ed.ed25519_sign_batch(sk, pk, msg)}[op]
+import ctypes
+lib = ed.library()
+tags, chunks, ms = (ctypes.c_int * 512)(), (ctypes.c_uint * 512)(), (ctypes.c_double * 512)()
+lib.eddsa_amd_debug_pipe_trace(1, tags, chunks, ms, 0)
 for _ in range(3):
     fn()
 time.sleep(0.05)
 t0 = time.perf_counter(); fn(); dt = time.perf_counter() - t0
 print(f"{op}: {dt*1e3:.2f} ms host to host, {n/dt/1e6:.1f} M/s")
+k = lib.eddsa_amd_debug_pipe_trace(0, tags, chunks, ms, 512)
+names = ["call start", "lane drained", "inputs staged+queued", "kernels queued", "download queued", "all lanes drained", "call end"]
+for i in range(k):
+    print(f"  host {ms[i]:8.3f} ms  chunk {chunks[i]}  {names[tags[i]]}")

@@ -17,11 +17,11 @@ def timeit(fn, reps=6):
         t0 = time.perf_counter(); out = fn(); best = min(best, time.perf_counter() - t0)
     return best, out
 lib = ed.library()
-for first in (16, 17, 18):
-    for stage in (18, 19, 20):
-        if stage < first: continue
+for chain in (0, 1, 2):
+    lib.eddsa_amd_set_pipeline_chain(chain)
+    for first, stage in ((16, 18), (16, 19), (17, 18), (17, 19), (18, 18), (18, 19)):
         lib.eddsa_amd_set_pipeline(ctypes.c_size_t(1 << first), ctypes.c_size_t(1 << stage))
         dv, ok = timeit(lambda: ed.ed25519_verify_batch(sig, pk, msg)); assert np.array_equal(ok, expect)
         dx, _ = timeit(lambda: ed.x25519_batch(sc, pt))
         ds, _ = timeit(lambda: ed.ed25519_sign_batch(sk, pk, msg))
-        print(f"first 2^{first} stage 2^{stage}: verify {n/dv/1e6:6.1f} M/s ({dv*1e3:5.2f} ms)  x25519 {n/dx/1e6:6.1f} ({dx*1e3:5.2f})  sign {n/ds/1e6:6.1f} ({ds*1e3:5.2f})", flush=True)
+        print(f"chain {chain} first 2^{first} stage 2^{stage}: verify {n/dv/1e6:6.1f} M/s ({dv*1e3:5.2f} ms)  x25519 {n/dx/1e6:6.1f} ({dx*1e3:5.2f})  sign {n/ds/1e6:6.1f} ({ds*1e3:5.2f})", flush=True)
