@@ -107,7 +107,7 @@ EDDSA_AMD_DECL int ed25519_verify_batch_multi_dev(uint8_t *const ok_full[], cons
  * engines in place, without the staging copy ordinary memory needs.  NULL when the allocation fails. */
 EDDSA_AMD_DECL void *eddsa_amd_host_alloc(size_t bytes);
 EDDSA_AMD_DECL void eddsa_amd_host_free(void *p);
-/* helper threads that copy ordinary caller memory into the staging buffers beside the calling thread (default 4, at
+/* helper threads that copy ordinary caller memory into the staging buffers beside the calling thread (default 6, at
  * most 16; 0 = the caller copies alone) */
 EDDSA_AMD_DECL void eddsa_amd_set_host_threads(int n);
 /* tuning (a measurement aid): items of the first chunk of a host-pointer call and of its later stages; 0 = the defaults

@@ -140,7 +140,7 @@ def set_rlc_min_items(items):
 
 
 def set_host_threads(n):
-    """helper threads that stage ordinary host memory into the pipeline's page-locked buffers (default 4, 0..16)"""
+    """helper threads that stage ordinary host memory into the pipeline's page-locked buffers (default 6, 0..16)"""
     library().eddsa_amd_set_host_threads(int(n))
 
 

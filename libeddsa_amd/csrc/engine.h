@@ -16,7 +16,9 @@
 #ifndef EDDSA_AMD_ENGINE_H
 #define EDDSA_AMD_ENGINE_H
 
+#ifndef _POSIX_C_SOURCE
 #define _POSIX_C_SOURCE 200809L
+#endif
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 
@@ -68,6 +70,7 @@ struct lane {
     /* the chunk in flight on this lane: its results go from pend_dev (HBM) to pend_dst (the caller's memory), through
      * pend_via (pinned staging) unless the caller's memory is page-locked itself, once the lane's kernels are done */
     uint8_t *pend_dst, *pend_via, *pend_dev; size_t pend_bytes;
+    int pend_queued;                  /* the download is already queued behind the kernels (calls of one chunk) */
     size_t used_in0;                  /* bytes of h_in[0] the chunk staged (zeroed after the chunk when they were secret) */
 };
 struct pipe {
@@ -83,10 +86,10 @@ struct pipe {
 struct creq;
 struct combiner {
     pthread_mutex_t lk;
-    pthread_cond_t cv;
+    uint32_t gen;                     /* bumped when a launch completes; waiters sleep on it (futex) */
     struct creq *head, *tail;
     int leader;                       /* some thread is packing / running a combined batch */
-    unsigned queued, last_reqs;       /* requests waiting; calls the previous launch carried */
+    unsigned queued, last_reqs, waiting_at_end;   /* requests waiting; calls the last launch carried; requests waiting when it ended */
     void *h_in[PIPE_MAX_IN]; size_t h_in_cap[PIPE_MAX_IN];     /* pinned: the packed batch */
     void *h_msgs; size_t h_msgs_cap;
     void *h_out; size_t h_out_cap;

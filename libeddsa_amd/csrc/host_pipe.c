@@ -25,13 +25,18 @@
  * pinned host buffers and in the combiner's buffers - before the call returns, on the error path too (the
  * reference wipes its stack after the same operations: lib/ed25519-sha512.c:77,136, lib/x25519.c:208,221).
  */
+#define _GNU_SOURCE                    /* syscall(): the combiner's waiters sleep on a futex */
 #include "engine.h"
 
+#include <limits.h>
+#include <linux/futex.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/syscall.h>
 #include <time.h>
-#include <sched.h>
+#include <unistd.h>
 
 /* ------------------------------------------------------------------------------------------
  * copier pool: memcpy / memset of large host ranges on several threads
@@ -50,7 +55,7 @@ static struct {
     int started, want, stop;
     struct ptask q[POOL_QUEUE];
     unsigned head, tail;                      /* tasks q[head % POOL_QUEUE .. tail) */
-} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 4, 0, {{0}}, 0, 0 };
+} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 6, 0, {{0}}, 0, 0 };
 
 static void ptask_run(const struct ptask *t)
 {
@@ -74,7 +79,7 @@ static void *pool_worker(void *arg)
     return NULL;
 }
 
-/* helper threads beside the calling thread (default 4; 0 = the caller copies alone).  Takes effect for the threads
+/* helper threads beside the calling thread (default 6; 0 = the caller copies alone).  Takes effect for the threads
  * not yet started; eddsa_amd_shutdown stops the pool, the next large call starts it again. */
 void eddsa_amd_set_host_threads(int n)
 {
@@ -337,9 +342,11 @@ static int lane_drain(struct lane *L, int wipe, int *wipes)
     int rc = 0;
     TRY(hipStreamSynchronize(L->st));
     if (L->pend_bytes) {
-        TRY(hipMemcpyAsync(L->pend_via ? L->pend_via : (void *)L->pend_dst, L->pend_dev, L->pend_bytes, hipMemcpyDeviceToHost, L->st));
-        if (wipe & 2) TRY(hipMemsetAsync(L->pend_dev, 0, L->pend_bytes, L->st));        /* shared secrets leave HBM with the call */
-        TRY(hipStreamSynchronize(L->st));
+        if (!L->pend_queued) {
+            TRY(hipMemcpyAsync(L->pend_via ? L->pend_via : (void *)L->pend_dst, L->pend_dev, L->pend_bytes, hipMemcpyDeviceToHost, L->st));
+            if (wipe & 2) TRY(hipMemsetAsync(L->pend_dev, 0, L->pend_bytes, L->st));    /* shared secrets leave HBM with the call */
+            TRY(hipStreamSynchronize(L->st));
+        }
         if (L->pend_via) par_copy(L->pend_dst, L->pend_via, L->pend_bytes);
     }
     /* wipes == NULL: the lane is about to be reused, zero it now; otherwise queue the zeroing (end of the call) */
@@ -430,7 +437,7 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
             if (m > stage) m = stage;
             if (ragged || m > n - lo) m = n - lo;
             /* the lane's previous chunk (k - 3): the two chunks after it keep the GPU busy meanwhile */
-            if ((rc = lane_drain(L, j->wipe, NULL))) goto out;
+            if (k >= PIPE_LANES && (rc = lane_drain(L, j->wipe, NULL))) goto out;    /* (every call leaves the lanes drained) */
             TRACE(1, k);
             for (int i = 0; i < j->n_in; i++) {
                 if ((rc = dev_grow(&L->d_in[i], &L->d_in_cap[i], m * j->in_w[i]))) goto out;
@@ -468,12 +475,18 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
                 L->pend_via = (uint8_t *)L->h_out;
             }
             L->pend_dst = j->out + lo * j->out_w; L->pend_dev = (uint8_t *)L->d_out; L->pend_bytes = m * j->out_w;
+            L->pend_queued = 0;
+            if (k == 0 && m == n) {            /* a call of one chunk has no uploads to hold up: everything in order, one wait */
+                TRY(hipMemcpyAsync(L->pend_via ? L->pend_via : (void *)L->pend_dst, L->pend_dev, L->pend_bytes, hipMemcpyDeviceToHost, L->st));
+                if (j->wipe & WIPE_OUT) TRY(hipMemsetAsync(L->pend_dev, 0, L->pend_bytes, L->st));
+                L->pend_queued = 1;
+            }
             /* secrets do not outlive the call in HBM */
             if (j->wipe & WIPE_IN0) TRY(hipMemsetAsync(L->d_in[0], 0, m * j->in_w[0], L->st));
             lo += m;
             TRACE(4, k);
             if (lo >= n) {                     /* the chunks still in flight, oldest first */
-                for (unsigned t = 1; t <= PIPE_LANES; t++)
+                for (unsigned t = k + 1 < PIPE_LANES ? PIPE_LANES - k : 1; t <= PIPE_LANES; t++)
                     if ((rc = lane_drain(&p->lane[(k + t) % PIPE_LANES], j->wipe, &wipes))) goto out;
                 TRACE(5, k);
             }
@@ -510,7 +523,7 @@ out:
 #define COMBINE_MAX_N 64                     /* items of a call that may be merged */
 #define COMBINE_MAX_BYTES ((size_t)1 << 20)  /* ... and its message bytes */
 #define COMBINE_MAX_BATCH 16384              /* items per combined launch */
-#define COMBINE_GATHER_NS 30000              /* how long a leader elected under contention waits for the callers of the previous batch */
+#define COMBINE_GATHER_NS 80000              /* how long a leader elected under contention waits for the callers of the previous batch */
 
 struct creq { const struct hjob *j; size_t n; int rc, done; struct creq *next; };
 
@@ -518,7 +531,6 @@ void combiner_init(struct combiner *q)
 {
     memset(q, 0, sizeof(*q));
     pthread_mutex_init(&q->lk, NULL);
-    pthread_cond_init(&q->cv, NULL);
 }
 
 void combiner_release(struct combiner *q)
@@ -528,7 +540,6 @@ void combiner_release(struct combiner *q)
     host_free_wiped(&q->h_out, &q->h_out_cap);
     { void *p = q->h_off; size_t c = q->h_off_cap; host_free_wiped(&p, &c); q->h_off = NULL; q->h_off_cap = 0; }
     pthread_mutex_destroy(&q->lk);
-    pthread_cond_destroy(&q->cv);
 }
 
 /* diagnostic: combined launches and the items they carried on the default device since its engine was built */
@@ -602,6 +613,19 @@ static int combiner_run(struct engine *e, struct creq *batch, size_t total)
     return rc;
 }
 
+/* Waiters sleep on the combiner's generation counter, not on a condition variable: when a launch completes, every
+ * caller it carried is woken at once and leaves on its own `done` flag without touching the queue's mutex (with a
+ * condition variable the 64 callers of a launch re-acquired the mutex one after the other, a context switch each,
+ * which cost more than the GPU pass). */
+static void gen_wait(uint32_t *gen, uint32_t seen)
+{
+    (void)syscall(SYS_futex, gen, FUTEX_WAIT_PRIVATE, seen, NULL, NULL, 0);
+}
+static void gen_wake_all(uint32_t *gen)
+{
+    (void)syscall(SYS_futex, gen, FUTEX_WAKE_PRIVATE, INT_MAX, NULL, NULL, 0);
+}
+
 static int combiner_submit(struct engine *e, const struct hjob *j, size_t n)
 {
     struct combiner *q = &e->comb_q;
@@ -610,21 +634,32 @@ static int combiner_submit(struct engine *e, const struct hjob *j, size_t n)
     if (q->tail) q->tail->next = &me; else q->head = &me;
     q->tail = &me;
     q->queued++;
-    while (!me.done) {
-        if (q->leader) { pthread_cond_wait(&q->cv, &q->lk); continue; }
-        q->leader = 1;
-        /* Under contention the callers of the batch that has just finished are about to queue again (they do within
-         * microseconds): give them a moment, or every other launch carries only the half of the callers that happened
-         * to be waiting.  A lone caller (the previous launch carried one call) never waits. */
-        if (q->last_reqs > 1 && q->queued < q->last_reqs) {
-            const int64_t until = now_ns() + COMBINE_GATHER_NS;
-            const unsigned want = q->last_reqs;
+    for (;;) {
+        if (__atomic_load_n(&me.done, __ATOMIC_ACQUIRE)) break;
+        if (q->leader) {
+            const uint32_t seen = __atomic_load_n(&q->gen, __ATOMIC_RELAXED);
             pthread_mutex_unlock(&q->lk);
-            for (;;) {
-                sched_yield();
-                pthread_mutex_lock(&q->lk);
-                if (q->queued >= want || now_ns() >= until) break;
+            gen_wait(&q->gen, seen);                   /* returns at once if a launch completed in between */
+            if (__atomic_load_n(&me.done, __ATOMIC_ACQUIRE)) return me.rc;
+            pthread_mutex_lock(&q->lk);
+            continue;
+        }
+        q->leader = 1;
+        /* Under contention the callers of the launch that has just finished are about to queue again (they do within
+         * microseconds of being woken): give them a moment, or the callers split into two camps that take turns and
+         * every launch carries half of them.  Expected: whoever was already waiting when that launch ended, plus the
+         * calls it carried.  Never long; a lone caller (the previous launch carried one call) never waits. */
+        {
+            const unsigned want = q->waiting_at_end + q->last_reqs;
+            if (q->last_reqs > 1 && q->queued < want) {
+                const int64_t until = now_ns() + COMBINE_GATHER_NS;
                 pthread_mutex_unlock(&q->lk);
+                for (;;) {
+                    sched_yield();
+                    pthread_mutex_lock(&q->lk);
+                    if (q->queued >= want || now_ns() >= until) break;
+                    pthread_mutex_unlock(&q->lk);
+                }
             }
         }
         /* everything queued for the operation of the OLDEST request (so that no operation starves); this thread's own
@@ -652,9 +687,18 @@ static int combiner_submit(struct engine *e, const struct hjob *j, size_t n)
         pthread_mutex_lock(&q->lk);
         q->batches++; q->items += reqs;
         q->last_reqs = (unsigned)reqs;
-        for (struct creq *r = batch; r;) { struct creq *nx = r->next; r->rc = rc; r->done = 1; r = nx; }
+        q->waiting_at_end = q->queued;
+        for (struct creq *r = batch; r;) {             /* a caller may return (and its request vanish) the moment `done` is set */
+            struct creq *nx = r->next;
+            r->rc = rc;
+            __atomic_store_n(&r->done, 1, __ATOMIC_RELEASE);
+            r = nx;
+        }
         q->leader = 0;
-        pthread_cond_broadcast(&q->cv);
+        __atomic_add_fetch(&q->gen, 1, __ATOMIC_RELEASE);
+        pthread_mutex_unlock(&q->lk);
+        gen_wake_all(&q->gen);
+        pthread_mutex_lock(&q->lk);
     }
     pthread_mutex_unlock(&q->lk);
     return me.rc;
