@@ -104,12 +104,18 @@ def test_bench_spawns_its_own_ranks_for_config4(engine, golden):
     assert d["config"]["total_items"] == 1 << 24 and d["config"]["items_per_gpu"] == 1 << 23
     assert d["verdicts"]["verdicts_sha512"] == v["verdicts_sha512"] and d["verdicts"]["accepted"] == v["accepted"]
     assert d["verdicts"]["matches_reference_digest"] is True
+    # a line at N > 1 carries the CPU baseline (rank 0 timed it while rank 1 slept in a host barrier)
+    # and a per-rank breakdown that lets a scaling point be attributed
+    assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["gpu_matches_cpu_on_sample"] is True
+    pr = d["per_rank"]
+    assert [r["rank"] for r in pr["ranks"]] == [0, 1] and pr["slowest_rank"] in (0, 1)
+    assert all(r["kernel_ms"] > 0 and r["gather_ms"] >= 0 and r["wall_ms_per_step"] >= r["kernel_ms"] * 0.5 for r in pr["ranks"])
 
 
 def test_bench_default_line_carries_the_whole_metric(engine, golden):
     """`python bench.py` at N = 1: config 2 verifies as `value`, x25519 and sign under `secondary`, each with
     its own roofline fraction and CPU baseline, the verdict digest equal to the reference's"""
-    d = _bench(["--steps", "2", "--warmup", "1", "--cpu-sample", "4096"])
+    d = _bench(["--steps", "2", "--warmup", "1", "--cpu-sample", "4096", "--sustained", "2"])
     assert d["n_gpus"] == 1 and d["outputs_correct"] is True and d["metric"] == "ed25519 verifies/sec"
     assert d["verdicts"]["verdicts_sha512"] == golden("batch_digests.json")["verify_2^20"]["verdicts_sha512"]
     assert d["verdicts"]["matches_reference_digest"] is True
@@ -119,6 +125,8 @@ def test_bench_default_line_carries_the_whole_metric(engine, golden):
         assert 0 < s["roofline"]["frac"] < 1.5 and s["cpu_baseline"]["gpu_matches_cpu_on_sample"]
     v = d["secondary"]["verify_rlc_all_valid"]
     assert v["outputs_correct"] is True and v["stats"][0] == 1 << 20 and v["value"] > d["value"]
+    su = d["secondary"]["verify_sustained"]                 # burst and steady state side by side
+    assert su["outputs_correct"] is True and su["seconds"] >= 2 and 0.5 < su["sustained_over_burst"] < 1.3
     r = d["roofline"]
     assert 0 < r["whole_pass"]["frac"] <= r["frac"] * 1.2 and "source" in r["valu_busy"] and "source" in r["traffic"]
 
