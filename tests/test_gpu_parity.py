@@ -497,5 +497,8 @@ def test_bench_two_ranks_on_one_gpu(engine):
     d = _bench_line(["--gpus", "2", "--steps", "2", "--warmup", "1", "--log2n", "14"],
                     {"EDDSA_BENCH_SHARE_GPU": "1", "EDDSA_BENCH_BACKEND": "gloo"}, launcher=2)
     assert d["n_gpus"] == 2 and d["outputs_correct"] is True and d["scaling"] == "weak"
-    assert d["config"]["parallelism"] == "shard2+allgather" and d["cpu_baseline"] is None
-    assert d["value"] > 0
+    assert d["config"]["parallelism"] == "shard2+allgather"
+    assert d["cpu_baseline"]["gpu_matches_cpu_on_sample"] is True       # rank 0 times it; the other rank sleeps in a host barrier
+    assert d["value"] > 0 and len(d["per_rank"]["ranks"]) == 2
+    for op in ("x25519", "sign"):
+        assert len(d["secondary"][op]["per_rank"]["ranks"]) == 2 and d["secondary"][op]["cpu_baseline"] is not None
