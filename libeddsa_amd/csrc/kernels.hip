@@ -207,10 +207,10 @@ k_verify_exact(uint8_t* ok, edk_verify_src src, const uint32_t* offlist, const u
 
 // The fast route of the exact path, for the first QUAD_MAX_ITEMS entries of the work list (the rest, if any:
 // k_verify_exact above, strided, after the main kernel): four lanes per item (quad_lanes.h), so that a chain
-// step is a squaring and a multiplication deep.  Both halves -- the set-up (joint sparse form of the two
-// scalars and the addends Q, B, Q+B, Q-B, all from what k_verify_prepare left in the workspace) and the
-// chain -- run on the side stream beside k_verify_main, which is launched with MAIN_LDS_RESERVE and therefore
-// leaves wave slots and registers free on every CU.
+// step is a squaring and a multiplication deep.  Set-up (joint sparse form of the two scalars and the addends
+// Q, B, Q+B, Q-B, all from what k_verify_prepare left in the workspace) and chain are one kernel,
+// k_verify_exact_quad, on the side stream beside k_verify_main, which is launched with MAIN_LDS_RESERVE and
+// therefore leaves wave slots, registers and a little LDS free on every CU.
 // Why this shape (tools/exact_path_time.py, tools/exact_trace.py timelines, profiles/r02_verify_ab.txt):
 // k_verify_main's grid for 2^20 items is an exact number of rounds of resident blocks, so it has no slack:
 // whatever holds up ONE of its blocks -- a displaced tile (round 1: chain blocks of four waves at 149 VGPRs
@@ -221,30 +221,37 @@ k_verify_exact(uint8_t* ok, edk_verify_src src, const uint32_t* offlist, const u
 // round 1, 0.4 ms now.
 constexpr int QUAD_MAX_ITEMS = 65536;
 constexpr int QUAD_BLOCK = 256;                  // k_verify_main_quad
-constexpr int QUAD_CHAIN_BLOCK = 64;             // k_verify_exact_chain_quad: one wave = 16 items
+constexpr int QUAD_CHAIN_BLOCK = 64;             // k_verify_exact_quad: one wave, up to 16 items
+constexpr int QUAD_SPREAD_MAX = 2048;            // work lists up to here are spread over the chip, one or two items per wave
+constexpr int QUAD_SPREAD_WAVES = 1024;
 static_assert((size_t)QUAD_MAX_ITEMS * QUAD_ITEM_WORDS * 4 <= EDK_EXACT_PAD_BYTES, "scratchpad too small");
 
-__global__ void __launch_bounds__(EXACT_BLOCK, 4)
-k_verify_exact_setup_quad(const uint32_t* digits, const uint32_t* table, const uint32_t* offlist,
-                          const uint32_t* offcount, const uint32_t* base16, uint32_t* pad) {
-  const size_t g = (size_t)blockIdx.x * EXACT_BLOCK + threadIdx.x;
-  if (g >= *offcount || g >= (size_t)QUAD_MAX_ITEMS) return;
-  const size_t i = offlist[g];
-  verify_exact_setup_quad_lane(digits + 16 * i, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
-                               base16 + TABLE_ENTRY_WORDS, pad + g * QUAD_ITEM_WORDS);
-}
-
+// Set-up and chain in ONE kernel (round 2 had two, 0.75 ms each however few the items: a pass of 2^14 items with one
+// off-curve key took 1.03 ms instead of 0.39).  A wave carries up to 16 items when the list is long - beside a full
+// k_verify_main_half that is what costs it least - and one or two when it is short (a small or mid-size pass waits
+// for this kernel: spread out, every item has a SIMD's issue slots to itself and steps without digits skip their
+// addition, quad_lanes.h).  The digit pairs live in LDS (33 words per item), the addends in the HBM scratchpad.
 __global__ void __launch_bounds__(QUAD_CHAIN_BLOCK, 2)
-k_verify_exact_chain_quad(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const uint32_t* offlist,
-                          const uint32_t* offcount, const uint32_t* pad) {
+k_verify_exact_quad(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const uint32_t* digits, const uint32_t* table,
+                    const uint32_t* offlist, const uint32_t* offcount, const uint32_t* base16, uint32_t* pad) {
+  __shared__ uint32_t lds_dig[(QUAD_CHAIN_BLOCK / 4) * QUAD_DIGIT_WORDS];
   __builtin_amdgcn_s_setprio(3);                 // small passes wait for the chain: 1-3 % there; no difference beside a full k_verify_main
-  const size_t g = ((size_t)blockIdx.x * QUAD_CHAIN_BLOCK + threadIdx.x) >> 2;   // quads are all-or-nothing
-  if (g >= *offcount || g >= (size_t)QUAD_MAX_ITEMS) return;
+  const size_t listed = *offcount;
+  const size_t count = listed < (size_t)QUAD_MAX_ITEMS ? listed : (size_t)QUAD_MAX_ITEMS;
+  const size_t per = count <= (size_t)QUAD_SPREAD_MAX ? (count + QUAD_SPREAD_WAVES - 1) / QUAD_SPREAD_WAVES : QUAD_CHAIN_BLOCK / 4;
+  const size_t quad = threadIdx.x >> 2;          // quads are all-or-nothing
+  const size_t g = (size_t)blockIdx.x * per + quad;
+  if (quad >= per || g >= count) return;
+  const int q = (int)(threadIdx.x & 3u);
   const size_t i = offlist[g];
+  uint32_t* item = pad + g * QUAD_ITEM_WORDS;
+  uint32_t* dig = lds_dig + quad * QUAD_DIGIT_WORDS;
+  verify_exact_setup_quad(digits + 16 * i, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16 + TABLE_ENTRY_WORDS, item, dig, q);
+  __syncthreads();                               // one wave: orders the quad's stores (LDS digits, HBM addends) before the other lanes' loads
   uint32_t rw[8];
   load32(rw, sigs, i, sig_stride);
-  const bool same = verify_exact_chain_quad(rw, pad + g * QUAD_ITEM_WORDS, (int)(threadIdx.x & 3u));
-  if ((threadIdx.x & 3u) == 1u) ok[i] = (uint8_t)same;
+  const bool same = verify_exact_chain_quad(rw, item, dig, q);
+  if (q == 1) ok[i] = (uint8_t)same;
 }
 
 __global__ void __launch_bounds__(BLOCK, 4)
@@ -334,7 +341,7 @@ constexpr int FINISH_K = 8;
 // waves) per CU.  Measured (profiles/r02_verify_ab.txt): the kernel itself is about 1 % FASTER that way (two
 // waves per SIMD already saturate VALU issue; fewer resident tables), and the exact path's waves fit beside
 // it on every CU without taking the place of any of its blocks.
-constexpr unsigned MAIN_LDS_RESERVE = 78 * 1024;
+constexpr unsigned MAIN_LDS_RESERVE = 74 * 1024;   // (2 x 74 of the CU's 160 KB: a third block does not fit, four waves of k_verify_exact_quad do)
 
 struct finish_pos {
   size_t tile, i;            // tile index and global item index of slot k for this lane
@@ -854,12 +861,9 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
     const size_t qi = n < fast_items ? n : fast_items;
     (void)hipEventRecord(ws->ev_prepared, stream);
     (void)hipStreamWaitEvent(ws->side, ws->ev_prepared, 0);
-    hipLaunchKernelGGL(k_verify_exact_setup_quad, dim3((unsigned)((qi + EXACT_BLOCK - 1) / EXACT_BLOCK)),
-                       dim3(EXACT_BLOCK), 0, ws->side, ws->digits, ws->table, ws->offlist, ws->offcount, base16,
-                       ws->exact_pad);
-    hipLaunchKernelGGL(k_verify_exact_chain_quad, dim3((unsigned)((4 * qi + QUAD_CHAIN_BLOCK - 1) / QUAD_CHAIN_BLOCK)),
-                       dim3(QUAD_CHAIN_BLOCK), 0, ws->side, ok, src.sigs, src.sig_stride, ws->offlist, ws->offcount,
-                       ws->exact_pad);
+    const size_t dense = (qi + QUAD_CHAIN_BLOCK / 4 - 1) / (QUAD_CHAIN_BLOCK / 4), spread = qi < (size_t)QUAD_SPREAD_WAVES ? qi : (size_t)QUAD_SPREAD_WAVES;
+    hipLaunchKernelGGL(k_verify_exact_quad, dim3((unsigned)(dense > spread ? dense : spread)), dim3(QUAD_CHAIN_BLOCK), 0, ws->side, ok,
+                       src.sigs, src.sig_stride, ws->digits, ws->table, ws->offlist, ws->offcount, base16, ws->exact_pad);
     (void)hipEventRecord(ws->ev_exact, ws->side);
   }
   if (half_quad) {

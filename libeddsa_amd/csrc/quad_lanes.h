@@ -35,8 +35,8 @@ namespace ed {
 
 #define QUAD_VALUE_WORDS 12                            /* 10 limbs + 2 padding words: three 16-byte loads */
 #define QUAD_ADDEND_WORDS (5 * QUAD_VALUE_WORDS)       /* y-x | y+x | 2d*t | -2d*t | 2z */
-#define QUAD_DIGIT_BYTES 264                           /* REF_JSF_LEN rounded up to 8 */
-#define QUAD_ITEM_WORDS (4 * QUAD_ADDEND_WORDS + 2 * QUAD_DIGIT_BYTES / 4)   /* Q, B, Q+B, Q-B, ux, uy */
+#define QUAD_ITEM_WORDS (4 * QUAD_ADDEND_WORDS)        /* the scratchpad of an item (HBM): Q, B, Q+B, Q-B */
+#define QUAD_DIGIT_WORDS 33                            /* the digit pairs of an item (LDS): REF_JSF_LEN nibbles, eight per word */
 
 // ---- set-up: one lane per item -------------------------------------------------------------------
 
@@ -65,36 +65,65 @@ ED_DEV void quad_addend_store(uint32_t* dst, const ge& p) {
   fe_add(t, p.Z, p.Z); fe_carry(t); quad_value_store(dst + 4 * QUAD_VALUE_WORDS, t);
 }
 
-// The loop invariants of ed.c:455-478 from what k_verify_prepare left in the workspace (the digit
-// words and entry 1 of the item's table), as lanes.h: verify_exact_setup_reuse_lane, laid out for
-// the quad chain: four addends x five factors, then the two digit strings.
-ED_DEV void verify_exact_setup_quad_lane(const uint32_t* digits, const uint32_t* tab, const uint32_t* base1,
-                                         uint32_t* item) {
-  uint32_t tw[8], sw[8];
+// The loop invariants of ed.c:455-478 from what k_verify_prepare left in the workspace (the digit words and entry 1
+// of the item's table), as lanes.h: verify_exact_setup_reuse_lane, shared out over the item's quad so that set-up and
+// chain are ONE kernel and one latency (round 2 ran a one-lane set-up kernel before the chain: 0.75 + 0.75 ms, with
+// 84 spilled registers and a digit string written to memory byte by byte):
+//   lane 0   the joint sparse form of (S, t) (sc.c:297-324, limb boundaries included), one nibble per step -
+//            (u0 + 1) | (u1 + 1) << 2 - eight steps per word of `dig` (LDS, QUAD_DIGIT_WORDS words)
+//   lane 1   the addends Q = -A (every coordinate doubled, see lanes.h) and B
+//   lane 2   Q + B            lane 3   Q - B        (ed.c:473-476), five factors each, at `item` (HBM)
+// The branches run one after the other (a wave executes them under partial masks): about 12 k instructions against the
+// chain's 300 k.
+ED_DEV void verify_exact_setup_quad(const uint32_t* digits, const uint32_t* tab, const uint32_t* base1, uint32_t* item,
+                                    uint32_t* dig, int q) {
+  if (q == 0) {
+    uint32_t tw[8], sw[8];
 #pragma unroll
-  for (int k = 0; k < 8; k++) { tw[k] = digits[k]; sw[k] = digits[8 + k]; }
-  words_sub_pattern(tw, 0x88888888u);
-  words_sub_pattern(sw, 0x80008000u);
-  int8_t* ux = reinterpret_cast<int8_t*>(item + 4 * QUAD_ADDEND_WORDS);
-  int8_t* uy = ux + QUAD_DIGIT_BYTES;
-  const int n = ref_jsf_strided(ux, uy, 1, sw, tw);
-  for (int i = n + 1; i < QUAD_DIGIT_BYTES; i++) { ux[i] = 0; uy[i] = 0; }
-  ge_cached c1;
-  cached_load(c1, tab, 1);
-  ge q, p;                                       // Q = -A with every coordinate doubled
-  fe_sub(q.X, c1.ypx, c1.ymx); fe_carry(q.X);
-  fe_add(q.Y, c1.ypx, c1.ymx); fe_carry(q.Y);
-  q.Z = c1.z2;
-  fe_mul(q.T, c1.t2d, fe_const_inv_d());
-  ge_niels pcB;
-  niels_load(pcB, base1);
-  quad_addend_store(item, q);
-  ge_base(p);
-  quad_addend_store(item + QUAD_ADDEND_WORDS, p);
-  ref_add_pc(p, q, pcB, false);
-  quad_addend_store(item + 2 * QUAD_ADDEND_WORDS, p);   // Q + B
-  ref_add_pc(p, q, pcB, true);
-  quad_addend_store(item + 3 * QUAD_ADDEND_WORDS, p);   // Q - B
+    for (int k = 0; k < 8; k++) { tw[k] = digits[k]; sw[k] = digits[8 + k]; }
+    words_sub_pattern(tw, 0x88888888u);
+    words_sub_pattern(sw, 0x80008000u);
+    int64_t n0 = 0, n1 = 0;
+    uint32_t word = 0;
+    int k = 0;
+#pragma unroll 1
+    for (int i = 0; i < 5; i++) {
+      n0 += (int64_t)ref_limb52(sw, i);
+      n1 += (int64_t)ref_limb52(tw, i);
+#pragma unroll 1
+      for (int j = 0; j < 52; j++, k++) {
+        const int d0 = ref_jsf_digit((uint64_t)n0, (uint64_t)n1), d1 = ref_jsf_digit((uint64_t)n1, (uint64_t)n0);
+        n0 = (n0 - d0) >> 1;
+        n1 = (n1 - d1) >> 1;
+        word |= (uint32_t)((d0 + 1) | ((d1 + 1) << 2)) << (4 * (k & 7));
+        if ((k & 7) == 7) { dig[k >> 3] = word; word = 0; }
+      }
+    }
+    {                                            // step 260 (sc.c:319-320), then "no digit" up to the end of the word
+      const int d0 = ref_jsf_digit((uint64_t)n0, (uint64_t)n1), d1 = ref_jsf_digit((uint64_t)n1, (uint64_t)n0);
+      word |= (uint32_t)((d0 + 1) | ((d1 + 1) << 2)) << (4 * (k & 7));
+      for (int z = (k & 7) + 1; z < 8; z++) word |= 5u << (4 * z);
+      dig[k >> 3] = word;
+    }
+  } else {
+    ge_cached c1;
+    cached_load(c1, tab, 1);
+    ge qp, p;                                    // Q = -A with every coordinate doubled
+    fe_sub(qp.X, c1.ypx, c1.ymx); fe_carry(qp.X);
+    fe_add(qp.Y, c1.ypx, c1.ymx); fe_carry(qp.Y);
+    qp.Z = c1.z2;
+    fe_mul(qp.T, c1.t2d, fe_const_inv_d());
+    if (q == 1) {
+      quad_addend_store(item, qp);
+      ge_base(p);
+      quad_addend_store(item + QUAD_ADDEND_WORDS, p);
+    } else {
+      ge_niels pcB;
+      niels_load(pcB, base1);
+      ref_add_pc(p, qp, pcB, q == 3);            // Q + B / Q - B
+      quad_addend_store(item + (q == 2 ? 2 : 3) * QUAD_ADDEND_WORDS, p);
+    }
+  }
 }
 
 // ---- the chain: four lanes per item ------------------------------------------------------------
@@ -136,27 +165,26 @@ ED_DEV void quad_stage_b(fe& out, const fe& m, int q) {
   fe_mul(out, x, y);
 }
 
-// ed.c:479-506 for one item; `item` = its scratchpad, q = lane & 3.  Returns (in every lane, but
-// lane 1 is the one that holds y) whether the encoding of the result equals R's bytes.
-ED_DEV bool verify_exact_chain_quad(const uint32_t rw[8], const uint32_t* item, int q) {
-  const uint32_t* uxw = item + 4 * QUAD_ADDEND_WORDS;          // digit strings, four steps per word
-  const uint32_t* uyw = uxw + QUAD_DIGIT_BYTES / 4;
+// ed.c:479-506 for one item; `item` = its addends (HBM), `dig` = its digit pairs (LDS), q = lane & 3.  Returns (in
+// every lane, but lane 1 is the one that holds y) whether the encoding of the result equals R's bytes.
+// A step whose digit pair is (0, 0) in EVERY item of the wave skips the addition altogether (the select would discard
+// it anyway): in a small pass, where a wave carries one or two items, that is half the additions.
+ED_DEV bool verify_exact_chain_quad(const uint32_t rw[8], const uint32_t* item, const uint32_t* dig, int q) {
   fe r, k;
   fe_set(r, (uint32_t)(q & 1));                  // neutral element (0, 1, 0, 1) as (X, Y, T, Z)
   fe_set(k, 1);                                  // the doubling's constants (1, 1, 2d, 2)
   { fe two; fe_set(two, 2); fe_cmov(k, fe_const_2d(), q == 2); fe_cmov(k, two, q == 3); }
-  // Two dependent loads stand before every step (digits, then the factor they select); both are
-  // issued ahead -- the factor one step, the digits one word = four steps -- so that their latency
-  // (microseconds beside k_verify_main's table traffic) hides behind the current step.
+  // The factor a step multiplies by is loaded one step ahead, so that its latency (microseconds beside the main
+  // kernel's table traffic) hides behind the current step.
   int i = REF_JSF_LEN - 1;
-  uint32_t wx = uxw[i >> 2], wy = uyw[i >> 2];   // word holding step i
-  uint32_t nx = uxw[(i >> 2) - 1], ny = uyw[(i >> 2) - 1];
+  uint32_t w = dig[i >> 3];                      // word holding step i
   fe mult_next;
   bool skip_next;
-  // decode step j from the current words and start the load of its factor
+  // decode step j from the current word and start the load of its factor
 #define QUAD_PREPARE_STEP(j)                                                                        \
   {                                                                                                 \
-    const int da = (int)(int8_t)(wx >> (8 * ((j) & 3))), db = (int)(int8_t)(wy >> (8 * ((j) & 3))); \
+    const uint32_t nib = (w >> (4 * ((j) & 7))) & 15u;                                              \
+    const int da = (int)(nib & 3u) - 1, db = (int)(nib >> 2) - 1;                                   \
     const bool both = (da != 0) && (db != 0);                                                       \
     skip_next = (da == 0) && (db == 0);                                                             \
     /* which addend: 2 = Q+B (digits equal), 3 = Q-B (digits opposite), 1 = B, 0 = Q; negated? */   \
@@ -172,17 +200,16 @@ ED_DEV bool verify_exact_chain_quad(const uint32_t rw[8], const uint32_t* item, 
     const bool skip = skip_next;
     if (i > 0) {
       const int j = i - 1;
-      if ((j & 3) == 3) {                        // step j starts the next word (wave-uniform)
-        wx = nx; wy = ny;
-        if (j >= 4) { nx = uxw[(j >> 2) - 1]; ny = uyw[(j >> 2) - 1]; }
-      }
+      if ((j & 7) == 7) w = dig[j >> 3];         // step j starts the next word (wave-uniform)
       QUAD_PREPARE_STEP(j)
     }
     fe first, m, sum;
-    quad_stage_a_operand(first, r, q);
-    fe_mul(m, first, mult);
-    quad_stage_b(sum, m, q);
-    fe_cmov(r, sum, !skip);
+    if (__any(!skip)) {                          // wave-uniform
+      quad_stage_a_operand(first, r, q);
+      fe_mul(m, first, mult);
+      quad_stage_b(sum, m, q);
+      fe_cmov(r, sum, !skip);
+    }
     if (i == 0) break;
     quad_stage_a_operand(first, r, q);
     fe_sq(m, first);
@@ -197,13 +224,13 @@ ED_DEV bool verify_exact_chain_quad(const uint32_t rw[8], const uint32_t* item, 
   fe_quad_perm<3, 3, 3, 3>(z, r);
   fe_inv(zi, z);
   fe_mul(aff, r, zi);
-  uint32_t w[8];
-  fe_tobytes(w, aff);
-  const uint32_t xpar = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[0], 0, 0xf, 0xf, false) & 1u;
-  w[7] |= xpar << 31;
+  uint32_t wd[8];
+  fe_tobytes(wd, aff);
+  const uint32_t xpar = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wd[0], 0, 0xf, 0xf, false) & 1u;
+  wd[7] |= xpar << 31;
   uint32_t diff = 0;
 #pragma unroll
-  for (int j = 0; j < 8; j++) diff |= w[j] ^ rw[j];
+  for (int j = 0; j < 8; j++) diff |= wd[j] ^ rw[j];
   return diff == 0;
 }
 
