@@ -222,15 +222,16 @@ k_verify_exact(uint8_t* ok, edk_verify_src src, const uint32_t* offlist, const u
 constexpr int QUAD_MAX_ITEMS = 65536;
 constexpr int QUAD_BLOCK = 256;                  // k_verify_main_quad
 constexpr int QUAD_CHAIN_BLOCK = 64;             // k_verify_exact_quad: one wave, up to 16 items
-constexpr int QUAD_SPREAD_MAX = 2048;            // work lists up to here are spread over the chip, one or two items per wave
-constexpr int QUAD_SPREAD_WAVES = 1024;
+constexpr int QUAD_SPREAD_WAVES = 256;           // a short work list is spread over this many waves, a long one packed 16 items to the wave
 static_assert((size_t)QUAD_MAX_ITEMS * QUAD_ITEM_WORDS * 4 <= EDK_EXACT_PAD_BYTES, "scratchpad too small");
 
-// Set-up and chain in ONE kernel (round 2 had two, 0.75 ms each however few the items: a pass of 2^14 items with one
-// off-curve key took 1.03 ms instead of 0.39).  A wave carries up to 16 items when the list is long - beside a full
-// k_verify_main_half that is what costs it least - and one or two when it is short (a small or mid-size pass waits
-// for this kernel: spread out, every item has a SIMD's issue slots to itself and steps without digits skip their
-// addition, quad_lanes.h).  The digit pairs live in LDS (33 words per item), the addends in the HBM scratchpad.
+// Set-up and chain in ONE kernel (round 2 had two, 0.37-0.75 + 0.75 ms however few the items: a pass of 2^14 items
+// with a handful of off-curve keys took 1.02 ms instead of 0.39; now 0.79).  A wave carries 16 items when the list is
+// long - beside a full k_verify_main_half that is what costs it least - and as few as one when it is short (up to
+// QUAD_SPREAD_WAVES waves: a small pass waits for this kernel, and a wave with one item skips the addition of every step
+// without digits, quad_lanes.h; spreading 540 items of a 2^16-item pass one to the wave was measured slower than 34
+// full waves - 1.28 against 1.18 ms - their instructions are taken from the main kernel's waves).  The digit pairs
+// live in LDS (33 words per item), the addends in the HBM scratchpad.
 __global__ void __launch_bounds__(QUAD_CHAIN_BLOCK, 2)
 k_verify_exact_quad(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const uint32_t* digits, const uint32_t* table,
                     const uint32_t* offlist, const uint32_t* offcount, const uint32_t* base16, uint32_t* pad) {
@@ -238,7 +239,8 @@ k_verify_exact_quad(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const u
   __builtin_amdgcn_s_setprio(3);                 // small passes wait for the chain: 1-3 % there; no difference beside a full k_verify_main
   const size_t listed = *offcount;
   const size_t count = listed < (size_t)QUAD_MAX_ITEMS ? listed : (size_t)QUAD_MAX_ITEMS;
-  const size_t per = count <= (size_t)QUAD_SPREAD_MAX ? (count + QUAD_SPREAD_WAVES - 1) / QUAD_SPREAD_WAVES : QUAD_CHAIN_BLOCK / 4;
+  size_t per = (count + QUAD_SPREAD_WAVES - 1) / QUAD_SPREAD_WAVES;               // items per wave: 1 .. 16
+  per = per > (size_t)(QUAD_CHAIN_BLOCK / 4) ? (size_t)(QUAD_CHAIN_BLOCK / 4) : per;
   const size_t quad = threadIdx.x >> 2;          // quads are all-or-nothing
   const size_t g = (size_t)blockIdx.x * per + quad;
   if (quad >= per || g >= count) return;
