@@ -143,11 +143,12 @@ __global__ void __launch_bounds__(64) k_init_comb_image(uint32_t* img, const uin
 //   k_verify_prepare  hash, scalars -> digit words, decompress -A, table of 0..8 * -A
 //   k_verify_main     the 252 doublings + 80 additions            (~85 % of the time)
 //   k_verify_finish   invert Z (shared by 8 items per lane), encode, compare with R
-//   k_verify_exact    (side stream, beside main) the reference's own chain for the items whose key
-//                     is not a curve point; owns their verdict bytes
+//   k_verify_exact_quad (side stream, beside main; k_verify_exact for lists beyond 65536 entries) the reference's own
+//                     chain for the items whose key is not a curve point; owns their verdict bytes
 // Workspace (HBM; tile = 256 items):
 //   digits [item][16]                  t + 0x88.., S + 0x80.. as little-endian words
-//   table  [item][entry 9][word 40]    1440 contiguous bytes per item
+//   table  [item][entry 9][word 32]    1152 contiguous bytes per item; an entry = ymx | ypx | t2d | z2 packed into 255 bits each
+//                                      (fe_pack), one 128-byte line
 //   acc    [tile][word 30][lane 256]   X, Y, Z of the result
 //   flags  [item]                      bit 0: A decoded to a curve point; bit 1: Z usable (set by finish)
 //   offlist[..], offcount              items whose A is off the curve, for k_verify_exact
@@ -277,7 +278,7 @@ k_verify_main(const uint32_t* digits, const uint32_t* table, const uint32_t* bas
 //   k_verify_main_half  132 doublings + 68 + 16 additions, neutral-element test, verdict byte
 // No finish kernel: "is the neutral element" needs no inversion.  Items the pair search gives up on join the
 // off-curve keys on the exact path's work list (so the list is complete only after k_verify_halve).
-// Workspace beside the one above: hdigits [item][HALF_DIGIT_WORDS], rtable [item][entry 9][word 40];
+// Workspace beside the one above: hdigits [item][HALF_DIGIT_WORDS], rtable [item][entry 9][word 32] (the same packed form);
 // flags bit 0: this path owns the verdict, bit 2: R is a canonical encoding of a curve point.
 // ---------------------------------------------------------------------------------------------
 template <int BITS>

@@ -17,12 +17,22 @@ src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "gpurun_out", "profiles_out")
 os.makedirs(dst, exist_ok=True)
 
+def kernel_name(raw):
+    """'void ed::k_verify_main_half<34>(unsigned char*, ...)' -> 'ed::k_verify_main_half' (the template arguments are the
+    window count / pair bound of the pass size; a 2^20-item pass runs one instantiation)"""
+    import re
+    name = raw.split("(")[0]
+    if name.startswith("void "):
+        name = name[5:]
+    return re.sub(r"<[^>]*>$", "", name)
+
+
 rows = []
 for sub in ("stats_all", "stats", "stats_x25519", "stats_sign", "stats_rlc"):
     for f in glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv")):
         for r in csv.DictReader(open(f)):
-            if r["Name"].startswith("ed::"):
-                r["Name"] = r["Name"].split("(")[0]
+            if kernel_name(r["Name"]).startswith("ed::"):
+                r["Name"] = kernel_name(r["Name"])
                 r["run"] = sub
                 rows.append(r)
 if rows:
@@ -38,7 +48,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc", "pmc_fetch_x25519", 
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         meta = {}
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
+            k = kernel_name(r["Kernel_Name"])
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta[k] = {"VGPR_Count": int(r["VGPR_Count"]), "Accum_VGPR_Count": int(r["Accum_VGPR_Count"]),
                        "SGPR_Count": int(r["SGPR_Count"]), "LDS_Block_Size": int(r["LDS_Block_Size"]),
