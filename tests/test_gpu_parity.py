@@ -409,6 +409,66 @@ def test_threaded_c_application_on_the_single_item_functions(engine, golden, tmp
     assert calls > 4 * launches
 
 
+def test_combined_small_calls_of_many_threads(engine, oracle):
+    """the combiner (host_pipe.c) under a mixed load: 24 Python threads (ctypes releases the GIL) issue host-pointer calls of
+    1..64 items - verify with message lengths that differ from call to call (the combined batch becomes ragged), sign,
+    x25519, genpub - while another thread runs large batches through the same pipeline; every caller gets its own results"""
+    import threading
+    rng = np.random.default_rng(123)
+    N = 4096
+    sk = rng.integers(0, 256, (N, 32), dtype=np.uint8)
+    pk = oracle.genpub_batch(sk)
+    pt = rng.integers(0, 256, (N, 32), dtype=np.uint8)
+    want_x = oracle.x25519_batch(sk, pt)
+    msgs = {L: rng.integers(0, 256, (N, L), dtype=np.uint8) for L in (0, 1, 31, 32, 100, 300)}
+    sigs = {L: oracle.sign_batch(sk, pk, m, L) if L else np.stack([np.frombuffer(oracle.sign(sk[i].tobytes(), pk[i].tobytes(), b""), np.uint8) for i in range(N)]) for L, m in msgs.items()}
+    before = engine.combiner_stats()
+    errors = []
+
+    def small(tid):
+        r = np.random.default_rng(1000 + tid)
+        try:
+            for it in range(40):
+                n = int(r.choice([1, 1, 1, 2, 5, 17, 64]))
+                lo = int(r.integers(0, N - n))
+                L = int(r.choice(list(msgs)))
+                kind = (tid + it) % 4
+                if kind == 0:
+                    bad = sigs[L][lo:lo + n].copy()
+                    flip = r.integers(0, 2, n).astype(bool)
+                    bad[flip, 37] ^= 4
+                    ok = engine.ed25519_verify_batch(bad, pk[lo:lo + n], msgs[L][lo:lo + n], msg_len=L)
+                    assert np.array_equal(ok, (~flip).astype(np.uint8)), ("verify", tid, it)
+                elif kind == 1:
+                    got = engine.ed25519_sign_batch(sk[lo:lo + n], pk[lo:lo + n], msgs[L][lo:lo + n], msg_len=L)
+                    assert np.array_equal(got, sigs[L][lo:lo + n]), ("sign", tid, it)
+                elif kind == 2:
+                    assert np.array_equal(engine.x25519_batch(sk[lo:lo + n], pt[lo:lo + n]), want_x[lo:lo + n]), ("x25519", tid, it)
+                else:
+                    assert np.array_equal(engine.ed25519_genpub_batch(sk[lo:lo + n]), pk[lo:lo + n]), ("genpub", tid, it)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def big():
+        try:
+            for _ in range(6):
+                assert np.array_equal(engine.x25519_batch(sk, pt), want_x)
+                assert bool(engine.ed25519_verify_batch(sigs[32], pk, msgs[32], msg_len=32).all())
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=small, args=(t,)) for t in range(24)] + [threading.Thread(target=big)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    after = engine.combiner_stats()
+    calls, launches = after[1] - before[1], after[0] - before[0]
+    assert calls == 24 * 40 and launches < calls          # some calls did travel together
+    assert engine.secret_residue()[2:] == (0, 0)          # and the packed copies of secret keys / shared secrets are gone
+
+
 def test_concurrent_host_threads(engine, oracle):
     """several host threads issue batched calls at once (host-pointer pipeline and device-pointer
     entry points on different torch streams): calls serialise on the engine's workspaces and every
