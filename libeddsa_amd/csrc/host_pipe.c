@@ -435,7 +435,7 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
             struct lane *L = &p->lane[k % PIPE_LANES];
             size_t m = first << (k < 8 ? k : 8);
             if (m > stage) m = stage;
-            if (ragged || m > n - lo) m = n - lo;
+            if (ragged || m > n - lo || n - lo - m < m / 2) m = n - lo;   /* (a short tail travels with the last chunk) */
             /* the lane's previous chunk (k - 3): the two chunks after it keep the GPU busy meanwhile */
             if (k >= PIPE_LANES && (rc = lane_drain(L, j->wipe, NULL))) goto out;    /* (every call leaves the lanes drained) */
             TRACE(1, k);

