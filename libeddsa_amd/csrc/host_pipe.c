@@ -68,7 +68,7 @@ static void *pool_worker(void *arg)
     pthread_mutex_lock(&g_pool.lk);
     for (;;) {
         while (!g_pool.stop && g_pool.head == g_pool.tail) pthread_cond_wait(&g_pool.work_cv, &g_pool.lk);
-        if (g_pool.stop) break;
+        if (g_pool.head == g_pool.tail) break;   /* stopping, and nothing queued is left undone */
         struct ptask t = g_pool.q[g_pool.head++ % POOL_QUEUE];
         pthread_mutex_unlock(&g_pool.lk);
         ptask_run(&t);
@@ -114,7 +114,7 @@ static size_t pool_submit(int *pending, uint8_t *d, const uint8_t *s, size_t byt
             if (pthread_create(&g_pool.th[g_pool.started], NULL, pool_worker, NULL) != 0) break;
             g_pool.started++;
         }
-        if (g_pool.started > 0) {
+        if (g_pool.started > 0 && !g_pool.stop) {   /* (a pool that is being stopped takes no new work: done here instead) */
             if (slice == 0) {
                 size_t parts = bytes / POOL_MIN_SLICE;
                 if (parts > (size_t)g_pool.started) parts = (size_t)g_pool.started;
