@@ -163,6 +163,17 @@ def step():
 elapsed, out = bench.timed_region(step, 4, world, lambda: None, torch.device("cpu"))
 assert len(calls) == 4                                   # exactly K steps
 assert 0.39 < elapsed < 1.5, elapsed                     # the MAX over ranks (4 x 0.1 s), on every rank
+# the per-rank breakdown and the host-side barrier of the N > 1 line (a second, gloo group beside the RCCL one)
+bench.HOST_GROUP[0] = dist.new_group(backend="gloo")
+pr = bench.per_rank_breakdown(world, rank, 4, 10.0 * (rank + 1), 1.0 + rank)
+assert [r["rank"] for r in pr["ranks"]] == [0, 1] and pr["slowest_rank"] == 1, pr
+assert pr["kernel_ms_min_max"] == [10.0, 20.0] and pr["gather_ms_max"] == 2.0
+assert abs(pr["ranks"][rank]["wall_ms_per_step"] - bench.LOCAL_ELAPSED[0] / 4 * 1e3) < 1e-6
+t0 = time.perf_counter()
+if rank == 0:
+    time.sleep(0.3)                                      # rank 0 "times the CPU baseline"; rank 1 sleeps in the barrier
+bench.host_barrier()
+assert time.perf_counter() - t0 > 0.25
 dist.destroy_process_group()
 open(os.path.join(os.environ["OUT_DIR"], f"rank{rank}.ok"), "w").write("ok")
 '''
