@@ -313,11 +313,19 @@ k_verify_halve(const uint8_t* sigs, size_t sig_stride, size_t n, const uint32_t*
   if ((fl & 1) != 0 && !mine && i < n) offlist[atomicAdd(offcount, 1u)] = (uint32_t)i;
 }
 
+// (A/B builds only: -DMAIN_HALF_BLOCK=128 -DMAIN_HALF_LDS_KB=50 gives three blocks of 128 lanes per CU, 1.5 waves per
+// SIMD, a resident set of 226 MB that fits the 256 MB Infinity Cache: profiles/r03_verify_ab.txt)
+#ifndef MAIN_HALF_BLOCK
+#define MAIN_HALF_BLOCK BLOCK
+#endif
+#ifndef MAIN_HALF_BLOCKS_PER_CU
+#define MAIN_HALF_BLOCKS_PER_CU 2
+#endif
 template <int WINDOWS>
-__global__ void __launch_bounds__(BLOCK, 2)
+__global__ void __launch_bounds__(MAIN_HALF_BLOCK, MAIN_HALF_BLOCKS_PER_CU)
 k_verify_main_half(uint8_t* ok, const uint32_t* hdigits, const uint32_t* table, const uint32_t* rtable,
                    const uint32_t* base16, const uint8_t* flags, size_t n, int exact_offcurve) {
-  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;   // < workspace capacity
+  const size_t i = (size_t)blockIdx.x * MAIN_HALF_BLOCK + threadIdx.x;   // < workspace capacity
   const uint32_t* hd = hdigits + HALF_DIGIT_WORDS * i;
   const bool neutral = verify_half_main_lane<false, WINDOWS>(hd, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
                                              rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16, false);
@@ -874,11 +882,17 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
                        ok, ws->hdigits, ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
     if (marks) { (void)hipEventRecord(marks[2], stream); (void)hipEventRecord(marks[3], stream); }
   } else if (half) {
+#ifdef MAIN_HALF_LDS_KB
+    constexpr unsigned half_lds = MAIN_HALF_LDS_KB * 1024;
+#else
+    constexpr unsigned half_lds = MAIN_LDS_RESERVE;
+#endif
+    const unsigned hblocks = blocks * (BLOCK / MAIN_HALF_BLOCK);
     if (wide)
-      hipLaunchKernelGGL(k_verify_main_half<HALF_WINDOWS_SMALL>, dim3(blocks), dim3(BLOCK), MAIN_LDS_RESERVE, stream, ok, ws->hdigits,
+      hipLaunchKernelGGL(k_verify_main_half<HALF_WINDOWS_SMALL>, dim3(hblocks), dim3(MAIN_HALF_BLOCK), half_lds, stream, ok, ws->hdigits,
                          ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
     else
-      hipLaunchKernelGGL(k_verify_main_half<HALF_WINDOWS>, dim3(blocks), dim3(BLOCK), MAIN_LDS_RESERVE, stream, ok, ws->hdigits,
+      hipLaunchKernelGGL(k_verify_main_half<HALF_WINDOWS>, dim3(hblocks), dim3(MAIN_HALF_BLOCK), half_lds, stream, ok, ws->hdigits,
                          ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
     if (marks) { (void)hipEventRecord(marks[2], stream); (void)hipEventRecord(marks[3], stream); }
   } else {
