@@ -887,7 +887,7 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
 #else
     constexpr unsigned half_lds = MAIN_LDS_RESERVE;
 #endif
-    const unsigned hblocks = blocks * (BLOCK / MAIN_HALF_BLOCK);
+    const unsigned hblocks = (blocks * BLOCK + MAIN_HALF_BLOCK - 1) / MAIN_HALF_BLOCK;
     if (wide)
       hipLaunchKernelGGL(k_verify_main_half<HALF_WINDOWS_SMALL>, dim3(hblocks), dim3(MAIN_HALF_BLOCK), half_lds, stream, ok, ws->hdigits,
                          ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
