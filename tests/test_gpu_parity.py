@@ -409,6 +409,38 @@ def test_threaded_c_application_on_the_single_item_functions(engine, golden, tmp
     assert calls > 4 * launches
 
 
+def test_page_locked_caller_memory_is_used_in_place(engine, oracle):
+    """arrays from eddsa_amd_host_alloc (1 MB and more: the size from which the library asks) are read and written by the
+    DMA engines directly, inputs and outputs alike; smaller ones and ordinary memory are staged: same bytes either way"""
+    import ctypes
+    n = 1 << 16
+    rng = np.random.default_rng(5)
+    sc = rng.integers(0, 256, (n, 32), dtype=np.uint8); pt = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    want = engine.x25519_batch(sc, pt)                             # ordinary memory, staged
+    assert np.array_equal(want[:500], oracle.x25519_batch(sc[:500], pt[:500]))
+    hs, hp, ho = engine.host_array((n, 32)), engine.host_array((n, 32)), engine.host_array((n, 32))
+    hs[...] = sc; hp[...] = pt; ho[...] = 0xEE
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    lib = engine.library()
+    assert lib.x25519_batch(P(ho), P(hs), P(hp), ctypes.c_size_t(n)) == 0          # all three page-locked
+    assert np.array_equal(ho, want)
+    out = np.zeros((n, 32), np.uint8)
+    assert lib.x25519_batch(P(out), P(hs), P(pt), ctypes.c_size_t(n)) == 0         # mixed: one input page-locked, the rest staged
+    assert np.array_equal(out, want)
+    ho[...] = 0
+    assert lib.x25519_batch(P(ho), P(hs), P(hp), ctypes.c_size_t(100)) == 0        # a small call from the same buffers: staged
+    assert np.array_equal(ho[:100], want[:100]) and not ho[100:].any()
+    # verify with a page-locked verdict array
+    sk = rng.integers(0, 256, (n, 32), dtype=np.uint8); msg = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    pk = engine.ed25519_genpub_batch(sk); sig = engine.ed25519_sign_batch(sk, pk, msg); sig[::7, 50] ^= 2
+    hsig, hok = engine.host_array((n, 64)), engine.host_array((1 << 20,))
+    hsig[...] = sig
+    assert lib.ed25519_verify_batch(P(hok), P(hsig), P(pk), P(msg), None, ctypes.c_size_t(32), ctypes.c_size_t(n)) == 0
+    assert np.array_equal(hok[:n], (np.arange(n) % 7 != 0).astype(np.uint8))
+    for a in (hs, hp, ho, hsig, hok):
+        engine.host_free(a)
+
+
 def test_combined_small_calls_of_many_threads(engine, oracle):
     """the combiner (host_pipe.c) under a mixed load: 24 Python threads (ctypes releases the GIL) issue host-pointer calls of
     1..64 items - verify with message lengths that differ from call to call (the combined batch becomes ragged), sign,
