@@ -538,7 +538,7 @@ k_x25519_finish(uint8_t* out, uint32_t* acc, size_t n) {
 // "point" kernel; the matching "finish" kernel encodes (and, for sign, hashes and computes S)
 // ---------------------------------------------------------------------------------------------
 
-constexpr int POINT_BLOCK = COMB_IMG_WORDS * 4 > 80 * 1024 ? 512 : 256;   // 8 waves per CU either way
+constexpr int POINT_BLOCK = COMB_IMG_WORDS * 4 > 80 * 1024 ? 512 : 256;   // 8 waves per CU either way (768 lanes: 6-101 spilled registers, 1024: 94-314)
 
 __global__ void __launch_bounds__(POINT_BLOCK, 512 / POINT_BLOCK)
 k_genpub_point(uint32_t* accout, const uint8_t* secs, size_t n, const uint32_t* comb) {
