@@ -348,7 +348,7 @@ k_verify_main_half(uint8_t* ok, const uint32_t* hdigits, const uint32_t* table, 
 // product) and  item(k, zinv, good): the rest of the work of item k.
 // ---------------------------------------------------------------------------------------------
 constexpr int FINISH_K = 8;
-// k_verify_main uses no LDS; launching it with 78 KB of dynamic LDS per block limits it to two blocks (eight
+// k_verify_main uses no LDS; launching it with 74 KB (78 until round 3) of dynamic LDS per block limits it to two blocks (eight
 // waves) per CU.  Measured (profiles/r02_verify_ab.txt): the kernel itself is about 1 % FASTER that way (two
 // waves per SIMD already saturate VALU issue; fewer resident tables), and the exact path's waves fit beside
 // it on every CU without taking the place of any of its blocks.

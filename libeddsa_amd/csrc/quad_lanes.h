@@ -14,8 +14,8 @@
 //   ed_double (ed.c:211-237): stage A is a squaring of (Y-X, Y+X, T, Z), followed by one fe_mul
 //   with the lane's constant (1, 1, 2d, 2); stage B is the same.
 //
-// The addend's factors (y-x, y+x, 2d*t, -2d*t, 2z) are loop invariants: the set-up kernel stores
-// them per item and a lane loads the one its role and the digit's sign select (negating the addend
+// The addend's factors (y-x, y+x, 2d*t, -2d*t, 2z) are loop invariants: the set-up (the same kernel,
+// verify_exact_setup_quad below) stores them per item and a lane loads the one its role and the digit's sign select (negating the addend
 // swaps y-x with y+x and negates 2d*t: ed_sub, ed.c:245-273).  Every value is a field element and
 // multiplication in GF(p) is associative and commutative, so T*(2d*t) is the reference's (T*t)*2d
 // and Z*(2z) its 2*(Z*z): the accumulator holds the reference's coordinates mod p (up to the common
