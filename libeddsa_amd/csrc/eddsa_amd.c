@@ -220,6 +220,7 @@ static int engine_create(int device)
     pthread_mutex_init(&e->pipe_lk, NULL);
     pthread_cond_init(&e->slot_cv, NULL);
     combiner_init(&e->comb_q);
+    pipe_setup(&e->pipe);
     (void)hipGetDevice(&saved);
     TRY(hipSetDevice(device));
     TRY(hipGetDeviceProperties(&prop, device));

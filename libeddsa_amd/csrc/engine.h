@@ -9,9 +9,9 @@
  *                 (single device and *_multi) and the thirteen eddsa.h functions (batches of one)
  *
  * Locks, always taken in this order:  g_table (rwlock: read for the duration of every call, write to create /
- * destroy engines)  ->  g_rccl_lk (the multi-device device-pointer call)  ->  engine.comb_lk (the combiner's
- * queue; never held while work runs)  ->  engine.pipe_lk (host staging pipeline)  ->  engine.lk (workspace pool,
- * profiling marks).
+ * destroy engines)  ->  g_rccl_lk (the multi-device device-pointer call)  ->  engine.comb_q.lk (the combiner's
+ * queue; never held while work runs)  ->  engine.pipe_lk (hands out the lanes of the host pipeline; never held while
+ * work runs either: a job owns its lanes through their busy marks)  ->  engine.lk (workspace pool, profiling marks).
  */
 #ifndef EDDSA_AMD_ENGINE_H
 #define EDDSA_AMD_ENGINE_H
@@ -67,6 +67,9 @@ struct lane {
     void *h_in[PIPE_MAX_IN]; size_t h_in_cap[PIPE_MAX_IN];     /* pinned host staging */
     void *h_msgs; size_t h_msgs_cap;
     void *h_out; size_t h_out_cap;
+    int busy;                         /* held by a job (under pipe_lk) */
+    void *d_off; size_t d_off_cap;    /* ragged message offsets (calls of one chunk) */
+    void *h_off; size_t h_off_cap;
     /* the chunk in flight on this lane: its results go from pend_dev (HBM) to pend_dst (the caller's memory), through
      * pend_via (pinned staging) unless the caller's memory is page-locked itself, once the lane's kernels are done */
     uint8_t *pend_dst, *pend_via, *pend_dev; size_t pend_bytes;
@@ -76,25 +79,29 @@ struct lane {
 struct pipe {
     int ready;
     struct lane lane[PIPE_LANES];
-    void *d_off; size_t d_off_cap;    /* ragged message offsets (single-chunk calls) */
-    void *h_off; size_t h_off_cap;
+    pthread_cond_t lane_cv;           /* (with engine.pipe_lk) a lane was released */
+    int big_waiting;                  /* calls of several chunks waiting for all lanes: calls of one chunk queue up behind them */
     uint32_t *d_stats;                /* 4 words: statistics of the batch verification */
     uint32_t *h_stats;                /* pinned */
 };
 
-/* the combiner for concurrent small host-pointer calls (host_pipe.c) */
+/* the combiner for concurrent small host-pointer calls (host_pipe.c): one queue, per operation a leader at a time */
 struct creq;
-struct combiner {
-    pthread_mutex_t lk;
-    uint32_t gen;                     /* bumped when a launch completes; waiters sleep on it (futex) */
-    struct creq *head, *tail;
-    int leader;                       /* some thread is packing / running a combined batch */
+#define COMB_KINDS 8                  /* hjob.kind: 1 verify, 2 sign, 3 x25519, 4 genpub, 5 x25519_base, 6 pk->x, 7 sk->x; 0: never combined */
+struct comb_kind {
+    int active;                       /* some thread is packing / running a launch of this operation */
     unsigned queued, last_reqs, waiting_at_end;   /* requests waiting; calls the last launch carried; requests waiting when it ended */
     void *h_in[PIPE_MAX_IN]; size_t h_in_cap[PIPE_MAX_IN];     /* pinned: the packed batch */
     void *h_msgs; size_t h_msgs_cap;
     void *h_out; size_t h_out_cap;
     uint64_t *h_off; size_t h_off_cap;
-    unsigned long batches, items;     /* statistics: combined launches, items they carried */
+};
+struct combiner {
+    pthread_mutex_t lk;
+    uint32_t gen;                     /* bumped when a launch completes; waiters sleep on it (futex) */
+    struct creq *head, *tail;
+    struct comb_kind kind[COMB_KINDS];
+    unsigned long batches, items;     /* statistics: combined launches, calls they carried */
 };
 
 struct engine {
@@ -156,6 +163,7 @@ int sk_to_x_on(struct engine *e, uint8_t *out, const uint8_t *in, size_t n, hipS
 int records_ok(size_t stride, size_t sig_off, size_t pub_off, size_t msg_off, size_t msg_len);
 
 /* host_pipe.c, called by the engine's life cycle and diagnostics in eddsa_amd.c */
+void pipe_setup(struct pipe *p);                   /* once per engine */
 void pipe_release(struct pipe *p);                 /* device current, no call in flight */
 void combiner_init(struct combiner *q);
 void combiner_release(struct combiner *q);

@@ -236,7 +236,7 @@ struct hjob {
     uint32_t *stats;                           /* rlc: host copy of the pass statistics (4 words) or NULL */
     size_t first_chunk;                        /* items of the first chunk (0: PIPE_FIRST_CHUNK); later ones double up to `chunk` */
     int chain;                                 /* the kernels of consecutive chunks run in chunk order (else side by side) */
-    int combinable;                            /* small calls of this job may be merged with other threads' (same `run`) */
+    int kind;                                  /* combiner slot (engine.h: COMB_KINDS): small calls of this operation may be merged; 0: never */
     int src_pinned;                            /* every host array of the job is page-locked: no staging */
 };
 
@@ -283,26 +283,70 @@ out:
     return rc;
 }
 
+void pipe_setup(struct pipe *p)
+{
+    pthread_cond_init(&p->lane_cv, NULL);
+}
+
 void pipe_release(struct pipe *p)
 {
+    pthread_cond_destroy(&p->lane_cv);
     for (int l = 0; l < PIPE_LANES; l++) {
         struct lane *L = &p->lane[l];
         for (int i = 0; i < PIPE_MAX_IN; i++) { wipe_free(L->d_in[i], L->d_in_cap[i]); host_free_wiped(&L->h_in[i], &L->h_in_cap[i]); }
         wipe_free(L->d_msgs, 0); host_free_wiped(&L->h_msgs, &L->h_msgs_cap);
         wipe_free(L->d_out, L->d_out_cap); host_free_wiped(&L->h_out, &L->h_out_cap);
+        wipe_free(L->d_off, 0); host_free_wiped(&L->h_off, &L->h_off_cap);
         if (L->st) (void)hipStreamDestroy(L->st);
         if (L->kdone) (void)hipEventDestroy(L->kdone);
     }
-    wipe_free(p->d_off, 0); host_free_wiped(&p->h_off, &p->h_off_cap);
     if (p->d_stats) (void)hipFree(p->d_stats);
     if (p->h_stats) (void)hipHostFree(p->h_stats);
     memset(p, 0, sizeof(*p));
 }
 
+/* Lanes are handed out under pipe_lk and owned through their busy marks, so that the lock is never held while work
+ * runs: a call of ONE chunk takes any free lane - three such calls (the combined launches of three operations, say)
+ * are in flight side by side -, a call of several chunks takes all three; while one of those waits, no new one-chunk
+ * call starts.  Returns the first lane of the job (0 when it has them all), or a negative error. */
+static int lanes_acquire(struct engine *e, int all)
+{
+    struct pipe *p = &e->pipe;
+    int got = -1;
+    pthread_mutex_lock(&e->pipe_lk);
+    int rc = pipe_init(p);
+    if (rc) { pthread_mutex_unlock(&e->pipe_lk); return rc; }
+    if (all) {
+        p->big_waiting++;
+        while (p->lane[0].busy || p->lane[1].busy || p->lane[2].busy) pthread_cond_wait(&p->lane_cv, &e->pipe_lk);
+        p->big_waiting--;
+        for (int l = 0; l < PIPE_LANES; l++) p->lane[l].busy = 1;
+        got = 0;
+    } else {
+        for (;;) {
+            for (int l = 0; l < PIPE_LANES && got < 0 && !p->big_waiting; l++) if (!p->lane[l].busy) got = l;
+            if (got >= 0) break;
+            pthread_cond_wait(&p->lane_cv, &e->pipe_lk);
+        }
+        p->lane[got].busy = 1;
+    }
+    pthread_mutex_unlock(&e->pipe_lk);
+    return got;
+}
+
+static void lanes_release(struct engine *e, int all, int first)
+{
+    pthread_mutex_lock(&e->pipe_lk);
+    for (int l = 0; l < PIPE_LANES; l++) if (all || l == first) e->pipe.lane[l].busy = 0;
+    pthread_cond_broadcast(&e->pipe.lane_cv);
+    pthread_mutex_unlock(&e->pipe_lk);
+}
+
 int pipe_residue(struct engine *e, uint64_t *in0, uint64_t *out)
 {
-    int rc = 0;
-    pthread_mutex_lock(&e->pipe_lk);
+    int rc = lanes_acquire(e, 1);                  /* no job in flight while the buffers are read */
+    if (rc < 0) return rc;
+    rc = 0;
     for (int l = 0; l < PIPE_LANES && !rc; l++) {
         const struct lane *L = &e->pipe.lane[l];
         rc = count_nonzero_dev(L->d_in[0], L->d_in_cap[0], in0);
@@ -310,9 +354,12 @@ int pipe_residue(struct engine *e, uint64_t *in0, uint64_t *out)
         for (size_t k = 0; L->h_in[0] && k < L->h_in_cap[0]; k++) *in0 += ((const uint8_t *)L->h_in[0])[k] != 0;
         for (size_t k = 0; L->h_out && k < L->h_out_cap; k++) *out += ((const uint8_t *)L->h_out)[k] != 0;
     }
-    pthread_mutex_unlock(&e->pipe_lk);
+    lanes_release(e, 1, 0);
     pthread_mutex_lock(&e->comb_q.lk);
-    for (size_t k = 0; e->comb_q.h_in[0] && k < e->comb_q.h_in_cap[0]; k++) *in0 += ((const uint8_t *)e->comb_q.h_in[0])[k] != 0;
+    for (int c = 0; c < COMB_KINDS; c++) {
+        const struct comb_kind *K = &e->comb_q.kind[c];
+        for (size_t k = 0; K->h_in[0] && k < K->h_in_cap[0]; k++) *in0 += ((const uint8_t *)K->h_in[0])[k] != 0;
+    }
     pthread_mutex_unlock(&e->comb_q.lk);
     return rc;
 }
@@ -410,17 +457,19 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
     struct pipe *p = &e->pipe;
     int staged_in[PIPE_MAX_IN] = { 0 }, staged_msgs = 0, staged_out = 0;
     if (n == 0) return 0;
-    pthread_mutex_lock(&e->pipe_lk);
+    const int ragged = j->has_msgs && j->msg_off != NULL;
+    const int tunable = j->stats == NULL;                       /* (a combination covers a fixed number of items) */
+    const size_t stage = tunable && g_pipe_stage ? g_pipe_stage : j->chunk ? j->chunk : PIPE_CHUNK;
+    const size_t first = tunable && g_pipe_first ? g_pipe_first : j->first_chunk ? j->first_chunk : PIPE_FIRST_CHUNK;
+    const size_t msg_total = !j->has_msgs ? 0 : ragged ? (size_t)j->msg_off[n] : n * j->msg_len;
+    /* one chunk, one lane (any); several chunks - and the batch verification, whose statistics live in the pipe - all of them */
+    const int all = j->stats != NULL || (!ragged && n > first);
+    const int base = lanes_acquire(e, all);
+    if (base < 0) return base;
+#define LANE_OF(k) (&p->lane[all ? (k) % PIPE_LANES : (unsigned)base])
     g_trace.n = 0;
     TRACE(0, 0);
-    rc = pipe_init(p);
-    if (rc) goto out;
     {
-        const int ragged = j->has_msgs && j->msg_off != NULL;
-        const int tunable = j->stats == NULL;                   /* (a combination covers a fixed number of items) */
-        const size_t stage = tunable && g_pipe_stage ? g_pipe_stage : j->chunk ? j->chunk : PIPE_CHUNK;
-        const size_t first = tunable && g_pipe_first ? g_pipe_first : j->first_chunk ? j->first_chunk : PIPE_FIRST_CHUNK;
-        const size_t msg_total = !j->has_msgs ? 0 : ragged ? (size_t)j->msg_off[n] : n * j->msg_len;
         struct lane *prev = NULL;
         for (int i = 0; i < j->n_in; i++)
             staged_in[i] = !j->src_pinned && !(n * j->in_w[i] >= PIN_CHECK_MIN && is_pinned(j->in[i]));
@@ -432,12 +481,12 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
         }
         size_t lo = 0;
         for (unsigned k = 0; lo < n; k++) {
-            struct lane *L = &p->lane[k % PIPE_LANES];
+            struct lane *L = LANE_OF(k);
             size_t m = first << (k < 8 ? k : 8);
             if (m > stage) m = stage;
-            if (ragged || m > n - lo || n - lo - m < m / 2) m = n - lo;   /* (a short tail travels with the last chunk) */
+            if (ragged || !all || m > n - lo || n - lo - m < m / 2) m = n - lo;   /* (a short tail travels with the last chunk) */
             /* the lane's previous chunk (k - 3): the two chunks after it keep the GPU busy meanwhile */
-            if (k >= PIPE_LANES && (rc = lane_drain(L, j->wipe, NULL))) goto out;    /* (every call leaves the lanes drained) */
+            if (k >= PIPE_LANES && (rc = lane_drain(L, j->wipe, NULL))) goto out;    /* (every call leaves its lanes drained) */
             TRACE(1, k);
             for (int i = 0; i < j->n_in; i++) {
                 if ((rc = dev_grow(&L->d_in[i], &L->d_in_cap[i], m * j->in_w[i]))) goto out;
@@ -451,8 +500,8 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
                 if ((rc = lane_upload(L, L->d_msgs, &L->h_msgs, &L->h_msgs_cap, src, bytes, staged_msgs))) goto out;
             }
             if (ragged) {
-                if ((rc = dev_grow(&p->d_off, &p->d_off_cap, (n + 1) * sizeof(uint64_t)))) goto out;
-                if ((rc = lane_upload(L, p->d_off, &p->h_off, &p->h_off_cap, (const uint8_t *)j->msg_off, (n + 1) * sizeof(uint64_t),
+                if ((rc = dev_grow(&L->d_off, &L->d_off_cap, (n + 1) * sizeof(uint64_t)))) goto out;
+                if ((rc = lane_upload(L, L->d_off, &L->h_off, &L->h_off_cap, (const uint8_t *)j->msg_off, (n + 1) * sizeof(uint64_t),
                                       !j->src_pinned))) goto out;
             }
             if ((rc = dev_grow(&L->d_out, &L->d_out_cap, m * j->out_w))) goto out;
@@ -462,7 +511,7 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
                 struct hjob jj = *j;
                 jj.stats = j->stats ? p->d_stats : NULL;
                 rc = j->run(e, &jj, (uint8_t *)L->d_out, (uint8_t *const *)L->d_in, (const uint8_t *)L->d_msgs,
-                            ragged ? (const uint64_t *)p->d_off : NULL, j->msg_len, m, L->st, L->kdone);
+                            ragged ? (const uint64_t *)L->d_off : NULL, j->msg_len, m, L->st, L->kdone);
             }
             prev = L;
             TRACE(3, k);
@@ -487,7 +536,7 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
             TRACE(4, k);
             if (lo >= n) {                     /* the chunks still in flight, oldest first */
                 for (unsigned t = k + 1 < PIPE_LANES ? PIPE_LANES - k : 1; t <= PIPE_LANES; t++)
-                    if ((rc = lane_drain(&p->lane[(k + t) % PIPE_LANES], j->wipe, &wipes))) goto out;
+                    if ((rc = lane_drain(LANE_OF(k + t), j->wipe, &wipes))) goto out;
                 TRACE(5, k);
             }
         }
@@ -498,11 +547,13 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
         }
     }
 out:
-    if (rc && p->ready) {
-        for (int l = 0; l < PIPE_LANES; l++) { (void)hipStreamSynchronize(p->lane[l].st); p->lane[l].pend_bytes = 0; p->lane[l].used_in0 = 0; }
+    if (rc) {
         /* a failed call must not leave its secrets behind either (best effort: whole buffers, HBM and pinned) */
         for (int l = 0; l < PIPE_LANES; l++) {
             struct lane *L = &p->lane[l];
+            if (!all && l != base) continue;
+            (void)hipStreamSynchronize(L->st);
+            L->pend_bytes = 0; L->used_in0 = 0;
             if ((j->wipe & WIPE_IN0) && L->d_in[0]) (void)hipMemsetAsync(L->d_in[0], 0, L->d_in_cap[0], L->st);
             if ((j->wipe & WIPE_OUT) && L->d_out) (void)hipMemsetAsync(L->d_out, 0, L->d_out_cap, L->st);
             if (j->wipe) (void)hipStreamSynchronize(L->st);
@@ -512,7 +563,8 @@ out:
     }
     if (j->wipe) pool_wait(&wipes);            /* nothing secret outlives the call in the pinned staging buffers */
     TRACE(6, 0);
-    pthread_mutex_unlock(&e->pipe_lk);
+#undef LANE_OF
+    lanes_release(e, all, base);
     return rc;
 }
 
@@ -535,10 +587,13 @@ void combiner_init(struct combiner *q)
 
 void combiner_release(struct combiner *q)
 {
-    for (int i = 0; i < PIPE_MAX_IN; i++) host_free_wiped(&q->h_in[i], &q->h_in_cap[i]);
-    host_free_wiped(&q->h_msgs, &q->h_msgs_cap);
-    host_free_wiped(&q->h_out, &q->h_out_cap);
-    { void *p = q->h_off; size_t c = q->h_off_cap; host_free_wiped(&p, &c); q->h_off = NULL; q->h_off_cap = 0; }
+    for (int c = 0; c < COMB_KINDS; c++) {
+        struct comb_kind *K = &q->kind[c];
+        for (int i = 0; i < PIPE_MAX_IN; i++) host_free_wiped(&K->h_in[i], &K->h_in_cap[i]);
+        host_free_wiped(&K->h_msgs, &K->h_msgs_cap);
+        host_free_wiped(&K->h_out, &K->h_out_cap);
+        { void *p = K->h_off; size_t cap = K->h_off_cap; host_free_wiped(&p, &cap); K->h_off = NULL; K->h_off_cap = 0; }
+    }
     pthread_mutex_destroy(&q->lk);
 }
 
@@ -562,11 +617,10 @@ static int64_t now_ns(void)
     return (int64_t)ts.tv_sec * 1000000000 + ts.tv_nsec;
 }
 
-/* the leader's work: pack the requests of `batch` (a list through ->next, all with the same `run`), run them as one
- * job from the combiner's pinned buffers, scatter the results.  Returns the job's status. */
-static int combiner_run(struct engine *e, struct creq *batch, size_t total)
+/* the leader's work: pack the requests of `batch` (a list through ->next, all of one operation), run them as one job
+ * from the operation's pinned buffers, scatter the results.  Returns the job's status. */
+static int combiner_run(struct engine *e, struct comb_kind *K, struct creq *batch, size_t total)
 {
-    struct combiner *q = &e->comb_q;
     const struct hjob *j0 = batch->j;
     int rc = 0, same_len = 1;
     size_t msg_bytes = 0;
@@ -574,42 +628,42 @@ static int combiner_run(struct engine *e, struct creq *batch, size_t total)
         if (r->j->msg_len != j0->msg_len) same_len = 0;
         msg_bytes += r->n * r->j->msg_len;
     }
-    for (int i = 0; i < j0->n_in; i++) if ((rc = host_grow(&q->h_in[i], &q->h_in_cap[i], total * j0->in_w[i]))) return rc;
-    if (j0->has_msgs && (rc = host_grow(&q->h_msgs, &q->h_msgs_cap, msg_bytes))) return rc;
-    if ((rc = host_grow(&q->h_out, &q->h_out_cap, total * j0->out_w))) return rc;
+    for (int i = 0; i < j0->n_in; i++) if ((rc = host_grow(&K->h_in[i], &K->h_in_cap[i], total * j0->in_w[i]))) return rc;
+    if (j0->has_msgs && (rc = host_grow(&K->h_msgs, &K->h_msgs_cap, msg_bytes))) return rc;
+    if ((rc = host_grow(&K->h_out, &K->h_out_cap, total * j0->out_w))) return rc;
     if (j0->has_msgs && !same_len) {
-        void *p = q->h_off;
-        rc = host_grow(&p, &q->h_off_cap, (total + 1) * sizeof(uint64_t));
-        q->h_off = (uint64_t *)p;
+        void *p = K->h_off;
+        rc = host_grow(&p, &K->h_off_cap, (total + 1) * sizeof(uint64_t));
+        K->h_off = (uint64_t *)p;
         if (rc) return rc;
     }
     size_t at = 0, mat = 0;
     for (struct creq *r = batch; r; r = r->next) {
-        for (int i = 0; i < j0->n_in; i++) memcpy((uint8_t *)q->h_in[i] + at * j0->in_w[i], r->j->in[i], r->n * j0->in_w[i]);
+        for (int i = 0; i < j0->n_in; i++) memcpy((uint8_t *)K->h_in[i] + at * j0->in_w[i], r->j->in[i], r->n * j0->in_w[i]);
         if (j0->has_msgs) {
-            if (r->n * r->j->msg_len != 0) memcpy((uint8_t *)q->h_msgs + mat, r->j->msgs, r->n * r->j->msg_len);
-            if (!same_len) for (size_t k = 0; k < r->n; k++) q->h_off[at + k] = mat + k * r->j->msg_len;
+            if (r->n * r->j->msg_len != 0) memcpy((uint8_t *)K->h_msgs + mat, r->j->msgs, r->n * r->j->msg_len);
+            if (!same_len) for (size_t k = 0; k < r->n; k++) K->h_off[at + k] = mat + k * r->j->msg_len;
             mat += r->n * r->j->msg_len;
         }
         at += r->n;
     }
-    if (j0->has_msgs && !same_len) q->h_off[total] = mat;
+    if (j0->has_msgs && !same_len) K->h_off[total] = mat;
     struct hjob big = *j0;
-    for (int i = 0; i < j0->n_in; i++) big.in[i] = (const uint8_t *)q->h_in[i];
-    big.msgs = (const uint8_t *)q->h_msgs;
-    big.msg_off = j0->has_msgs && !same_len ? q->h_off : NULL;
-    big.out = (uint8_t *)q->h_out;
-    big.combinable = 0;
+    for (int i = 0; i < j0->n_in; i++) big.in[i] = (const uint8_t *)K->h_in[i];
+    big.msgs = (const uint8_t *)K->h_msgs;
+    big.msg_off = j0->has_msgs && !same_len ? K->h_off : NULL;
+    big.out = (uint8_t *)K->h_out;
+    big.kind = 0;
     big.src_pinned = 1;
     rc = pipe_run_on(e, &big, total);
     at = 0;
     for (struct creq *r = batch; r && !rc; r = r->next) {
-        memcpy(r->j->out, (uint8_t *)q->h_out + at * j0->out_w, r->n * j0->out_w);
+        memcpy(r->j->out, (uint8_t *)K->h_out + at * j0->out_w, r->n * j0->out_w);
         at += r->n;
     }
     /* the packed copies of secrets go as well */
-    if (j0->wipe & WIPE_IN0) memset(q->h_in[0], 0, total * j0->in_w[0]);
-    if (j0->wipe & WIPE_OUT) memset(q->h_out, 0, total * j0->out_w);
+    if (j0->wipe & WIPE_IN0) memset(K->h_in[0], 0, total * j0->in_w[0]);
+    if (j0->wipe & WIPE_OUT) memset(K->h_out, 0, total * j0->out_w);
     return rc;
 }
 
@@ -626,17 +680,21 @@ static void gen_wake_all(uint32_t *gen)
     (void)syscall(SYS_futex, gen, FUTEX_WAKE_PRIVATE, INT_MAX, NULL, NULL, 0);
 }
 
+/* One leader per OPERATION at a time: the calls queued for verify travel in one launch while, side by side on another
+ * lane of the pipeline, the calls queued for sign travel in theirs (threads that issue different operations would
+ * otherwise take turns: 64 threads split over four operations got 28 k calls/s that way). */
 static int combiner_submit(struct engine *e, const struct hjob *j, size_t n)
 {
     struct combiner *q = &e->comb_q;
+    struct comb_kind *K = &q->kind[j->kind];
     struct creq me = { j, n, 0, 0, NULL };
     pthread_mutex_lock(&q->lk);
     if (q->tail) q->tail->next = &me; else q->head = &me;
     q->tail = &me;
-    q->queued++;
+    K->queued++;
     for (;;) {
         if (__atomic_load_n(&me.done, __ATOMIC_ACQUIRE)) break;
-        if (q->leader) {
+        if (K->active) {
             const uint32_t seen = __atomic_load_n(&q->gen, __ATOMIC_RELAXED);
             pthread_mutex_unlock(&q->lk);
             gen_wait(&q->gen, seen);                   /* returns at once if a launch completed in between */
@@ -644,38 +702,37 @@ static int combiner_submit(struct engine *e, const struct hjob *j, size_t n)
             pthread_mutex_lock(&q->lk);
             continue;
         }
-        q->leader = 1;
+        K->active = 1;
         /* Under contention the callers of the launch that has just finished are about to queue again (they do within
          * microseconds of being woken): give them a moment, or the callers split into two camps that take turns and
          * every launch carries half of them.  Expected: whoever was already waiting when that launch ended, plus the
          * calls it carried.  Never long; a lone caller (the previous launch carried one call) never waits. */
         {
-            const unsigned want = q->waiting_at_end + q->last_reqs;
-            if (q->last_reqs > 1 && q->queued < want) {
+            const unsigned want = K->waiting_at_end + K->last_reqs;
+            if (K->last_reqs > 1 && K->queued < want) {
                 const int64_t until = now_ns() + COMBINE_GATHER_NS;
                 pthread_mutex_unlock(&q->lk);
                 for (;;) {
                     sched_yield();
                     pthread_mutex_lock(&q->lk);
-                    if (q->queued >= want || now_ns() >= until) break;
+                    if (K->queued >= want || now_ns() >= until) break;
                     pthread_mutex_unlock(&q->lk);
                 }
             }
         }
-        /* everything queued for the operation of the OLDEST request (so that no operation starves); this thread's own
-         * request may have to wait for a later leader */
+        /* everything queued for this operation (this thread's own request is among it unless thousands are ahead of it:
+         * then it leads again) */
         struct creq *batch = NULL, *btail = NULL, **pp = &q->head, *last = NULL;
-        const struct hjob *j0 = q->head->j;
         size_t total = 0, reqs = 0;
         while (*pp) {
             struct creq *r = *pp;
-            if (r->j->run == j0->run && r->j->has_msgs == j0->has_msgs && total + r->n <= COMBINE_MAX_BATCH) {
+            if (r->j->kind == j->kind && total + r->n <= COMBINE_MAX_BATCH) {
                 *pp = r->next;
                 r->next = NULL;
                 if (btail) btail->next = r; else batch = r;
                 btail = r;
                 total += r->n; reqs++;
-                q->queued--;
+                K->queued--;
             } else {
                 last = r;
                 pp = &r->next;
@@ -683,18 +740,18 @@ static int combiner_submit(struct engine *e, const struct hjob *j, size_t n)
         }
         q->tail = last;
         pthread_mutex_unlock(&q->lk);
-        const int rc = reqs == 1 && batch == &me ? pipe_run_on(e, j, n) : combiner_run(e, batch, total);
+        const int rc = reqs == 1 && batch == &me ? pipe_run_on(e, j, n) : combiner_run(e, K, batch, total);
         pthread_mutex_lock(&q->lk);
         q->batches++; q->items += reqs;
-        q->last_reqs = (unsigned)reqs;
-        q->waiting_at_end = q->queued;
+        K->last_reqs = (unsigned)reqs;
+        K->waiting_at_end = K->queued;
         for (struct creq *r = batch; r;) {             /* a caller may return (and its request vanish) the moment `done` is set */
             struct creq *nx = r->next;
             r->rc = rc;
             __atomic_store_n(&r->done, 1, __ATOMIC_RELEASE);
             r = nx;
         }
-        q->leader = 0;
+        K->active = 0;
         __atomic_add_fetch(&q->gen, 1, __ATOMIC_RELEASE);
         pthread_mutex_unlock(&q->lk);
         gen_wake_all(&q->gen);
@@ -712,7 +769,7 @@ static int pipe_run(const struct hjob *j, size_t n)
     if (n == 0) return 0;
     rc = enter(&c, -1);
     if (rc) return rc;
-    if (j->combinable && n <= COMBINE_MAX_N && !(j->has_msgs && (j->msg_off || n * j->msg_len > COMBINE_MAX_BYTES)))
+    if (j->kind && n <= COMBINE_MAX_N && !(j->has_msgs && (j->msg_off || n * j->msg_len > COMBINE_MAX_BYTES)))
         rc = combiner_submit(c.e, j, n);
     else
         rc = pipe_run_on(c.e, j, n);
@@ -788,25 +845,25 @@ static struct hjob job_verify(uint8_t *ok, const uint8_t *sigs, const uint8_t *p
      * tails that the neighbouring chunks' kernels fill when the lanes run side by side (95.7 M/s; in chunk order 79-86),
      * and the small first chunk gets the chip working 0.2 ms after the call. */
     struct hjob j = { 2, { sigs, pubs, NULL }, { 64, 32, 0 }, 1, msgs, msg_off, msg_len, ok, 1, run_verify, 0, 0, 0,
-                      PIPE_CHUNK_VERIFY, WIPE_NONE, NULL, (size_t)1 << 16, 0, 1, 0 };
+                      PIPE_CHUNK_VERIFY, WIPE_NONE, NULL, (size_t)1 << 16, 0, 1, 0 };   /* kind 1 */
     return j;
 }
 static struct hjob job_sign(uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs, const uint8_t *msgs,
                             const uint64_t *msg_off, size_t msg_len)
 {
     struct hjob j = { 2, { secs, pubs, NULL }, { 32, 32, 0 }, 1, msgs, msg_off, msg_len, sigs, 64, run_sign, 0, 0, 0, 0,
-                      WIPE_IN0, NULL, 0, 1, 1, 0 };
+                      WIPE_IN0, NULL, 0, 1, 2, 0 };
     return j;
 }
 static struct hjob job_x25519(uint8_t *out, const uint8_t *scalars, const uint8_t *points)
 {
     struct hjob j = { 2, { scalars, points, NULL }, { 32, 32, 0 }, 0, NULL, NULL, 0, out, 32, run_x25519, 0, 0, 0, 0,
-                      WIPE_IN0 | WIPE_OUT, NULL, 0, 1, 1, 0 };
+                      WIPE_IN0 | WIPE_OUT, NULL, 0, 1, 3, 0 };
     return j;
 }
-static struct hjob job_1in(int (*run)(RUN_ARGS), uint8_t *out, const uint8_t *in, int wipe)
+static struct hjob job_1in(int (*run)(RUN_ARGS), uint8_t *out, const uint8_t *in, int wipe, int kind)
 {
-    struct hjob j = { 1, { in, NULL, NULL }, { 32, 0, 0 }, 0, NULL, NULL, 0, out, 32, run, 0, 0, 0, 0, wipe, NULL, 0, 1, 1, 0 };
+    struct hjob j = { 1, { in, NULL, NULL }, { 32, 0, 0 }, 0, NULL, NULL, 0, out, 32, run, 0, 0, 0, 0, wipe, NULL, 0, 1, kind, 0 };
     return j;
 }
 
@@ -829,7 +886,7 @@ int ed25519_verify_batch_rlc(uint8_t *ok, uint32_t stats[4], const uint8_t *sigs
     j.run = run_verify_rlc;
     j.chunk = j.first_chunk = CHUNK_MAX;   /* one combination per 2^20 items */
     j.stats = local;
-    j.combinable = 0;
+    j.kind = 0;
     int rc = pipe_run(&j, n);
     if (stats) memcpy(stats, local, sizeof(local));
     return rc;
@@ -859,22 +916,22 @@ int x25519_batch(uint8_t *out, const uint8_t *scalars, const uint8_t *points, si
 
 int ed25519_genpub_batch(uint8_t *pubs, const uint8_t *secs, size_t n)
 {
-    struct hjob j = job_1in(run_genpub, pubs, secs, WIPE_IN0);
+    struct hjob j = job_1in(run_genpub, pubs, secs, WIPE_IN0, 4);
     return pipe_run(&j, n);
 }
 int x25519_base_batch(uint8_t *out, const uint8_t *scalars, size_t n)
 {
-    struct hjob j = job_1in(run_xbase, out, scalars, WIPE_IN0);
+    struct hjob j = job_1in(run_xbase, out, scalars, WIPE_IN0, 5);
     return pipe_run(&j, n);
 }
 int pk_ed25519_to_x25519_batch(uint8_t *out, const uint8_t *in, size_t n)
 {
-    struct hjob j = job_1in(run_pk_to_x, out, in, WIPE_NONE);
+    struct hjob j = job_1in(run_pk_to_x, out, in, WIPE_NONE, 6);
     return pipe_run(&j, n);
 }
 int sk_ed25519_to_x25519_batch(uint8_t *out, const uint8_t *in, size_t n)
 {
-    struct hjob j = job_1in(run_sk_to_x, out, in, WIPE_IN0 | WIPE_OUT);
+    struct hjob j = job_1in(run_sk_to_x, out, in, WIPE_IN0 | WIPE_OUT, 7);
     return pipe_run(&j, n);
 }
 
