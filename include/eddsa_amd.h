@@ -41,7 +41,8 @@
  * stream are ordered by the stream.  Host-pointer calls on one device share its staging pipeline: large
  * calls run one after the other; SMALL calls (up to 64 items, fixed-length messages - among them every call
  * of the eddsa.h single-item functions) issued by several threads at once are merged: the calls queued for
- * one operation travel as ONE launch and every caller gets its own results back (the reference is
+ * one operation travel as ONE launch (launches of different operations side by side) and every caller gets
+ * its own results back (the reference is
  * reentrant and scales with its caller's threads, lib/eddsa.h:44-80; a GPU pass costs about 0.4 ms however
  * few items it carries).  eddsa_amd_shutdown waits for calls in flight.
  * Host memory: ordinary (malloc) memory is staged through page-locked buffers by a few copier threads

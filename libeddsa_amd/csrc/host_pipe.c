@@ -18,8 +18,8 @@
  *   3. A combiner for concurrent small calls (flat combining).  A GPU pass costs about 0.4 ms however few items it
  *      carries, so T threads that each loop over ed25519_verify would get 1 / 0.4 ms verifies per second IN TOTAL
  *      if their calls ran one after the other.  Instead a small call queues its request; one of the waiting
- *      threads becomes the leader, packs everything queued for the same operation into one batch, runs it as a
- *      single pipeline job and hands the results back.
+ *      threads becomes the leader of its operation, packs everything queued for that operation into one batch, runs
+ *      it as a single pipeline job (one lane: the launches of different operations overlap) and hands the results back.
  *
  * Jobs that carry secrets (secret keys, scalars, shared secrets) zero their staging copies - in HBM, in the
  * pinned host buffers and in the combiner's buffers - before the call returns, on the error path too (the
