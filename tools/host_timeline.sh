@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/host_tl_$OP
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/tr -- python3 $REPO/tools/host_trace.py $OP ${2:-20} > $OUT/run.log 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/tr -- python3 $REPO/tools/host_trace.py $OP $2 > $OUT/run.log 2>&1
 tail -2 $OUT/run.log
 python3 - $OUT <<'PY' | tee $OUT.txt
 import csv, glob, sys
@@ -25,6 +25,6 @@ cut = max(gaps)[1] + 1
 last = ev[cut:]
 t0 = last[0][0]
 for s, e, name, q in last:
-    if (e - s) < 20000 and 'k_' not in name: continue
+    if (e - s) < 20000 and 'k_' not in name and len(last) > 60: continue
     print('%-44s %-5s start %8.3f  end %8.3f  dur %7.3f ms' % (name[:44], q, (s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e6))
 PY
