@@ -166,6 +166,16 @@ def test_multi_device_python_mirror(engine, oracle):
     for d, o in enumerate(outs):
         torch.cuda.synchronize(d)
         assert np.array_equal(o.cpu().numpy(), want), d
+    # the C entry point trusts its pointers, so the mirror checks every shard's size and device first
+    lo, hi = shards[0]
+    with pytest.raises(ValueError):
+        engine.ed25519_verify_batch_multi_dev([to(s2[lo:hi - 1], 0)] + [to(s2[a:b], d) for d, (a, b) in enumerate(shards)][1:],
+                                              [to(pk[a:b], d) for d, (a, b) in enumerate(shards)],
+                                              [to(m[a:b], d) for d, (a, b) in enumerate(shards)], 32, n)
+    with pytest.raises(ValueError):
+        engine.ed25519_verify_batch_multi_dev([to(s2[a:b], d) for d, (a, b) in enumerate(shards)],
+                                              [to(pk[a:b], d) for d, (a, b) in enumerate(shards)],
+                                              [to(m[a:b], d) for d, (a, b) in enumerate(shards)], 31, n)
 
 
 def test_c_program_on_the_multi_device_entry_points(engine, golden, tmp_path):
