@@ -5,7 +5,8 @@
  * operation are merged into one GPU launch (host_pipe.c: the combiner); every caller must still get exactly its
  * own result.  Checks every result against the golden table and prints the aggregate rates.
  *
- * usage: threaded_callers <ed25519_table.bin> <ed25519_msgs.bin> <x25519_table.bin> [threads [iterations]]
+ * usage: threaded_callers <ed25519_table.bin> <ed25519_msgs.bin> <x25519_table.bin> [threads [iterations [entries]]]
+ *        (entries: only the first so many table entries are used, i.e. messages shorter than that; default all 1024)
  * exit status 0 = every result was right.
  */
 #define _POSIX_C_SOURCE 200809L
@@ -39,7 +40,7 @@ static double now(void)
 }
 
 static const uint8_t *g_et, *g_msgs, *g_xt;
-static int g_iters, g_mode;             /* mode 0: every thread verifies; 1: threads take different operations */
+static int g_iters, g_mode, g_entries = 1024;             /* mode 0: every thread verifies; 1: threads take different operations */
 static pthread_barrier_t g_start;
 
 struct worker { int id; long done, wrong; };
@@ -51,7 +52,7 @@ static void *work(void *arg)
     uint8_t out[64];
     pthread_barrier_wait(&g_start);
     for (int it = 0; it < g_iters; it++) {
-        const size_t i = (size_t)((w->id * 131 + it * 7) % 1024);
+        const size_t i = (size_t)((w->id * 131 + it * 7) % g_entries);
         const uint8_t *sk = g_et + 128 * i, *pk = sk + 32, *sig = sk + 64, *m = g_msgs + i * (i - 1) / 2;
         const int op = g_mode == 0 ? 0 : w->id % 4;
         if (op == 0) {                  /* a genuine signature, then the same with one bit flipped */
@@ -95,12 +96,13 @@ static int run(int threads, const char *what)
 
 int main(int argc, char **argv)
 {
-    if (argc < 4) { fprintf(stderr, "usage: %s ed25519_table.bin ed25519_msgs.bin x25519_table.bin [threads [iterations]]\n", argv[0]); return 2; }
+    if (argc < 4) { fprintf(stderr, "usage: %s ed25519_table.bin ed25519_msgs.bin x25519_table.bin [threads [iterations [entries]]]\n", argv[0]); return 2; }
     size_t el, ml, xl;
     g_et = slurp(argv[1], &el); g_msgs = slurp(argv[2], &ml); g_xt = slurp(argv[3], &xl);
     if (el != 1024 * 128 || ml != 1024 * 1023 / 2 || xl != 1024 * 96) { fprintf(stderr, "threaded_callers: unexpected table sizes\n"); return 2; }
     const int threads = argc > 4 ? atoi(argv[4]) : 64;
     g_iters = argc > 5 ? atoi(argv[5]) : 200;
+    if (argc > 6 && atoi(argv[6]) > 0 && atoi(argv[6]) <= 1024) g_entries = atoi(argv[6]);
     uint8_t warm[32];
     ed25519_genpub(warm, g_et);         /* builds the engine (tables) before the clock starts */
     int bad = 0;
