@@ -122,3 +122,38 @@ def test_fuzz_batch_verification_on_mostly_valid_traffic(engine, oracle, case):
     assert np.array_equal(got.cpu().numpy(), want)
     groups = (n + 8191) // 8192
     assert st[2] + st[3] == groups and st[2] <= nbad and st[0] + st[1] == n
+
+
+CHUNK_EDGE_SIZES = [65535, 65536, 65537, 98303, 98304, 98305, 131071, 131072, 131073, 196607, 196608, 196609, 393215, 393217,
+                    458751, 458753, 600001]
+
+
+@pytest.mark.parametrize("n", CHUNK_EDGE_SIZES)
+def test_host_pipeline_at_chunk_boundaries(engine, oracle, n):
+    """the host-pointer pipeline (host_pipe.c: chunks of 2^16 / 2^17 items doubling up to the stage size, three lanes, a short
+    tail travelling with the last chunk) at sizes on both sides of every boundary of its schedule: same bytes as the
+    device-pointer entry points on the same data (those are pinned against the reference elsewhere), the constructed
+    verdict pattern, and the oracle on a sample that straddles the first chunk boundary"""
+    rng = np.random.default_rng(n)
+    sk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    msg = rng.integers(0, 256, (n, 20), dtype=np.uint8)
+    d_sk, d_msg = dev(sk), dev(msg)
+    d_pk = engine.ed25519_genpub_batch(d_sk)
+    d_sig = engine.ed25519_sign_batch(d_sk, d_pk, d_msg, msg_len=20)
+    pk, sig = d_pk.cpu().numpy(), d_sig.cpu().numpy()
+    assert np.array_equal(engine.ed25519_genpub_batch(sk), pk)                       # host path, chunked
+    assert np.array_equal(engine.ed25519_sign_batch(sk, pk, msg, msg_len=20), sig)
+    bad = sig.copy()
+    flip = (np.arange(n) % 11 == 3) | (np.arange(n) == n - 1) | (np.arange(n) == 65536 % n)
+    bad[flip, 41] ^= 8
+    ok = engine.ed25519_verify_batch(bad, pk, msg, msg_len=20)
+    assert np.array_equal(ok, (~flip).astype(np.uint8))
+    assert np.array_equal(ok, engine.ed25519_verify_batch(dev(bad), d_pk, d_msg, msg_len=20).cpu().numpy())
+    pt = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    xo = engine.x25519_batch(sk, pt)
+    assert np.array_equal(xo, engine.x25519_batch(d_sk, dev(pt)).cpu().numpy())
+    lo = max(0, min(n, 65536) - 40)
+    hi = min(n, lo + 80)
+    assert np.array_equal(xo[lo:hi], oracle.x25519_batch(sk[lo:hi], pt[lo:hi]))
+    assert np.array_equal(ok[lo:hi], oracle.verify_batch(bad[lo:hi], pk[lo:hi], msg[lo:hi], 20))
+    assert np.array_equal(sig[lo:hi], oracle.sign_batch(sk[lo:hi], pk[lo:hi], msg[lo:hi], 20))
