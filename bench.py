@@ -26,7 +26,8 @@ Prints ONE JSON line on rank 0 (see the driver contract), with two extra objects
   cpu_baseline  the reference itself (oracle/_ref, compiled from its own sources) timed on this
                 box's host cores on a bounded sample of the same workload (rank 0; at N > 1 the other ranks
                 sleep in a host-side barrier meanwhile)
-At N = 1 `secondary.verify_sustained` repeats the config-2 pass back to back for --sustained seconds (default 10)
+At N = 1 `secondary.verify_host_to_host` is the PCIe-inclusive rate of the same batch through the host-pointer entry
+point (for the record; `value` never includes transfers) and `secondary.verify_sustained` repeats the config-2 pass back to back for --sustained seconds (default 10)
 and reports the rate of the last half with the power and clock rocm-smi shows: the headline region lasts 0.2 s,
 which a power-bound chip runs above its steady-state clock.  At N > 1 `per_rank` breaks the step down by rank
 (kernel ms, gather ms, wall ms, the slowest rank), so that a scaling point can be attributed.
@@ -531,6 +532,24 @@ def main():
             "items_per_gpu": m, "stats": st, "outputs_correct": good,
             "note": "not the headline: verdicts equal the per-item path's, see include/eddsa_amd.h for the caveat; "
                     "time of this rank (no gather)"}
+    if args.op == "all" and main_op == "verify" and world == 1:
+        # PCIe-inclusive, for the record only (never `value`): the same batch from ordinary host memory to host memory through
+        # the host-pointer entry point (staging, three lanes: libeddsa_amd/csrc/host_pipe.c)
+        m = min(n, 1 << 20)
+        hs, hp, hm = (w[k][:m].cpu().numpy() for k in ("sigs", "pubs", "msgs"))
+        for _ in range(2):
+            okh = ed.ed25519_verify_batch(hs, hp, hm, msg_len=32)
+        best = float("inf")
+        for _ in range(5):
+            t0 = time.perf_counter()
+            okh = ed.ed25519_verify_batch(hs, hp, hm, msg_len=32)
+            best = min(best, time.perf_counter() - t0)
+        good = bool(np.array_equal(okh, w["expect"][:m].cpu().numpy()))
+        correct = correct and good
+        secondary["verify_host_to_host"] = {
+            "metric": "ed25519 verifies/sec, PCIe-inclusive: numpy (malloc) arrays in, numpy array out, best of 5",
+            "value": m / best, "unit": UNIT["verify"], "ms_per_call": best * 1e3, "items": m, "outputs_correct": good,
+            "note": "not the headline: `value` is measured with inputs resident in HBM"}
     if args.op == "all" and main_op == "verify" and world == 1 and args.sustained > 0:
         secondary["verify_sustained"] = sustained_verify(w, n, args.sustained, local, line["value"])
         correct = correct and secondary["verify_sustained"]["outputs_correct"]
