@@ -520,6 +520,31 @@ def test_combined_small_calls_of_many_threads(engine, oracle):
     assert res[0] == 0 and res[2] == 0, res               # scalar workspace, input staging (HBM, pinned, the combiner's)
 
 
+def test_edge_and_torsion_vectors_as_concurrent_single_item_calls(engine, golden):
+    """the 273 edge cases and the 192 mixed-order vectors, every one as its own ed25519_verify call, issued by 16 threads
+    at once: the combiner packs whatever meets into ragged batches (off-curve keys, non-canonical encodings, messages of
+    0..1023 bytes side by side) and every caller must get the reference's verdict for ITS item"""
+    import threading
+    cases = golden("verify_edges.json") + golden("verify_torsion.json")
+    items = [(bytes.fromhex(c["sig"]), bytes.fromhex(c["pub"]), bytes.fromhex(c["msg"]), bool(c["accept"]), c["name"]) for c in cases]
+    wrong, before = [], engine.combiner_stats()
+
+    def worker(t):
+        for k in range(t, len(items), 16):
+            sig, pub, msg, want, name = items[k]
+            if engine.ed25519_verify(sig, pub, msg) != want:
+                wrong.append(name)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not wrong, wrong[:5]
+    after = engine.combiner_stats()
+    assert after[1] - before[1] == len(items) and after[0] - before[0] < len(items)
+
+
 def test_concurrent_host_threads(engine, oracle):
     """several host threads issue batched calls at once (host-pointer pipeline and device-pointer
     entry points on different torch streams): calls serialise on the engine's workspaces and every
