@@ -358,9 +358,9 @@ struct finish_pos {
   size_t tile, i;            // tile index and global item index of slot k for this lane
   const uint32_t* acc;       // this lane's column of the tile: X at [j*BLOCK], Y at [(10+j)*BLOCK], Z at [(20+j)*BLOCK]
 };
-ED_DEV finish_pos finish_at(int k, const uint32_t* accin) {
+ED_DEV finish_pos finish_at(int k, const uint32_t* accin, int K) {
   finish_pos p;
-  p.tile = (size_t)blockIdx.x * FINISH_K + k;
+  p.tile = (size_t)blockIdx.x * K + k;
   p.i = p.tile * BLOCK + threadIdx.x;
   p.acc = accin + p.tile * (ACC_WORDS * BLOCK) + threadIdx.x;
   return p;
@@ -384,50 +384,51 @@ ED_DEV void acc_store(uint32_t* accout, size_t i, const ge& p) {
 // inversion's temporaries every finish kernel needed more than 256 VGPRs and spilled 660 bytes per
 // lane.  The same lane writes and later reads these slots.  Phase B is an ordinary loop over the
 // items, so the (large) per-item code exists once.
-ED_DEV void slot_store(uint32_t* acc, int k, int coord, const fe& f) {
-  uint32_t* o = acc + ((size_t)blockIdx.x * FINISH_K + k) * (ACC_WORDS * BLOCK) + threadIdx.x;
+ED_DEV void slot_store(uint32_t* acc, int k, int coord, const fe& f, int K) {
+  uint32_t* o = acc + ((size_t)blockIdx.x * K + k) * (ACC_WORDS * BLOCK) + threadIdx.x;
 #pragma unroll
   for (int j = 0; j < 10; j++) o[(10 * coord + j) * BLOCK] = f.v[j];
 }
-ED_DEV void slot_load(fe& f, const uint32_t* acc, int k, int coord) {
-  const uint32_t* o = acc + ((size_t)blockIdx.x * FINISH_K + k) * (ACC_WORDS * BLOCK) + threadIdx.x;
+ED_DEV void slot_load(fe& f, const uint32_t* acc, int k, int coord, int K) {
+  const uint32_t* o = acc + ((size_t)blockIdx.x * K + k) * (ACC_WORDS * BLOCK) + threadIdx.x;
 #pragma unroll
   for (int j = 0; j < 10; j++) f.v[j] = o[(10 * coord + j) * BLOCK];
 }
-ED_DEV void zinv_store(uint32_t* acc, int k, const fe& zi) { slot_store(acc, k, 2, zi); }
+ED_DEV void zinv_store(uint32_t* acc, int k, const fe& zi, int K) { slot_store(acc, k, 2, zi, K); }
 
 template <class P>
 ED_DEV void finish_batch8(const P& pol, uint32_t* acc) {
+  const int K = pol.K;                           // items per lane that share the inversion: FINISH_K, fewer in small passes
   fe z, p, u, zi;
   pol.den(0, p);
-  slot_store(acc, 0, 3, p);
+  slot_store(acc, 0, 3, p, K);
 #pragma unroll 1
-  for (int k = 1; k < FINISH_K; k++) {
+  for (int k = 1; k < K; k++) {
     pol.den(k, z);
     fe_mul(p, p, z);
-    slot_store(acc, k, 3, p);                    // z0 ... zk
+    slot_store(acc, k, 3, p, K);                 // z0 ... zk
   }
-  fe_inv(u, p);                                  // u = 1 / (z0 ... z7)
+  fe_inv(u, p);                                  // u = 1 / (z0 ... z(K-1))
 #pragma unroll 1
-  for (int k = FINISH_K - 1; k >= 1; k--) {
-    slot_load(p, acc, k - 1, 3);
+  for (int k = K - 1; k >= 1; k--) {
+    slot_load(p, acc, k - 1, 3, K);
     fe_mul(zi, u, p);                            // 1 / zk
-    slot_load(z, acc, k, 2);
+    slot_load(z, acc, k, 2, K);
     fe_mul(u, u, z);                             // 1 / (z0 ... z(k-1))
-    zinv_store(acc, k, zi);
+    zinv_store(acc, k, zi, K);
   }
-  zinv_store(acc, 0, u);
+  zinv_store(acc, 0, u, K);
 #pragma unroll 1
-  for (int k = 0; k < FINISH_K; k++) pol.item(k);
+  for (int k = 0; k < K; k++) pol.item(k);
 }
 
 // z := good ? z : 1, committed to slot k's Z so that the unwinding re-reads exactly this value
-ED_DEV void den_commit(fe& z, bool good, uint32_t* acc, int k) {
+ED_DEV void den_commit(fe& z, bool good, uint32_t* acc, int k, int K) {
   fe one;
   fe_set(one, 1);
   fe_cmov(one, z, good);
   z = one;
-  zinv_store(acc, k, z);
+  zinv_store(acc, k, z, K);
 }
 
 // verify: encode and compare with R as bytes (ed25519-sha512.c:176-180): a non-canonical R can
@@ -435,9 +436,9 @@ ED_DEV void den_commit(fe& z, bool good, uint32_t* acc, int k) {
 // verdict; DESIGN.md "Off-curve public keys"); Z = 0 cannot occur for a curve point (the a = -1 law
 // is complete) and is rejected defensively.
 struct verify_finish_policy {
-  uint8_t* ok; const uint8_t* sigs; size_t sig_stride; uint32_t* acc; uint8_t* flags; size_t n; int exact_offcurve;
+  uint8_t* ok; const uint8_t* sigs; size_t sig_stride; uint32_t* acc; uint8_t* flags; size_t n; int exact_offcurve; int K;
   ED_DEV void den(int k, fe& z) const {
-    const finish_pos p = finish_at(k, acc);
+    const finish_pos p = finish_at(k, acc, K);
     fe_set(z, 1);
     bool good = false;
     if (p.i < n) {
@@ -446,10 +447,10 @@ struct verify_finish_policy {
       good = (fl & 1) != 0 && !fe_iszero(z);
       flags[p.i] = (uint8_t)((fl & 1) | (good ? 2 : 0));   // phase B reads it back
     }
-    den_commit(z, good, acc, k);
+    den_commit(z, good, acc, k, K);
   }
   ED_DEV void item(int k) const {
-    const finish_pos p = finish_at(k, acc);
+    const finish_pos p = finish_at(k, acc, K);
     if (p.i >= n) return;
     fe x, y, zinv;
     acc_load(x, p.acc, 0); acc_load(y, p.acc, 1); acc_load(zinv, p.acc, 2);
@@ -488,16 +489,16 @@ k_verify_main_quad(const uint32_t* digits, const uint32_t* table, const uint32_t
 
 __global__ void __launch_bounds__(BLOCK, 2)
 k_verify_finish(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, uint32_t* acc, uint8_t* flags, size_t n,
-                int exact_offcurve) {
-  finish_batch8(verify_finish_policy{ok, sigs, sig_stride, acc, flags, n, exact_offcurve}, acc);
+                int exact_offcurve, int K) {
+  finish_batch8(verify_finish_policy{ok, sigs, sig_stride, acc, flags, n, exact_offcurve, K}, acc);
 }
 
 // x25519.c:144-149: x2 / z2, and 0 when z2 = 0 (fld_inv(0) = 0): such an item contributes 1 to the
 // shared product and its "inverse" is forced to 0
 struct x25519_finish_policy {
-  uint8_t* out; uint32_t* acc; size_t n;
+  uint8_t* out; uint32_t* acc; size_t n; int K;
   ED_DEV void den(int k, fe& z) const {
-    const finish_pos p = finish_at(k, acc);
+    const finish_pos p = finish_at(k, acc, K);
     fe_set(z, 1);
     bool good = false;
     if (p.i < n) {
@@ -509,10 +510,10 @@ struct x25519_finish_policy {
         for (int j = 0; j < 10; j++) o[j * BLOCK] = 0;
       }
     }
-    den_commit(z, good, acc, k);
+    den_commit(z, good, acc, k, K);
   }
   ED_DEV void item(int k) const {
-    const finish_pos p = finish_at(k, acc);
+    const finish_pos p = finish_at(k, acc, K);
     fe x, zinv;
     if (p.i < n) { acc_load(x, p.acc, 0); acc_load(zinv, p.acc, 2); }
     // (x2 : z2), 1/z2 and the prefix products of the shared inversion determine shared secrets: they
@@ -528,8 +529,8 @@ struct x25519_finish_policy {
 };
 
 __global__ void __launch_bounds__(BLOCK, 2)
-k_x25519_finish(uint8_t* out, uint32_t* acc, size_t n) {
-  finish_batch8(x25519_finish_policy{out, acc, n}, acc);
+k_x25519_finish(uint8_t* out, uint32_t* acc, size_t n, int K) {
+  finish_batch8(x25519_finish_policy{out, acc, n, K}, acc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -544,7 +545,7 @@ __global__ void __launch_bounds__(POINT_BLOCK, 512 / POINT_BLOCK)
 k_genpub_point(uint32_t* accout, const uint8_t* secs, size_t n, const uint32_t* comb) {
   __shared__ alignas(16) uint32_t lds_comb[COMB_IMG_WORDS];
   stage_table(lds_comb, comb, COMB_IMG_WORDS);
-  const size_t i = (size_t)blockIdx.x * POINT_BLOCK + threadIdx.x;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // blocks of POINT_BLOCK lanes, or single waves for small passes (EDK_POINT_GRID)
   uint32_t sk[8];
   load32(sk, secs, i < n ? i : n - 1, 32);
   ge A;
@@ -554,15 +555,15 @@ k_genpub_point(uint32_t* accout, const uint8_t* secs, size_t n, const uint32_t* 
 
 // Z of a comb result is never 0 (B and its multiples are curve points)
 struct encode_finish_policy {
-  uint8_t* out; uint32_t* acc; size_t n;
+  uint8_t* out; uint32_t* acc; size_t n; int K;
   ED_DEV void den(int k, fe& z) const {
-    const finish_pos p = finish_at(k, acc);
+    const finish_pos p = finish_at(k, acc, K);
     fe_set(z, 1);
     if (p.i < n) acc_load(z, p.acc, 2);
-    den_commit(z, true, acc, k);
+    den_commit(z, true, acc, k, K);
   }
   ED_DEV void item(int k) const {
-    const finish_pos p = finish_at(k, acc);
+    const finish_pos p = finish_at(k, acc, K);
     if (p.i >= n) return;
     fe x, y, zinv;
     acc_load(x, p.acc, 0); acc_load(y, p.acc, 1); acc_load(zinv, p.acc, 2);
@@ -573,8 +574,8 @@ struct encode_finish_policy {
 };
 
 __global__ void __launch_bounds__(BLOCK, 2)
-k_encode_finish(uint8_t* out, uint32_t* acc, size_t n) {
-  finish_batch8(encode_finish_policy{out, acc, n}, acc);
+k_encode_finish(uint8_t* out, uint32_t* acc, size_t n, int K) {
+  finish_batch8(encode_finish_policy{out, acc, n, K}, acc);
 }
 
 __global__ void __launch_bounds__(POINT_BLOCK, 512 / POINT_BLOCK)
@@ -582,7 +583,7 @@ k_sign_point(uint32_t* accout, uint32_t* aux, const uint8_t* secs, const uint8_t
              const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* comb) {
   __shared__ alignas(16) uint32_t lds_comb[COMB_IMG_WORDS];
   stage_table(lds_comb, comb, COMB_IMG_WORDS);
-  const size_t i = (size_t)blockIdx.x * POINT_BLOCK + threadIdx.x;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // blocks of POINT_BLOCK lanes, or single waves for small passes (EDK_POINT_GRID)
   const size_t item = i < n ? i : n - 1;
   const uint8_t* m; size_t mlen;
   msg_span(m, mlen, msgs, msg_off, msg_len, item);
@@ -599,15 +600,15 @@ k_sign_point(uint32_t* accout, uint32_t* aux, const uint8_t* secs, const uint8_t
 
 struct sign_finish_policy {
   uint8_t* sigs; uint32_t* acc; uint32_t* aux; const uint8_t* pubs; const uint8_t* msgs;
-  const uint64_t* msg_off; size_t msg_len; size_t n;
+  const uint64_t* msg_off; size_t msg_len; size_t n; int K;
   ED_DEV void den(int k, fe& z) const {
-    const finish_pos p = finish_at(k, acc);
+    const finish_pos p = finish_at(k, acc, K);
     fe_set(z, 1);
     if (p.i < n) acc_load(z, p.acc, 2);
-    den_commit(z, true, acc, k);
+    den_commit(z, true, acc, k, K);
   }
   ED_DEV void item(int k) const {
-    const finish_pos p = finish_at(k, acc);
+    const finish_pos p = finish_at(k, acc, K);
     if (p.i >= n) return;
     fe x, y, zinv;
     acc_load(x, p.acc, 0); acc_load(y, p.acc, 1); acc_load(zinv, p.acc, 2);
@@ -633,15 +634,15 @@ struct sign_finish_policy {
 
 __global__ void __launch_bounds__(BLOCK, 2)
 k_sign_finish(uint8_t* sigs, uint32_t* acc, uint32_t* aux, const uint8_t* pubs, const uint8_t* msgs,
-              const uint64_t* msg_off, size_t msg_len, size_t n) {
-  finish_batch8(sign_finish_policy{sigs, acc, aux, pubs, msgs, msg_off, msg_len, n}, acc);
+              const uint64_t* msg_off, size_t msg_len, size_t n, int K) {
+  finish_batch8(sign_finish_policy{sigs, acc, aux, pubs, msgs, msg_off, msg_len, n, K}, acc);
 }
 
 __global__ void __launch_bounds__(POINT_BLOCK, 512 / POINT_BLOCK)
 k_x25519_base_point(uint32_t* accout, const uint8_t* scalars, size_t n, const uint32_t* comb) {
   __shared__ alignas(16) uint32_t lds_comb[COMB_IMG_WORDS];
   stage_table(lds_comb, comb, COMB_IMG_WORDS);
-  const size_t i = (size_t)blockIdx.x * POINT_BLOCK + threadIdx.x;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // blocks of POINT_BLOCK lanes, or single waves for small passes (EDK_POINT_GRID)
   uint32_t s[8];
   load32(s, scalars, i < n ? i : n - 1, 32);
   ge R;
@@ -654,9 +655,9 @@ k_x25519_base_point(uint32_t* accout, const uint8_t* scalars, size_t n, const ui
 // u = (z + y) / (z - y); z = y gives 0 in the reference (fld_inv(0) = 0, x25519.c:192): such an
 // item contributes 1 to the shared product and gets the "inverse" 0 by hand.
 struct x25519_base_finish_policy {
-  uint8_t* out; uint32_t* acc; size_t n;
+  uint8_t* out; uint32_t* acc; size_t n; int K;
   ED_DEV void den(int k, fe& d) const {
-    const finish_pos p = finish_at(k, acc);
+    const finish_pos p = finish_at(k, acc, K);
     fe_set(d, 1);
     bool good = false;
     if (p.i < n) {
@@ -665,10 +666,10 @@ struct x25519_base_finish_policy {
       fe_sub(d, z, y);                           // 3u
       good = !fe_iszero(d);
     }
-    den_commit(d, good, acc, k);
+    den_commit(d, good, acc, k, K);
   }
   ED_DEV void item(int k) const {
-    const finish_pos p = finish_at(k, acc);
+    const finish_pos p = finish_at(k, acc, K);
     if (p.i >= n) return;
     fe x, y, dinv, z, d;
     acc_load(y, p.acc, 1); acc_load(dinv, p.acc, 2);     // the Z slot now holds 1/(z - y) (or 1/1)
@@ -688,8 +689,8 @@ struct x25519_base_finish_policy {
 };
 
 __global__ void __launch_bounds__(BLOCK, 2)
-k_x25519_base_finish(uint8_t* out, uint32_t* acc, size_t n) {
-  finish_batch8(x25519_base_finish_policy{out, acc, n}, acc);
+k_x25519_base_finish(uint8_t* out, uint32_t* acc, size_t n, int K) {
+  finish_batch8(x25519_base_finish_policy{out, acc, n, K}, acc);
 }
 
 __global__ void __launch_bounds__(BLOCK, 2)
@@ -805,6 +806,16 @@ __global__ void __launch_bounds__(BLOCK) k_debug_halve(uint8_t* out, const uint8
 
 using namespace ed;
 
+// Items per lane that share one inversion in the finish kernels: FINISH_K (8) in a pass that fills the chip; in a smaller
+// pass as few as it takes to keep one block of 256 lanes per CU - a lane with one item runs 31 k dependent instructions,
+// with eight 70 k, and a pass of 2^12 items would otherwise occupy two CUs.
+static unsigned finish_k(size_t n) {
+  const size_t tiles = (n + BLOCK - 1) / BLOCK;
+  for (unsigned k = 1; k < (unsigned)FINISH_K; k *= 2)
+    if ((tiles + k - 1) / k <= 256) return k;
+  return FINISH_K;
+}
+
 extern "C" {
 
 hipError_t edk_init_tables(uint32_t* base16, uint32_t* comb, uint32_t* comb_img, hipStream_t stream) {
@@ -823,7 +834,7 @@ hipError_t edk_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* point
                        scalars, points, n);
   else
     hipLaunchKernelGGL(k_x25519_ladder, dim3(blocks), dim3(BLOCK), 0, stream, ws->acc, scalars, points, n);
-  hipLaunchKernelGGL(k_x25519_finish, dim3((blocks + FINISH_K - 1) / FINISH_K), dim3(BLOCK), 0, stream, out, ws->acc, n);
+  hipLaunchKernelGGL(k_x25519_finish, dim3((blocks + finish_k(n) - 1) / finish_k(n)), dim3(BLOCK), 0, stream, out, ws->acc, n, (int)finish_k(n));
   return hipGetLastError();
 }
 
@@ -902,8 +913,8 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
     else
       hipLaunchKernelGGL(k_verify_main, dim3(blocks), dim3(BLOCK), MAIN_LDS_RESERVE, stream, ws->digits, ws->table, base16, ws->acc);
     if (marks) (void)hipEventRecord(marks[2], stream);
-    hipLaunchKernelGGL(k_verify_finish, dim3((blocks + FINISH_K - 1) / FINISH_K), dim3(BLOCK), 0, stream, ok, src.sigs,
-                       src.sig_stride, ws->acc, ws->flags, n, ws->exact_offcurve);
+    hipLaunchKernelGGL(k_verify_finish, dim3((blocks + finish_k(n) - 1) / finish_k(n)), dim3(BLOCK), 0, stream, ok, src.sigs,
+                       src.sig_stride, ws->acc, ws->flags, n, ws->exact_offcurve, (int)finish_k(n));
     if (marks) (void)hipEventRecord(marks[3], stream);
   }
   // everything that fills the chip has been queued; what follows on this stream only waits for the exact path's few
@@ -920,14 +931,20 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
 
 #define EDK_GRID(n) dim3((unsigned)(((n) + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream
 
-#define EDK_POINT_GRID(n) dim3((unsigned)(((n) + POINT_BLOCK - 1) / POINT_BLOCK)), dim3(POINT_BLOCK), 0, stream
-#define EDK_FINISH_GRID(n) dim3((unsigned)((((n) + BLOCK - 1) / BLOCK + FINISH_K - 1) / FINISH_K)), dim3(BLOCK), 0, stream
+// Point kernels stage the comb in LDS per block, one block per CU.  A pass that fills the chip runs blocks of POINT_BLOCK
+// lanes (two waves per SIMD).  A smaller pass runs smaller blocks: a block of 512 lanes puts two waves on every SIMD of
+// ONE CU, which then take turns (a single ed25519_genpub ran its one useful wave beside seven idle-lane waves redoing
+// the same item: 0.23 ms in the point kernel against 0.12 with a wave to itself), and 4096 items occupied 8 CUs of 256.
+// So: the smallest block that covers the pass with one block per CU - one, two or four waves, each with a SIMD to itself.
+#define POINT_LANES(n) ((n) <= (size_t)64 * 256 ? 64 : (n) <= (size_t)128 * 256 ? 128 : (n) <= (size_t)256 * 256 ? 256 : POINT_BLOCK)
+#define EDK_POINT_GRID(n) dim3((unsigned)(((n) + POINT_LANES(n) - 1) / POINT_LANES(n))), dim3(POINT_LANES(n)), 0, stream
+#define EDK_FINISH_GRID(n) dim3((unsigned)((((n) + BLOCK - 1) / BLOCK + finish_k(n) - 1) / finish_k(n))), dim3(BLOCK), 0, stream
 
 hipError_t edk_genpub(uint8_t* pubs, const uint8_t* secs, size_t n, const uint32_t* comb,
                       const edk_fixed_ws* ws, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_genpub_point, EDK_POINT_GRID(n), ws->acc, secs, n, comb);
-  hipLaunchKernelGGL(k_encode_finish, EDK_FINISH_GRID(n), pubs, ws->acc, n);
+  hipLaunchKernelGGL(k_encode_finish, EDK_FINISH_GRID(n), pubs, ws->acc, n, (int)finish_k(n));
   return hipGetLastError();
 }
 
@@ -936,7 +953,7 @@ hipError_t edk_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, con
                     const edk_fixed_ws* ws, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_sign_point, EDK_POINT_GRID(n), ws->acc, ws->aux, secs, msgs, msg_off, msg_len, n, comb);
-  hipLaunchKernelGGL(k_sign_finish, EDK_FINISH_GRID(n), sigs, ws->acc, ws->aux, pubs, msgs, msg_off, msg_len, n);
+  hipLaunchKernelGGL(k_sign_finish, EDK_FINISH_GRID(n), sigs, ws->acc, ws->aux, pubs, msgs, msg_off, msg_len, n, (int)finish_k(n));
   return hipGetLastError();
 }
 
@@ -944,7 +961,7 @@ hipError_t edk_x25519_base(uint8_t* out, const uint8_t* scalars, size_t n, const
                            const edk_fixed_ws* ws, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_x25519_base_point, EDK_POINT_GRID(n), ws->acc, scalars, n, comb);
-  hipLaunchKernelGGL(k_x25519_base_finish, EDK_FINISH_GRID(n), out, ws->acc, n);
+  hipLaunchKernelGGL(k_x25519_base_finish, EDK_FINISH_GRID(n), out, ws->acc, n, (int)finish_k(n));
   return hipGetLastError();
 }
 

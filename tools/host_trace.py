@@ -10,7 +10,7 @@ import libeddsa_amd as ed
 import workload
 ed.init(0)
 op = sys.argv[1] if len(sys.argv) > 1 else "verify"
-n = 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else (10 if op == "verify1" else 20))
+n = 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else (10 if op.endswith("1") else 20))
 sk, msg = workload.sign_inputs(n, seed=1, config=2)
 pk = ed.ed25519_genpub_batch(sk)
 sig = ed.ed25519_sign_batch(sk, pk, msg)
@@ -18,7 +18,10 @@ workload.corrupt_for_verify(sig, pk, msg)
 sc, pt = workload.x25519_inputs(n)
 fn = {"verify": lambda: ed.ed25519_verify_batch(sig, pk, msg), "x25519": lambda: ed.x25519_batch(sc, pt),
       "sign": lambda: ed.ed25519_sign_batch(sk, pk, msg),
-      "verify1": lambda: ed.ed25519_verify(sig[0].tobytes(), pk[0].tobytes(), msg[0].tobytes())}[op]
+      "verify1": lambda: ed.ed25519_verify(sig[0].tobytes(), pk[0].tobytes(), msg[0].tobytes()),
+      "sign1": lambda: ed.ed25519_sign(sk[0].tobytes(), pk[0].tobytes(), msg[0].tobytes()),
+      "genpub1": lambda: ed.ed25519_genpub(sk[0].tobytes()),
+      "x255191": lambda: ed.x25519(sc[0].tobytes(), pt[0].tobytes())}[op]
 import ctypes
 lib = ed.library()
 tags, chunks, ms = (ctypes.c_int * 512)(), (ctypes.c_uint * 512)(), (ctypes.c_double * 512)()
