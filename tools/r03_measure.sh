@@ -12,6 +12,9 @@ echo
 echo "== tools/verify_small.py: one pass, device-resident, ms"
 python3 tools/verify_small.py 2>&1 | grep "algo 0"
 echo
+echo "== tools/fixed_small.py: one pass of the fixed-base operations, device-resident, ms"
+python3 tools/fixed_small.py 2>&1 | grep -v amdgpu.ids
+echo
 echo "== tools/chunked_device.py: what chunking alone costs (no copies)"
 python3 tools/chunked_device.py 2>&1 | grep -v amdgpu.ids
 echo
