@@ -238,6 +238,7 @@ struct hjob {
     int chain;                                 /* the kernels of consecutive chunks run in chunk order (else side by side) */
     int kind;                                  /* combiner slot (engine.h: COMB_KINDS): small calls of this operation may be merged; 0: never */
     int src_pinned;                            /* every host array of the job is page-locked: no staging */
+    int traced;                                /* the caller (the combiner's leader) has started the call's trace already */
 };
 
 static int dev_grow(void **buf, size_t *cap, size_t need)
@@ -273,11 +274,12 @@ static int pipe_init(struct pipe *p)
     int rc = 0;
     if (p->ready) return 0;
     for (int l = 0; l < PIPE_LANES; l++) {
-        TRY(hipStreamCreateWithFlags(&p->lane[l].st, hipStreamNonBlocking));
-        TRY(hipEventCreateWithFlags(&p->lane[l].kdone, hipEventDisableTiming));
+        /* (a call that failed half-way through here is retried by the next one: what exists is kept) */
+        if (!p->lane[l].st) TRY(hipStreamCreateWithFlags(&p->lane[l].st, hipStreamNonBlocking));
+        if (!p->lane[l].kdone) TRY(hipEventCreateWithFlags(&p->lane[l].kdone, hipEventDisableTiming));
     }
-    TRY(hipMalloc((void **)&p->d_stats, 256));
-    TRY(hipHostMalloc((void **)&p->h_stats, 256, hipHostMallocDefault));
+    if (!p->d_stats) TRY(hipMalloc((void **)&p->d_stats, 256));
+    if (!p->h_stats) TRY(hipHostMalloc((void **)&p->h_stats, 256, hipHostMallocDefault));
     p->ready = 1;
 out:
     return rc;
@@ -420,7 +422,8 @@ static double trace_now(void)
 
 /* on != 0: record host-side time stamps in every host-pointer call from now on; returns the number of stamps of the last
  * call and copies up to `max` of them: tag (0 call start, 1 lane drained, 2 inputs staged and queued, 3 kernels queued,
- * 4 download queued, 5 all lanes drained, 6 call end), chunk index, milliseconds since the call started */
+ * 4 download queued, 5 all lanes drained, 6 call end; of a combined launch also 7 leader elected, 8 callers gathered,
+ * 9 requests packed, 10 results handed back), chunk index, milliseconds since the call started */
 int eddsa_amd_debug_pipe_trace(int on, int *tags, unsigned *chunks, double *ms, int max)
 {
     pthread_rwlock_wrlock(&g_table);
@@ -467,7 +470,7 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
     const int base = lanes_acquire(e, all);
     if (base < 0) return base;
 #define LANE_OF(k) (&p->lane[all ? (k) % PIPE_LANES : (unsigned)base])
-    g_trace.n = 0;
+    if (g_trace.on && !j->traced) g_trace.n = 0;
     TRACE(0, 0);
     {
         struct lane *prev = NULL;
@@ -655,6 +658,8 @@ static int combiner_run(struct engine *e, struct comb_kind *K, struct creq *batc
     big.out = (uint8_t *)K->h_out;
     big.kind = 0;
     big.src_pinned = 1;
+    big.traced = 1;
+    TRACE(9, (unsigned)total);
     rc = pipe_run_on(e, &big, total);
     at = 0;
     for (struct creq *r = batch; r && !rc; r = r->next) {
@@ -664,6 +669,7 @@ static int combiner_run(struct engine *e, struct comb_kind *K, struct creq *batc
     /* the packed copies of secrets go as well */
     if (j0->wipe & WIPE_IN0) memset(K->h_in[0], 0, total * j0->in_w[0]);
     if (j0->wipe & WIPE_OUT) memset(K->h_out, 0, total * j0->out_w);
+    TRACE(10, (unsigned)total);
     return rc;
 }
 
@@ -703,6 +709,8 @@ static int combiner_submit(struct engine *e, const struct hjob *j, size_t n)
             continue;
         }
         K->active = 1;
+        if (g_trace.on) g_trace.n = 0;
+        TRACE(7, 0);
         /* Under contention the callers of the launch that has just finished are about to queue again (they do within
          * microseconds of being woken): give them a moment, or the callers split into two camps that take turns and
          * every launch carries half of them.  Expected: whoever was already waiting when that launch ended, plus the
@@ -722,6 +730,7 @@ static int combiner_submit(struct engine *e, const struct hjob *j, size_t n)
         }
         /* everything queued for this operation (this thread's own request is among it unless thousands are ahead of it:
          * then it leads again) */
+        TRACE(8, K->queued);
         struct creq *batch = NULL, *btail = NULL, **pp = &q->head, *last = NULL;
         size_t total = 0, reqs = 0;
         while (*pp) {
@@ -740,7 +749,9 @@ static int combiner_submit(struct engine *e, const struct hjob *j, size_t n)
         }
         q->tail = last;
         pthread_mutex_unlock(&q->lk);
-        const int rc = reqs == 1 && batch == &me ? pipe_run_on(e, j, n) : combiner_run(e, K, batch, total);
+        struct hjob own = *j;
+        own.traced = 1;
+        const int rc = reqs == 1 && batch == &me ? pipe_run_on(e, &own, n) : combiner_run(e, K, batch, total);
         pthread_mutex_lock(&q->lk);
         q->batches++; q->items += reqs;
         K->last_reqs = (unsigned)reqs;

@@ -98,7 +98,7 @@ k_x25519_ladder(uint32_t* accout, const uint8_t* scalars, const uint8_t* points,
 }
 
 // small passes: four lanes per item (quad_lanes.h: x25519_ladder_quad); writes the same workspace slots
-constexpr size_t X25519_QUAD_MAX_N = (size_t)1 << 13;
+constexpr size_t X25519_QUAD_MAX_N = (size_t)1 << 14;
 __global__ void __launch_bounds__(BLOCK, 2)
 k_x25519_ladder_quad(uint32_t* accout, const uint8_t* scalars, const uint8_t* points, size_t n) {
   const size_t i = ((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 2;          // quads are all-or-nothing

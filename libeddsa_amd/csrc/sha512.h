@@ -39,24 +39,67 @@ ED_DEV constexpr uint64_t sha512_k(int r) {
   return SHA512_K[r];
 }
 
-ED_DEV uint64_t rotr64(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+// 64-bit rotation, n a constant in 1..63 other than 32.  On the device: two v_alignbit_b32 (hipcc expands the portable
+// form into 64-bit shifts and an OR, 3.2 instructions per rotation on average; a compression has 736 rotations)
+ED_DEV uint64_t rotr64(uint64_t x, int n) {
+#ifdef ED_HOST_CHECK
+  return (x >> n) | (x << (64 - n));
+#else
+  const uint32_t lo = (uint32_t)(n < 32 ? x : x >> 32), hi = (uint32_t)(n < 32 ? x >> 32 : x);
+  const uint32_t rl = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(n & 31)), rh = __builtin_amdgcn_alignbit(lo, hi, (uint32_t)(n & 31));
+  return ((uint64_t)rh << 32) | rl;
+#endif
+}
+
+// Maj(a, b, c) = (a & b) ^ (a & c) ^ (b & c): c where a and b differ, b where they agree - a bit select under a ^ b.
+// hipcc turns every C spelling of it back into two ANDs and two XORs per half; v_bfi_b32 is one.
+ED_DEV uint64_t sha512_maj(uint64_t a, uint64_t b, uint64_t c) {
+#ifdef ED_HOST_CHECK
+  return (a & b) ^ (a & c) ^ (b & c);
+#else
+  const uint64_t x = a ^ b;
+  uint32_t lo, hi;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(lo) : "v"((uint32_t)x), "v"((uint32_t)c), "v"((uint32_t)b));
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hi) : "v"((uint32_t)(x >> 32)), "v"((uint32_t)(c >> 32)), "v"((uint32_t)(b >> 32)));
+  return ((uint64_t)hi << 32) | lo;
+#endif
+}
+
+// sha512.c:83-124 compress, one round.  The NAMES a..h rotate over s[] instead of the values (round R's a is
+// s[(80 - R) & 7]), and the rounds are instantiated one by one rather than unrolled from a loop: with the intrinsic
+// rotations the body of an 80-round loop is past the size up to which hipcc honours `#pragma unroll`, and the rolled
+// loop it then emits indexes w[] and the constants through s_set_gpr_idx.
+template <int R>
+ED_DEV void sha512_round(uint64_t (&s)[8], uint64_t (&w)[16]) {
+  constexpr int o = (80 - R) & 7;
+  const uint64_t a = s[o], b = s[(o + 1) & 7], c = s[(o + 2) & 7], e = s[(o + 4) & 7], f = s[(o + 5) & 7], g = s[(o + 6) & 7];
+  if (R >= 16) {
+    const uint64_t w15 = w[(R + 1) & 15], w2 = w[(R + 14) & 15];
+    w[R & 15] += (rotr64(w15, 1) ^ rotr64(w15, 8) ^ (w15 >> 7)) + w[(R + 9) & 15] +
+                 (rotr64(w2, 19) ^ rotr64(w2, 61) ^ (w2 >> 6));
+  }
+  const uint64_t t1 = s[(o + 7) & 7] + (rotr64(e, 14) ^ rotr64(e, 18) ^ rotr64(e, 41)) + ((e & f) ^ (~e & g)) +
+                      sha512_k(R) + w[R & 15];
+  const uint64_t t2 = (rotr64(a, 28) ^ rotr64(a, 34) ^ rotr64(a, 39)) + sha512_maj(a, b, c);
+  s[(o + 3) & 7] += t1;                          // e of the next round
+  s[(o + 7) & 7] = t1 + t2;                      // a of the next round
+}
+template <int R>
+ED_DEV void sha512_rounds_from(uint64_t (&s)[8], uint64_t (&w)[16]) {
+  if constexpr (R < 80) {
+    sha512_round<R>(s, w);
+    sha512_rounds_from<R + 1>(s, w);
+  }
+}
 
 // sha512.c:83-124 compress; w[] is consumed (used as the schedule ring)
 ED_DEV void sha512_compress(uint64_t st[8], uint64_t w[16]) {
-  uint64_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+  uint64_t s[8], (&wr)[16] = *reinterpret_cast<uint64_t (*)[16]>(w);
 #pragma unroll
-  for (int r = 0; r < 80; r++) {
-    if (r >= 16) {
-      const uint64_t w15 = w[(r + 1) & 15], w2 = w[(r + 14) & 15];
-      w[r & 15] += (rotr64(w15, 1) ^ rotr64(w15, 8) ^ (w15 >> 7)) + w[(r + 9) & 15] +
-                   (rotr64(w2, 19) ^ rotr64(w2, 61) ^ (w2 >> 6));
-    }
-    const uint64_t t1 = h + (rotr64(e, 14) ^ rotr64(e, 18) ^ rotr64(e, 41)) + ((e & f) ^ (~e & g)) +
-                        sha512_k(r) + w[r & 15];
-    const uint64_t t2 = (rotr64(a, 28) ^ rotr64(a, 34) ^ rotr64(a, 39)) + ((a & b) ^ (a & c) ^ (b & c));
-    h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
-  }
-  st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+  for (int i = 0; i < 8; i++) s[i] = st[i];
+  sha512_rounds_from<0>(s, wr);
+#pragma unroll
+  for (int i = 0; i < 8; i++) st[i] += s[i];
 }
 
 ED_DEV uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }

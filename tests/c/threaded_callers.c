@@ -5,8 +5,9 @@
  * operation are merged into one GPU launch (host_pipe.c: the combiner); every caller must still get exactly its
  * own result.  Checks every result against the golden table and prints the aggregate rates.
  *
- * usage: threaded_callers <ed25519_table.bin> <ed25519_msgs.bin> <x25519_table.bin> [threads [iterations [entries]]]
- *        (entries: only the first so many table entries are used, i.e. messages shorter than that; default all 1024)
+ * usage: threaded_callers <ed25519_table.bin> <ed25519_msgs.bin> <x25519_table.bin> [threads [iterations [entries [trace]]]]
+ *        (entries: only the first so many table entries are used, i.e. messages shorter than that; default all 1024;
+ *         trace: also print the host-side time stamps of the last combined launch of the verify loop)
  * exit status 0 = every result was right.
  */
 #define _POSIX_C_SOURCE 200809L
@@ -106,9 +107,16 @@ int main(int argc, char **argv)
     uint8_t warm[32];
     ed25519_genpub(warm, g_et);         /* builds the engine (tables) before the clock starts */
     int bad = 0;
+    const int trace = argc > 7;
+    int tags[64]; unsigned chunks[64]; double ms[64];
     g_mode = 0;
     bad |= run(1, "ed25519_verify, one caller");
+    if (trace) eddsa_amd_debug_pipe_trace(1, tags, chunks, ms, 0);
     bad |= run(threads, "ed25519_verify");
+    if (trace) {
+        const int k = eddsa_amd_debug_pipe_trace(0, tags, chunks, ms, 64);
+        for (int i = 0; i < k; i++) printf("  stamp %d  %8.3f ms\n", tags[i], ms[i]);
+    }
     g_mode = 1;
     bad |= run(threads, "verify / sign / x25519 / genpub by thread");
     eddsa_amd_shutdown();

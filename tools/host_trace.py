@@ -32,6 +32,6 @@ time.sleep(0.05)
 t0 = time.perf_counter(); fn(); dt = time.perf_counter() - t0
 print(f"{op}: {dt*1e3:.2f} ms host to host, {n/dt/1e6:.1f} M/s")
 k = lib.eddsa_amd_debug_pipe_trace(0, tags, chunks, ms, 512)
-names = ["call start", "lane drained", "inputs staged+queued", "kernels queued", "download queued", "all lanes drained", "call end"]
+names = ["call start", "lane drained", "inputs staged+queued", "kernels queued", "download queued", "all lanes drained", "call end", "leader elected", "callers gathered", "requests packed", "results handed back"]
 for i in range(k):
     print(f"  host {ms[i]:8.3f} ms  chunk {chunks[i]}  {names[tags[i]]}")
