@@ -715,25 +715,26 @@ k_sk_to_x(uint8_t* out, const uint8_t* in, size_t n) {
 
 // ---------------------------------------------------------------------------------------------
 // The half-length route for SMALL passes (up to QUAD_MAIN_MAX_N items), where what counts is the latency of one
-// item: k_verify_prepare_pair does the work of k_verify_prepare + k_verify_halve with two lanes per item - both
-// hash and search the pair (the same values twice, no divergence), then lane 0 decompresses A and builds its table
-// while lane 1 does the same for R - and k_verify_main_half_quad is verify_half_main_lane with a coordinate per
+// item: k_verify_prepare_pair does the work of k_verify_prepare + k_verify_halve with three lanes per item in two kinds
+// of blocks - the points' blocks, where lane 0 of a pair decompresses A and builds its table while lane 1 does the same
+// for R, and the scalars' blocks, where one lane hashes and searches the pair (nothing of the one depends on the other:
+// a single item's 0.13 ms became 0.09) - and k_verify_main_half_quad is verify_half_main_lane with a coordinate per
 // lane (quad_lanes.h).  Two kernels, 132 doublings and no inversion instead of three, 252 and one.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(BLOCK, 2)
 k_verify_prepare_pair(edk_verify_src src, size_t n, uint32_t* digits, uint32_t* hdigits, uint32_t* table, uint32_t* rtable,
-                      uint8_t* flags, uint32_t* offlist, uint32_t* offcount, int all_exact) {
-  const size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  const size_t i = g >> 1;                       // pairs are all-or-nothing
-  if (i >= n) return;
-  const bool second = (g & 1) != 0;
-  uint32_t rw[8], aw[8], sw[8], tw[8], hd[HALF_DIGIT_WORDS];
-  const uint8_t* m; size_t mlen;
-  verify_item(rw, sw, aw, m, mlen, src, i);
-  verify_hash_lane(tw, rw, aw, m, mlen);
-  verify_s_lane(sw);
-  verify_half_scalars_lane(hd, tw, sw);
-  if (!second) {
+                      uint8_t* flags, uint32_t* offlist, uint32_t* offcount, int all_exact, unsigned point_blocks) {
+  if (blockIdx.x >= point_blocks) {
+    // the scalars' blocks, one lane per item: hash, reduce, search the pair.  They need nothing from the points' blocks
+    // and those nothing from here: the two square-root chains of an item run BESIDE its hash and its search
+    const size_t i = (size_t)(blockIdx.x - point_blocks) * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t rw[8], aw[8], sw[8], tw[8], hd[HALF_DIGIT_WORDS];
+    const uint8_t* m; size_t mlen;
+    verify_item(rw, sw, aw, m, mlen, src, i);
+    verify_hash_lane(tw, rw, aw, m, mlen);
+    verify_s_lane(sw);
+    verify_half_scalars_lane(hd, tw, sw);
     uint4* d = reinterpret_cast<uint4*>(digits + 16 * i);
     d[0] = make_uint4(tw[0], tw[1], tw[2], tw[3]); d[1] = make_uint4(tw[4], tw[5], tw[6], tw[7]);
     d[2] = make_uint4(sw[0], sw[1], sw[2], sw[3]); d[3] = make_uint4(sw[4], sw[5], sw[6], sw[7]);
@@ -741,11 +742,15 @@ k_verify_prepare_pair(edk_verify_src src, size_t n, uint32_t* digits, uint32_t* 
 #pragma unroll
     for (int q = 0; q < HALF_DIGIT_WORDS / 4; q++) o[q] = make_uint4(hd[4 * q], hd[4 * q + 1], hd[4 * q + 2], hd[4 * q + 3]);
     if ((hd[24] & 4u) != 0) atomicAdd(offcount + EDK_REFUSED_WORD, 1u);
+    return;
   }
+  const size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const size_t i = g >> 1;                       // pairs are all-or-nothing
+  if (i >= n) return;
+  const bool second = (g & 1) != 0;
   // lane 0: -A permissively (ed.c:100-149), lane 1: -R' strictly (lanes.h: verify_half_point_lane)
   uint32_t pw[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) pw[k] = second ? rw[k] : aw[k];
+  load32(pw, second ? src.sigs : src.pubs, i, second ? src.sig_stride : src.pub_stride);
   uint32_t* tab = (second ? rtable : table) + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS);
   bool oncurve;
   ge p;
@@ -860,8 +865,9 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   const bool half = algo == 2 || (algo == 0 && !small_half);
   const bool half_quad = algo == 0 && small_half;
   if (half_quad)
-    hipLaunchKernelGGL(k_verify_prepare_pair, dim3((unsigned)((2 * n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, src, n,
-                       ws->digits, ws->hdigits, ws->table, ws->rtable, ws->flags, ws->offlist, ws->offcount, ws->exact_offcurve == 2);
+    hipLaunchKernelGGL(k_verify_prepare_pair, dim3((unsigned)((2 * n + BLOCK - 1) / BLOCK + (n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, src, n,
+                       ws->digits, ws->hdigits, ws->table, ws->rtable, ws->flags, ws->offlist, ws->offcount, ws->exact_offcurve == 2,
+                       (unsigned)((2 * n + BLOCK - 1) / BLOCK));
   else
     hipLaunchKernelGGL(k_verify_prepare, dim3(blocks), dim3(BLOCK), 0, stream, src, n, ws->digits, ws->table, ws->flags, ws->offlist, ws->offcount,
                        ws->exact_offcurve == 2);
