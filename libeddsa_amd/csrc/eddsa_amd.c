@@ -66,9 +66,10 @@ static void ws_release(struct vslot *v)
     if (v->ws.offlist) (void)hipFree(v->ws.offlist);
     if (v->ws.offcount) (void)hipFree(v->ws.offcount);
     if (v->ws.exact_pad) (void)hipFree(v->ws.exact_pad);
+    if (v->ws.sums) (void)hipFree(v->ws.sums);
     v->ws.capacity = 0;
     v->ws.digits = v->ws.table = v->ws.acc = v->ws.offlist = v->ws.offcount = v->ws.exact_pad = NULL;
-    v->ws.hdigits = v->ws.rtable = NULL;
+    v->ws.hdigits = v->ws.rtable = v->ws.sums = NULL;
     v->ws.flags = NULL;
 }
 
@@ -132,6 +133,7 @@ static int ws_reserve(struct vslot *v, size_t items)
     TRY(hipMemset(v->ws.offcount, 0, 256));
     TRY(hipStreamSynchronize(NULL));      /* the pass's stream does not wait for the null stream */
     TRY(hipMalloc((void **)&v->ws.exact_pad, EDK_EXACT_PAD_BYTES));
+    TRY(hipMalloc((void **)&v->ws.sums, EDK_SUMS_BYTES));
     v->ws.capacity = cap;
 out:
     if (rc) ws_release(v);

@@ -31,6 +31,8 @@ extern "C" {
 
 hipError_t edk_init_tables(uint32_t* base16, uint32_t* comb, uint32_t* comb_img, hipStream_t stream);
 
+#define EDK_SUMS_MAX_ITEMS ((size_t)1 << 11)          /* passes of up to this many items add their windows' sums first (kernels.hip: k_verify_window_sums) */
+#define EDK_SUMS_BYTES (EDK_SUMS_MAX_ITEMS * 64 * 40 * sizeof(uint32_t))   /* 64 windows x four multipliers of ten limbs per item */
 #define EDK_EXACT_PAD_BYTES ((size_t)65536 * 1536)   /* 65536 work-list entries x (four addends x five factors + two digit strings), >= the one-lane kernel's 1024 x 64 lanes x 292 words */
 
 /* verify workspace for up to `capacity` items (a multiple of VERIFY_TILE), all in HBM */
@@ -46,6 +48,7 @@ typedef struct edk_verify_ws {
   uint32_t* offcount; /* 64 words, zeroed at allocation: [0] the length of offlist (zeroed by every pass), [EDK_REFUSED_WORD] half-length
                          pairs that the exact check of lanes.h: verify_half_scalars_lane refused since allocation (diagnostic) */
   uint32_t* exact_pad;/* EDK_EXACT_PAD_BYTES: per-lane scratchpad of k_verify_exact */
+  uint32_t* sums;     /* EDK_SUMS_BYTES: the windows' sums of a small pass */
   hipStream_t side;   /* the exact path runs here, beside the main kernel */
   hipEvent_t ev_prepared, ev_exact;
   int algo;           /* 0: half-length scalars (four lanes per item up to 2^15 items, one above); 1: always full-length; 2: half-length, one lane per item */

@@ -786,6 +786,32 @@ k_verify_main_half_quad(uint8_t* ok, const uint32_t* hdigits, const uint32_t* ta
   ok[i] = (uint8_t)(neutral && (fl & 4) != 0);
 }
 
+// The smallest passes (quad_lanes.h: verify_half_window_sum_quad): block i adds up the 64 windows of item i, one quad each;
+// then the chain over the sums.
+__global__ void __launch_bounds__(QUAD_BLOCK, 2)
+k_verify_window_sums(uint32_t* sums, const uint32_t* hdigits, const uint32_t* table, const uint32_t* rtable, const uint32_t* base16) {
+  const size_t i = blockIdx.x;
+  const int w = (int)(threadIdx.x >> 2), q = (int)(threadIdx.x & 3u);
+  verify_half_window_sum_quad(sums + (i * HALF_LONG_WINDOWS + (size_t)w) * HALF_SUM_WORDS, hdigits + HALF_DIGIT_WORDS * i,
+                              table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
+                              base16, w, q);
+}
+
+__global__ void __launch_bounds__(QUAD_BLOCK, 2)
+k_verify_main_sums_quad(uint8_t* ok, const uint32_t* hdigits, const uint32_t* sums, const uint8_t* flags, size_t n, int exact_offcurve) {
+  const size_t i = ((size_t)blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;      // quads are all-or-nothing
+  if (i >= n) return;
+  const int q = (int)(threadIdx.x & 3u);
+  const bool neutral = verify_half_main_sums_quad(hdigits + HALF_DIGIT_WORDS * i, sums + i * (HALF_LONG_WINDOWS * HALF_SUM_WORDS), q);
+  if (q != 0) return;
+  const uint8_t fl = flags[i];
+  if ((fl & 1) == 0) {                           // the exact path owns this verdict
+    if (!exact_offcurve) ok[i] = 0;
+    return;
+  }
+  ok[i] = (uint8_t)(neutral && (fl & 4) != 0);
+}
+
 // diagnostic (eddsa_amd_debug_halve): halve_scalar_lane on the device for given t; out = v (20 bytes) | |u| (20) |
 // u < 0 (1) | found (1) | 6 bytes of padding per item
 template <int BITS>
@@ -894,7 +920,13 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
                        src.sigs, src.sig_stride, ws->digits, ws->table, ws->offlist, ws->offcount, base16, ws->exact_pad);
     (void)hipEventRecord(ws->ev_exact, ws->side);
   }
-  if (half_quad) {
+  if (half_quad && n <= EDK_SUMS_MAX_ITEMS) {
+    static_assert(QUAD_BLOCK == 4 * HALF_LONG_WINDOWS, "a block of k_verify_window_sums is the windows of one item");
+    hipLaunchKernelGGL(k_verify_window_sums, dim3((unsigned)n), dim3(QUAD_BLOCK), 0, stream, ws->sums, ws->hdigits, ws->table, ws->rtable, base16);
+    hipLaunchKernelGGL(k_verify_main_sums_quad, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, stream,
+                       ok, ws->hdigits, ws->sums, ws->flags, n, ws->exact_offcurve);
+    if (marks) { (void)hipEventRecord(marks[2], stream); (void)hipEventRecord(marks[3], stream); }
+  } else if (half_quad) {
     hipLaunchKernelGGL(k_verify_main_half_quad, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, stream,
                        ok, ws->hdigits, ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
     if (marks) { (void)hipEventRecord(marks[2], stream); (void)hipEventRecord(marks[3], stream); }

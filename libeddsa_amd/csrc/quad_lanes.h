@@ -293,7 +293,7 @@ ED_DEV void quad_add_entry(fe& r, const uint32_t* e, bool neg, bool has_z2, int 
     quad_coord_load(mult, e + 10 * co);
     fe two; fe_set(two, 2); fe_cmov(mult, two, q == 3);
   }
-  fe_neg(nm, mult); fe_carry(nm);
+  fe_neg(nm, mult);                              // < 2u: within the second operand's bound
   fe_cmov(mult, nm, neg && q == 2);
   quad_stage_a_operand(first, r, q);
   fe_mul(m, first, mult);
@@ -335,15 +335,33 @@ ED_DEV bool verify_half_main_quad(const uint32_t* hd, const uint32_t* tab_a, con
   const int top = (__any(is_long) ? HALF_LONG_WINDOWS : HALF_WINDOWS) - 1;   // the wave's loop (lanes.h: verify_half_main_lane)
 #pragma unroll 1
   for (int w = top; w >= 0; w--) {
+    // the lane's coordinate of the window's two per-item entries: requested before the doublings, consumed after them
+    uint32_t raw[2][8];
+    bool neg[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int dig = (int)((hd[8 * h + (w >> 3)] >> (4 * (w & 7))) & 15u) - 8;
+      const uint32_t mag = (uint32_t)(dig < 0 ? -dig : dig);
+      neg[h] = (dig < 0) != (h == 0 && uneg);
+      const int co = q == 0 ? (neg[h] ? 1 : 0) : q == 1 ? (neg[h] ? 0 : 1) : q;
+      const word4* p = reinterpret_cast<const word4*>((h ? tab_r : tab_a) + mag * VERIFY_ENTRY_WORDS + 8 * co);
+      const word4 a = p[0], b = p[1];
+      raw[h][0] = a.x; raw[h][1] = a.y; raw[h][2] = a.z; raw[h][3] = a.w;
+      raw[h][4] = b.x; raw[h][5] = b.y; raw[h][6] = b.z; raw[h][7] = b.w;
+    }
     if (w != top) {
 #pragma unroll 1
       for (int k = 0; k < 4; k++) quad_dbl(r, q);
     }
 #pragma unroll 1
     for (int h = 0; h < 2; h++) {                // h = 0: v on -A (sign of u applied), h = 1: |u| on -R'
-      const int dig = (int)((hd[8 * h + (w >> 3)] >> (4 * (w & 7))) & 15u) - 8;
-      const uint32_t mag = (uint32_t)(dig < 0 ? -dig : dig);
-      quad_add_entry(r, (h ? tab_r : tab_a) + mag * VERIFY_ENTRY_WORDS, (dig < 0) != (h == 0 && uneg), true, q);
+      fe mult, nm, first, m;
+      fe_unpack(mult, raw[h]);
+      fe_neg(nm, mult);
+      fe_cmov(mult, nm, neg[h] && q == 2);
+      quad_stage_a_operand(first, r, q);
+      fe_mul(m, first, mult);
+      quad_stage_b(r, m, q);
     }
     if ((w & 3) == 0) {
       const int j = w >> 2;
@@ -358,6 +376,98 @@ ED_DEV bool verify_half_main_quad(const uint32_t* hd, const uint32_t* tab_a, con
     }
   }
   // X = 0 (lane 0), Y = Z (lane 1 against lane 3), Z != 0 (lane 3); lane 2 (T) has no say
+  fe z, d;
+  fe_quad_perm<3, 3, 3, 3>(z, r);
+  fe_sub(d, r, z);
+  const bool mine = q == 0 ? fe_iszero(r) : q == 1 ? fe_iszero(d) : q == 3 ? !fe_iszero(r) : true;
+  const uint64_t votes = __ballot(mine);
+  const unsigned lane = __lane_id();
+  return ((votes >> (lane & ~3u)) & 0xfu) == 0xfu;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same evaluation for the SMALLEST passes (up to EDK_SUMS_MAX_ITEMS items), where the 66 + 16 additions of an item
+// are a third of its latency although none of them depends on the accumulator: the sum of a window's addends
+//   S_w = sigma d_w (-A) + e_w (-R') [+ the base point's entries of windows 0, 4, 8, ...]
+// is computed for all windows of all items AT ONCE (k_verify_window_sums: one quad per window, a few additions deep),
+// and the chain is 132 doublings and 34 additions of a ready sum instead of 82 additions with lookups in between.
+// The result is the same group element (the addition law is complete on the curve's points, the order of additions
+// does not matter), so the same verdict.
+// ---------------------------------------------------------------------------------------------
+
+#define HALF_SUM_WORDS 40                              /* a sum as its four stage-A multipliers y-x | y+x | 2d*t | 2z, ten limbs each */
+
+// S_w of one item as multipliers at `out`; q = lane & 3.  hd, tab_a, tab_r as for verify_half_main_quad.
+ED_DEV void verify_half_window_sum_quad(uint32_t* out, const uint32_t* hd, const uint32_t* tab_a, const uint32_t* tab_r,
+                                        const uint32_t* base16, int w, int q) {
+  const bool uneg = (hd[24] & 1u) != 0, is_long = (hd[24] & 2u) != 0;
+  fe r;
+  if (w >= (is_long ? HALF_LONG_WINDOWS : HALF_WINDOWS)) {
+    fe_set(r, q == 3 ? 2u : q == 2 ? 0u : 1u);   // the neutral element's multipliers (1, 1, 0, 2): a wave with a long item runs 64 windows
+  } else {
+    {                                            // the neutral element plus an entry: stage A is (y-x, y+x, 0, 2z) itself
+      const int dig = (int)((hd[w >> 3] >> (4 * (w & 7))) & 15u) - 8;
+      const uint32_t mag = (uint32_t)(dig < 0 ? -dig : dig);
+      const bool neg = (dig < 0) != uneg;
+      const int co = q == 0 ? (neg ? 1 : 0) : q == 1 ? (neg ? 0 : 1) : 3;
+      const word4* p = reinterpret_cast<const word4*>(tab_a + mag * VERIFY_ENTRY_WORDS + 8 * co);
+      const word4 a = p[0], b = p[1];
+      const uint32_t pw[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      fe m, zero;
+      fe_unpack(m, pw);
+      fe_carry(m);                               // (the packed top limb may hold a carry: tight again for the subtractions)
+      fe_set(zero, 0);
+      fe_cmov(m, zero, q == 2);
+      quad_stage_b(r, m, q);
+    }
+    {
+      const int dig = (int)((hd[8 + (w >> 3)] >> (4 * (w & 7))) & 15u) - 8;
+      const uint32_t mag = (uint32_t)(dig < 0 ? -dig : dig);
+      quad_add_entry(r, tab_r + mag * VERIFY_ENTRY_WORDS, dig < 0, true, q);
+    }
+    if ((w & 3) == 0) {                          // lanes.h: verify_half_main_lane - digit j of s' from k*B, digit 8 + j from k*2^128*B
+      const int j = w >> 2;
+#pragma unroll 1
+      for (int h = 0; h < (j < 8 ? 2 : 1); h++) {
+        const int jj = j + 8 * h;
+        int dig = (int)((hd[16 + (jj >> 1)] >> (16 * (jj & 1))) & 0xffffu) - 32768;
+        dig = (is_long ? h == 0 : j < 8) ? dig : 0;
+        const uint32_t mag = (uint32_t)(dig < 0 ? -dig : dig);
+        quad_add_entry(r, base16 + TABLE_ENTRY_WORDS * ((size_t)mag + (h ? (size_t)TABLE_BASE16_ENTRIES : 0)), dig < 0, false, q);
+      }
+    }
+    fe first, t2d, z2;                           // (X, Y, T, Z) -> (Y - X, Y + X, 2d T, 2 Z)
+    quad_stage_a_operand(first, r, q);           // < 3u
+    fe_mul(t2d, first, fe_const_2d());
+    fe_add(z2, first, first);                    // lane 3: 2Z, 2u
+    r = first;
+    fe_cmov(r, t2d, q == 2);
+    fe_cmov(r, z2, q == 3);
+    fe_carry(r);
+  }
+  word2* o = reinterpret_cast<word2*>(out + 10 * q);
+#pragma unroll
+  for (int j = 0; j < 5; j++) o[j] = word2{r.v[2 * j], r.v[2 * j + 1]};
+}
+
+// the chain over the sums; returns, in every lane of the quad, whether the result is the neutral element
+ED_DEV bool verify_half_main_sums_quad(const uint32_t* hd, const uint32_t* sums, int q) {
+  fe r;
+  fe_set(r, (uint32_t)(q & 1));                  // neutral element (0, 1, 0, 1) as (X, Y, T, Z)
+  const bool is_long = (hd[24] & 2u) != 0;
+  const int top = (__any(is_long) ? HALF_LONG_WINDOWS : HALF_WINDOWS) - 1;
+#pragma unroll 1
+  for (int w = top; w >= 0; w--) {
+    fe mult, first, m;
+    quad_coord_load(mult, sums + w * HALF_SUM_WORDS + 10 * q);   // requested before the doublings, consumed after them
+    if (w != top) {
+#pragma unroll 1
+      for (int k = 0; k < 4; k++) quad_dbl(r, q);
+    }
+    quad_stage_a_operand(first, r, q);
+    fe_mul(m, first, mult);
+    quad_stage_b(r, m, q);
+  }
   fe z, d;
   fe_quad_perm<3, 3, 3, 3>(z, r);
   fe_sub(d, r, z);

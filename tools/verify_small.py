@@ -10,7 +10,7 @@ for algo in (0, 1):
     ed.set_verify_algo(algo)
     for clean in (True, False):
         print(f"algo {algo} {'valid only   ' if clean else 'config-2 mix '}", end=" ")
-        for l in (17, 16, 15, 14, 13, 12, 10, 6, 0):
+        for l in (17, 16, 15, 14, 13, 12, 11, 10, 8, 6, 0):
             n = 1 << l
             sk, msg = workload.sign_inputs(n, seed=1, config=2)
             pk = ed.ed25519_genpub_batch(d(sk)); sig = ed.ed25519_sign_batch(d(sk), pk, d(msg)).cpu().numpy(); pk = pk.cpu().numpy()
