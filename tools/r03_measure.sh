@@ -15,6 +15,12 @@ echo
 echo "== tools/fixed_small.py: one pass of the fixed-base operations, device-resident, ms"
 python3 tools/fixed_small.py 2>&1 | grep -v amdgpu.ids
 echo
+echo "== tools/x25519_small.py: one x25519 pass, device-resident, ms"
+python3 tools/x25519_small.py 2>&1 | grep x25519
+echo
+echo "== tools/msglen_sweep.py: verify / sign against the message length, 2^18 items in HBM"
+python3 tools/msglen_sweep.py 2>&1 | grep msg_len
+echo
 echo "== tools/chunked_device.py: what chunking alone costs (no copies)"
 python3 tools/chunked_device.py 2>&1 | grep -v amdgpu.ids
 echo
