@@ -218,3 +218,9 @@ def test_small_passes_with_items_that_have_no_short_pair(engine, oracle):
     sig[long_items[-1], 33] ^= 4; want[long_items[-1]] = 0
     got = engine.ed25519_verify_batch(sig, pk, msg, msg_len=32)
     assert np.array_equal(got, want) and np.array_equal(oracle.verify_batch(sig, pk, msg, 32), want)
+    # the same items in the smallest passes (the windows' sums are added up first, 64 of them for an item without a
+    # pair): a few hundred items around each, the item with one neighbour, the item alone
+    for i in long_items[:3]:
+        for lo, hi in ((max(0, i - 150), min(n, i + 200)), (i & ~1, (i & ~1) + 2), (i, i + 1)):
+            got = engine.ed25519_verify_batch(sig[lo:hi].copy(), pk[lo:hi].copy(), msg[lo:hi].copy(), msg_len=32)
+            assert np.array_equal(got, want[lo:hi]), (i, lo, hi)
