@@ -27,7 +27,8 @@ Prints ONE JSON line on rank 0 (see the driver contract), with two extra objects
                 box's host cores on a bounded sample of the same workload (rank 0; at N > 1 the other ranks
                 sleep in a host-side barrier meanwhile)
 At N = 1 `secondary.verify_host_to_host` is the PCIe-inclusive rate of the same batch through the host-pointer entry
-point (for the record; `value` never includes transfers) and `secondary.verify_sustained` repeats the config-2 pass back to back for --sustained seconds (default 10)
+point (for the record; `value` never includes transfers), `secondary.verify_small_calls` the latency of one single-item
+call and of a batch of 256 through the same entry points, and `secondary.verify_sustained` repeats the config-2 pass back to back for --sustained seconds (default 10)
 and reports the rate of the last half with the power and clock rocm-smi shows: the headline region lasts 0.2 s,
 which a power-bound chip runs above its steady-state clock.  At N > 1 `per_rank` breaks the step down by rank
 (kernel ms, gather ms, wall ms, the slowest rank), so that a scaling point can be attributed.
@@ -550,6 +551,29 @@ def main():
             "metric": "ed25519 verifies/sec, PCIe-inclusive: numpy (malloc) arrays in, numpy array out, best of 5",
             "value": m / best, "unit": UNIT["verify"], "ms_per_call": best * 1e3, "items": m, "outputs_correct": good,
             "note": "not the headline: `value` is measured with inputs resident in HBM"}
+        # the drop-in side of the boundary: one call of the reference's single-item function (eddsa.h), host buffers,
+        # a pass of one item on the GPU; and a small batch, where the pass costs its latency whatever it carries
+        one = [hs[0].tobytes(), hp[0].tobytes(), hm[0].tobytes()]
+        for _ in range(20):
+            ok1 = ed.ed25519_verify(*one)
+        t0 = time.perf_counter()
+        for _ in range(200):
+            ok1 = ed.ed25519_verify(*one)
+        t_one = (time.perf_counter() - t0) / 200
+        sel = np.flatnonzero(w["expect"][:8192].cpu().numpy())[:256]     # 256 genuine signatures (a key off the curve adds the exact path's 0.5 ms)
+        s256, p256, m256 = (np.ascontiguousarray(a[sel]) for a in (hs, hp, hm))
+        for _ in range(5):
+            ok256 = ed.ed25519_verify_batch(s256, p256, m256, msg_len=32)
+        t0 = time.perf_counter()
+        for _ in range(50):
+            ok256 = ed.ed25519_verify_batch(s256, p256, m256, msg_len=32)
+        t_256 = (time.perf_counter() - t0) / 50
+        good = bool(ok1) == bool(w["expect"][0].item()) and len(sel) == 256 and bool(ok256.all())
+        correct = correct and good
+        secondary["verify_small_calls"] = {
+            "metric": "latency of host-pointer calls, one caller in a loop", "single_ed25519_verify_ms": t_one * 1e3,
+            "verify_batch_256_valid_ms": t_256 * 1e3, "outputs_correct": good,
+            "note": "concurrent single-item calls are merged into one launch (tests/c/threaded_callers.c measures that)"}
     if args.op == "all" and main_op == "verify" and world == 1 and args.sustained > 0:
         secondary["verify_sustained"] = sustained_verify(w, n, args.sustained, local, line["value"])
         correct = correct and secondary["verify_sustained"]["outputs_correct"]

@@ -127,6 +127,8 @@ def test_bench_default_line_carries_the_whole_metric(engine, golden):
     assert v["outputs_correct"] is True and v["stats"][0] == 1 << 20 and v["value"] > d["value"]
     hh = d["secondary"]["verify_host_to_host"]              # PCIe-inclusive, for the record
     assert hh["outputs_correct"] is True and 0 < hh["value"] < d["value"] * 1.05
+    sc = d["secondary"]["verify_small_calls"]               # the single-item function and a small batch, one caller
+    assert sc["outputs_correct"] is True and 0 < sc["single_ed25519_verify_ms"] < 5 and 0 < sc["verify_batch_256_valid_ms"] < 5
     su = d["secondary"]["verify_sustained"]                 # burst and steady state side by side
     assert su["outputs_correct"] is True and su["seconds"] >= 2 and 0.5 < su["sustained_over_burst"] < 1.3
     r = d["roofline"]
