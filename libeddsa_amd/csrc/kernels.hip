@@ -541,16 +541,54 @@ k_x25519_finish(uint8_t* out, uint32_t* acc, size_t n, int K) {
 
 constexpr int POINT_BLOCK = COMB_IMG_WORDS * 4 > 80 * 1024 ? 512 : 256;   // 8 waves per CU either way (768 lanes: 6-101 spilled registers, 1024: 94-314)
 
+// PARTS = 4: four lanes per item for small passes (lanes.h: scale_base_lane<4>) - a block is four waves, wave w holds
+// share w of 64 items - and the shares are added through LDS, pairwise: waves 1 and 3 hand theirs to waves 0 and 2,
+// then wave 2 to wave 0, which delivers.  The shares are secrets (partial sums of a secret multiple): the slots are
+// zeroed once read.
+constexpr int POINT_SPLIT = 4, POINT_SPLIT_ITEMS = 64;
+ED_DEV void share_store(uint32_t* slot, const ge& p) {
+#pragma unroll
+  for (int j = 0; j < 10; j++) {
+    slot[j * 64] = p.X.v[j]; slot[(10 + j) * 64] = p.Y.v[j]; slot[(20 + j) * 64] = p.Z.v[j]; slot[(30 + j) * 64] = p.T.v[j];
+  }
+}
+ED_DEV void share_take(ge& p, uint32_t* slot) {
+#pragma unroll
+  for (int j = 0; j < 10; j++) {
+    p.X.v[j] = slot[j * 64]; p.Y.v[j] = slot[(10 + j) * 64]; p.Z.v[j] = slot[(20 + j) * 64]; p.T.v[j] = slot[(30 + j) * 64];
+    slot[j * 64] = 0; slot[(10 + j) * 64] = 0; slot[(20 + j) * 64] = 0; slot[(30 + j) * 64] = 0;
+  }
+}
+// every wave of the block calls it; afterwards the lanes of wave 0 hold the sums (Z, Y, X; T is not computed)
+ED_DEV void point_reduce4(ge& a, uint32_t* lds_shares, int part) {
+  uint32_t* slot = lds_shares + (part >> 1) * (40 * 64) + (threadIdx.x & 63u);
+  ge o;
+  ge_cached c;
+  if (part & 1) share_store(slot, a);
+  __syncthreads();
+  if (!(part & 1)) { share_take(o, slot); ge_to_cached(c, o); ge_add_cached(a, a, c, true); }
+  __syncthreads();
+  slot = lds_shares + (threadIdx.x & 63u);
+  if (part == 2) share_store(slot, a);
+  __syncthreads();
+  if (part == 0) { share_take(o, slot); ge_to_cached(c, o); ge_add_cached(a, a, c, false); }
+}
+
+template <int PARTS>
 __global__ void __launch_bounds__(POINT_BLOCK, 512 / POINT_BLOCK)
 k_genpub_point(uint32_t* accout, const uint8_t* secs, size_t n, const uint32_t* comb) {
   __shared__ alignas(16) uint32_t lds_comb[COMB_IMG_WORDS];
   stage_table(lds_comb, comb, COMB_IMG_WORDS);
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // blocks of POINT_BLOCK lanes, or single waves for small passes (EDK_POINT_GRID)
+  __shared__ uint32_t lds_shares[PARTS == 1 ? 1 : 2 * 40 * 64];
+  // blocks of POINT_BLOCK lanes, or smaller ones for small passes (EDK_POINT_GRID); PARTS = 4: four waves, 64 items
+  const int part = PARTS == 1 ? 0 : (int)(threadIdx.x >> 6);
+  const size_t i = PARTS == 1 ? (size_t)blockIdx.x * blockDim.x + threadIdx.x : (size_t)blockIdx.x * POINT_SPLIT_ITEMS + (threadIdx.x & 63u);
   uint32_t sk[8];
   load32(sk, secs, i < n ? i : n - 1, 32);
   ge A;
-  genpub_point_lane(A, sk, lds_comb);
-  acc_store(accout, i, A);
+  genpub_point_lane<PARTS>(A, sk, lds_comb, part);
+  if (PARTS > 1) point_reduce4(A, lds_shares, part);
+  if (PARTS == 1 || (part == 0 && i < n)) acc_store(accout, i, A);
 }
 
 // Z of a comb result is never 0 (B and its multiples are curve points)
@@ -578,21 +616,26 @@ k_encode_finish(uint8_t* out, uint32_t* acc, size_t n, int K) {
   finish_batch8(encode_finish_policy{out, acc, n, K}, acc);
 }
 
+template <int PARTS>
 __global__ void __launch_bounds__(POINT_BLOCK, 512 / POINT_BLOCK)
 k_sign_point(uint32_t* accout, uint32_t* aux, const uint8_t* secs, const uint8_t* msgs,
              const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* comb) {
   __shared__ alignas(16) uint32_t lds_comb[COMB_IMG_WORDS];
   stage_table(lds_comb, comb, COMB_IMG_WORDS);
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // blocks of POINT_BLOCK lanes, or single waves for small passes (EDK_POINT_GRID)
+  __shared__ uint32_t lds_shares[PARTS == 1 ? 1 : 2 * 40 * 64];
+  // blocks of POINT_BLOCK lanes, or smaller ones for small passes (EDK_POINT_GRID); PARTS = 4: four waves, 64 items
+  const int part = PARTS == 1 ? 0 : (int)(threadIdx.x >> 6);
+  const size_t i = PARTS == 1 ? (size_t)blockIdx.x * blockDim.x + threadIdx.x : (size_t)blockIdx.x * POINT_SPLIT_ITEMS + (threadIdx.x & 63u);
   const size_t item = i < n ? i : n - 1;
   const uint8_t* m; size_t mlen;
   msg_span(m, mlen, msgs, msg_off, msg_len, item);
   uint32_t sk[8], aw[8], rw[8];
   load32(sk, secs, item, 32);
   ge R;
-  sign_point_lane(R, aw, rw, sk, m, mlen, lds_comb);
-  acc_store(accout, i, R);
-  if (i >= n) return;                            // an idle lane must not leave a copy of the last item's secrets
+  sign_point_lane<PARTS>(R, aw, rw, sk, m, mlen, lds_comb, part);
+  if (PARTS > 1) point_reduce4(R, lds_shares, part);
+  if (PARTS == 1 || (part == 0 && i < n)) acc_store(accout, i, R);
+  if (i >= n || part != 0) return;               // an idle lane must not leave a copy of the last item's secrets
   uint4* d = reinterpret_cast<uint4*>(aux + 16 * i);     // the secret scalars a and r, for the finish step
   d[0] = make_uint4(aw[0], aw[1], aw[2], aw[3]); d[1] = make_uint4(aw[4], aw[5], aw[6], aw[7]);
   d[2] = make_uint4(rw[0], rw[1], rw[2], rw[3]); d[3] = make_uint4(rw[4], rw[5], rw[6], rw[7]);
@@ -638,18 +681,23 @@ k_sign_finish(uint8_t* sigs, uint32_t* acc, uint32_t* aux, const uint8_t* pubs, 
   finish_batch8(sign_finish_policy{sigs, acc, aux, pubs, msgs, msg_off, msg_len, n, K}, acc);
 }
 
+template <int PARTS>
 __global__ void __launch_bounds__(POINT_BLOCK, 512 / POINT_BLOCK)
 k_x25519_base_point(uint32_t* accout, const uint8_t* scalars, size_t n, const uint32_t* comb) {
   __shared__ alignas(16) uint32_t lds_comb[COMB_IMG_WORDS];
   stage_table(lds_comb, comb, COMB_IMG_WORDS);
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // blocks of POINT_BLOCK lanes, or single waves for small passes (EDK_POINT_GRID)
+  __shared__ uint32_t lds_shares[PARTS == 1 ? 1 : 2 * 40 * 64];
+  // blocks of POINT_BLOCK lanes, or smaller ones for small passes (EDK_POINT_GRID); PARTS = 4: four waves, 64 items
+  const int part = PARTS == 1 ? 0 : (int)(threadIdx.x >> 6);
+  const size_t i = PARTS == 1 ? (size_t)blockIdx.x * blockDim.x + threadIdx.x : (size_t)blockIdx.x * POINT_SPLIT_ITEMS + (threadIdx.x & 63u);
   uint32_t s[8];
   load32(s, scalars, i < n ? i : n - 1, 32);
   ge R;
-  x25519_base_point_lane(R, s, lds_comb);
+  x25519_base_point_lane<PARTS>(R, s, lds_comb, part);
+  if (PARTS > 1) point_reduce4(R, lds_shares, part);
   fe_add(R.X, R.Z, R.Y);                         // the finish step needs z + y, not x
   fe_carry(R.X);
-  acc_store(accout, i, R);
+  if (PARTS == 1 || (part == 0 && i < n)) acc_store(accout, i, R);
 }
 
 // u = (z + y) / (z - y); z = y gives 0 in the reference (fld_inv(0) = 0, x25519.c:192): such an
@@ -976,12 +1024,19 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
 // So: the smallest block that covers the pass with one block per CU - one, two or four waves, each with a SIMD to itself.
 #define POINT_LANES(n) ((n) <= (size_t)64 * 256 ? 64 : (n) <= (size_t)128 * 256 ? 128 : (n) <= (size_t)256 * 256 ? 256 : POINT_BLOCK)
 #define EDK_POINT_GRID(n) dim3((unsigned)(((n) + POINT_LANES(n) - 1) / POINT_LANES(n))), dim3(POINT_LANES(n)), 0, stream
+// Passes of up to POINT_SPLIT_MAX_N items spend four lanes on an item (lanes.h: scale_base_lane<4>, k_genpub_point above): the 44 additions of
+// the comb in a row were the latency of the pass (a single ed25519_sign: 0.17 ms in k_sign_point, now 0.09).
+constexpr size_t POINT_SPLIT_MAX_N = (size_t)1 << 14;
+#define EDK_POINT_LAUNCH(kernel, n, ...) do { \
+    if ((n) <= POINT_SPLIT_MAX_N) hipLaunchKernelGGL((kernel<POINT_SPLIT>), dim3((unsigned)(((n) + POINT_SPLIT_ITEMS - 1) / POINT_SPLIT_ITEMS)), \
+                                                     dim3(POINT_SPLIT * 64), 0, stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((kernel<1>), EDK_POINT_GRID(n), __VA_ARGS__); } while (0)
 #define EDK_FINISH_GRID(n) dim3((unsigned)((((n) + BLOCK - 1) / BLOCK + finish_k(n) - 1) / finish_k(n))), dim3(BLOCK), 0, stream
 
 hipError_t edk_genpub(uint8_t* pubs, const uint8_t* secs, size_t n, const uint32_t* comb,
                       const edk_fixed_ws* ws, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_genpub_point, EDK_POINT_GRID(n), ws->acc, secs, n, comb);
+  EDK_POINT_LAUNCH(k_genpub_point, n, ws->acc, secs, n, comb);
   hipLaunchKernelGGL(k_encode_finish, EDK_FINISH_GRID(n), pubs, ws->acc, n, (int)finish_k(n));
   return hipGetLastError();
 }
@@ -990,7 +1045,7 @@ hipError_t edk_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, con
                     const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* comb,
                     const edk_fixed_ws* ws, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_sign_point, EDK_POINT_GRID(n), ws->acc, ws->aux, secs, msgs, msg_off, msg_len, n, comb);
+  EDK_POINT_LAUNCH(k_sign_point, n, ws->acc, ws->aux, secs, msgs, msg_off, msg_len, n, comb);
   hipLaunchKernelGGL(k_sign_finish, EDK_FINISH_GRID(n), sigs, ws->acc, ws->aux, pubs, msgs, msg_off, msg_len, n, (int)finish_k(n));
   return hipGetLastError();
 }
@@ -998,7 +1053,7 @@ hipError_t edk_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, con
 hipError_t edk_x25519_base(uint8_t* out, const uint8_t* scalars, size_t n, const uint32_t* comb,
                            const edk_fixed_ws* ws, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_x25519_base_point, EDK_POINT_GRID(n), ws->acc, scalars, n, comb);
+  EDK_POINT_LAUNCH(k_x25519_base_point, n, ws->acc, scalars, n, comb);
   hipLaunchKernelGGL(k_x25519_base_finish, EDK_FINISH_GRID(n), out, ws->acc, n, (int)finish_k(n));
   return hipGetLastError();
 }

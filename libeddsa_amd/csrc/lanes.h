@@ -865,8 +865,15 @@ ED_DEV void comb_select(ge_niels& e, const uint32_t* table, int row, uint32_t di
 #endif
 
 // out = x * B for a reduced scalar (x < 2^253) given as eight little-endian words; comb = the LDS
-// image on the device, the table in its global layout in the host build (see comb_select)
-ED_DEV void scale_base_lane(ge& out, const uint32_t xw[8], const uint32_t* comb) {
+// image on the device, the table in its global layout in the host build (see comb_select).
+// PARTS = 4 (small passes, where the 44 additions in a row are the latency of the pass): four lanes - in four
+// different WAVES of a block, `part` is uniform over a wave because the lanes of a wave share the row they look up
+// (comb_select) - hold the same scalar; lane `part` adds up rows part, part + 4, ... (5 or 6 of the 22) and doubles
+// its own odd-digit sum: out = the part's share of x * B (with T), and the caller adds the four shares
+// (kernels.hip: point_reduce4).  12 + 1 + 2 additions deep instead of 44 + 1.  The lookups stay what they are: no
+// address and no branch depends on a digit; which rows a lane takes depends on its wave's number only.
+template <int PARTS = 1>
+ED_DEV void scale_base_lane(ge& out, const uint32_t xw[8], const uint32_t* comb, int part = 0) {
   // y = x + sum_j COMB_HALF * 2^(w j): nine words (w = 6: 264 bits)
   uint32_t y[9];
   {
@@ -884,25 +891,37 @@ ED_DEV void scale_base_lane(ge& out, const uint32_t xw[8], const uint32_t* comb)
       c >>= 32;
     }
   }
+#pragma unroll
+  for (int s = 1; s < PARTS; s++) {              // bring the lane's first row down: `part` shifts by one row
+    const bool go = s <= part;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const uint32_t v = (y[k] >> (2 * COMB_W)) | (y[k + 1] << (32 - 2 * COMB_W)); y[k] = go ? v : y[k]; }
+    y[8] = go ? y[8] >> (2 * COMB_W) : y[8];
+  }
   ge r0, r1;
   ge_neutral(r0); ge_neutral(r1);
 #pragma unroll 1
-  for (int i = 0; i < COMB_ROWS; i++) {
-    const uint32_t two = y[0] & ((1u << (2 * COMB_W)) - 1u);   // digits 2i and 2i+1
+  for (int i = 0; i < (COMB_ROWS + PARTS - 1) / PARTS; i++) {
+    const int row = PARTS * i + part;
+    const bool valid = PARTS == 1 || row < COMB_ROWS;          // (a lane past the last row adds neutral elements)
+    const uint32_t two = y[0] & ((1u << (2 * COMB_W)) - 1u);   // digits 2 row and 2 row + 1
 #pragma unroll
-    for (int k = 0; k < 8; k++) y[k] = (y[k] >> (2 * COMB_W)) | (y[k + 1] << (32 - 2 * COMB_W));
-    y[8] >>= 2 * COMB_W;
+    for (int s = 0; s < PARTS; s++) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) y[k] = (y[k] >> (2 * COMB_W)) | (y[k + 1] << (32 - 2 * COMB_W));
+      y[8] >>= 2 * COMB_W;
+    }
     ge_niels e;
-    comb_select(e, comb, i, two & ((1u << COMB_W) - 1u));
+    comb_select(e, comb, valid ? row : 0, valid ? two & ((1u << COMB_W) - 1u) : (uint32_t)COMB_HALF);
     ge_add_niels(r0, r0, e, true);
-    comb_select(e, comb, i, two >> COMB_W);
+    comb_select(e, comb, valid ? row : 0, valid ? two >> COMB_W : (uint32_t)COMB_HALF);
     ge_add_niels(r1, r1, e, true);
   }
 #pragma unroll 1
   for (int k = 0; k < COMB_W; k++) ge_dbl(r1, r1, k == COMB_W - 1);
   ge_cached c;
   ge_to_cached(c, r1);
-  ge_add_cached(out, r0, c, false);
+  ge_add_cached(out, r0, c, PARTS > 1);
 }
 
 // ed25519-sha512.c:31-47 ed25519_key_setup: h = SHA-512(sk), clamped
@@ -926,18 +945,20 @@ ED_DEV void encode_lane(uint32_t out[8], const fe& X, const fe& Y, const fe& zin
 }
 
 // ed25519-sha512.c:53-67 genpub, up to the point A = a*B
-ED_DEV void genpub_point_lane(ge& A, const uint32_t sk[8], const uint32_t* comb) {
+template <int PARTS = 1>
+ED_DEV void genpub_point_lane(ge& A, const uint32_t sk[8], const uint32_t* comb, int part = 0) {
   uint32_t h[16], aw[8];
   key_setup(h, sk);
   sc a;
   sc_from_words<8>(a, h);
   sc_to_words(aw, a);
-  scale_base_lane(A, aw, comb);
+  scale_base_lane<PARTS>(A, aw, comb, part);
 }
 
 // ed25519-sha512.c:84-110 sign, up to R = r*B; aw, rw = the reduced scalars a and r as words
+template <int PARTS = 1>
 ED_DEV void sign_point_lane(ge& R, uint32_t aw[8], uint32_t rw[8], const uint32_t sk[8],
-                            const uint8_t* m, size_t mlen, const uint32_t* comb) {
+                            const uint8_t* m, size_t mlen, const uint32_t* comb, int part = 0) {
   uint32_t h[16], dig[16], rdig[8];
   key_setup(h, sk);
   sc a, r;
@@ -948,7 +969,7 @@ ED_DEV void sign_point_lane(ge& R, uint32_t aw[8], uint32_t rw[8], const uint32_
   sc_to_words(rw, r);
 #pragma unroll
   for (int k = 0; k < 8; k++) rdig[k] = rw[k];
-  scale_base_lane(R, rdig, comb);
+  scale_base_lane<PARTS>(R, rdig, comb, part);
 }
 
 // ed25519-sha512.c:112-122 sign, from the encoded R on: S = r + H(R || A || M) * a, in two steps so that
@@ -976,13 +997,14 @@ ED_DEV void sign_finish_lane(uint32_t Sw[8], const uint32_t Rw[8], const uint32_
 }
 
 // x25519.c:158-190 do_x25519_base, up to R = x*B
-ED_DEV void x25519_base_point_lane(ge& R, uint32_t s[8], const uint32_t* comb) {
+template <int PARTS = 1>
+ED_DEV void x25519_base_point_lane(ge& R, uint32_t s[8], const uint32_t* comb, int part = 0) {
   uint32_t xw[8];
   clamp(s);
   sc x;
   sc_from_words<8>(x, s);
   sc_to_words(xw, x);
-  scale_base_lane(R, xw, comb);
+  scale_base_lane<PARTS>(R, xw, comb, part);
 }
 
 // x25519.c:191-196: u = (z + y) / (z - y), given dinv = 1 / (z - y)  (0 when z = y, as fld_inv)

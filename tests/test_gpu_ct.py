@@ -1,7 +1,7 @@
 """Constant-time evidence for the secret-scalar kernels (the discipline being claimed is the
 reference's scale16, lib/ed.c:346-391: no branch and no address depends on a secret digit): the hardware counters
 of k_x25519_base_point, k_genpub_point and k_sign_point - VALU / SALU / LDS / SMEM / VMEM instruction counts and
-LDS bank-conflict cycles - must be IDENTICAL whether the 2^16 secrets are all zero, all ones, random, or a
+LDS bank-conflict cycles - must be IDENTICAL whether the 2^16 (one lane per item) or 2^12 (four lanes per item) secrets are all zero, all ones, random, or a
 different class in every lane.  Runs tools/ct_counters.sh (rocprofv3 --pmc passes, no tracing) as a child."""
 import json
 import os
@@ -30,7 +30,8 @@ def test_point_kernels_counters_do_not_depend_on_the_secrets(engine, tmp_path):
     if not all(d["counters"].get(c) for c in ("zero", "ones", "random", "mixed")):
         pytest.skip("rocprofv3 collected no counters for some class on this box")
     same = d["identical_across_secret_classes"]
-    assert set(same) == {"ed::k_x25519_base_point", "ed::k_genpub_point", "ed::k_sign_point"}, same
+    assert set(same) == {k + w for k in ("ed::k_x25519_base_point", "ed::k_genpub_point", "ed::k_sign_point")
+                         for w in ("<1>", "<4>")}, same             # one lane per item, and the four-lane form of small passes
     assert all(same.values()), d["counters"]
-    c = d["counters"]["random"]["ed::k_sign_point"]
+    c = d["counters"]["random"]["ed::k_sign_point<1>"]
     assert c["SQ_INSTS_VALU"][0] > 1e6 and len(c["SQ_LDS_BANK_CONFLICT"]) == 1     # one value over all launches

@@ -19,8 +19,8 @@ for c in ("zero", "ones", "random", "mixed"):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(f"{sys.argv[1]}/{c}/*/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
-            if k.endswith("_point"):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")     # "void ed::k_sign_point<4>(...)": the lanes per item stay in the name
+            if k.split("<")[0].endswith("_point"):
                 agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out[c] = {k: {n: sorted(set(v)) for n, v in cs.items()} for k, cs in agg.items()}
 kernels = sorted(out["random"])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Constant-time probe: run the three secret-scalar point kernels (k_x25519_base_point,
-k_genpub_point, k_sign_point) on 2^16 secrets of one CLASS - zero | ones | random | mixed (every lane of a
+k_genpub_point, k_sign_point; <1>: one lane per item, <4>: the four-lane form of small passes) on 2^16 and on 2^12 secrets of one CLASS - zero | ones | random | mixed (every lane of a
 wave a different class) - so that tools/ct_counters.sh can compare the hardware counters of the
 launches across classes.  x25519_base takes the scalar itself (clamped, x25519.c:163-166), so `zero`
 and `ones` really are the extreme digit strings there; genpub and sign hash the key first."""
@@ -29,8 +29,9 @@ msg = np.zeros((n, 32), np.uint8)
 ed.init(0)
 d_sec, d_msg = torch.from_numpy(sec).cuda(), torch.from_numpy(msg).cuda()
 for _ in range(3):
-    ed.x25519_base_batch(d_sec)
-    pk = ed.ed25519_genpub_batch(d_sec)
-    ed.ed25519_sign_batch(d_sec, pk, d_msg)
+    for m in (n, 1 << 12):
+        ed.x25519_base_batch(d_sec[:m])
+        pk = ed.ed25519_genpub_batch(d_sec[:m])
+        ed.ed25519_sign_batch(d_sec[:m], pk, d_msg[:m])
 torch.cuda.synchronize()
 print("ct_probe", cls, "done")
