@@ -363,7 +363,7 @@ out:
 void eddsa_amd_set_verify_algo(int algo)
 {
     pthread_rwlock_wrlock(&g_table);
-    g_verify_algo = algo == 1 || algo == 2 ? algo : 0;
+    g_verify_algo = algo >= 1 && algo <= 3 ? algo : 0;
     pthread_rwlock_unlock(&g_table);
 }
 

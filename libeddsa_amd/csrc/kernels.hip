@@ -321,14 +321,17 @@ k_verify_halve(const uint8_t* sigs, size_t sig_stride, size_t n, const uint32_t*
 #ifndef MAIN_HALF_BLOCKS_PER_CU
 #define MAIN_HALF_BLOCKS_PER_CU 2
 #endif
-template <int WINDOWS>
+// WITH_LONG: after k_verify_prepare_pair (mid-size passes), which leaves the items without a short pair to this kernel:
+// the wave of such an item (2 in 10^7 with the wide search) runs the long loop
+template <int WINDOWS, bool WITH_LONG = false>
 __global__ void __launch_bounds__(MAIN_HALF_BLOCK, MAIN_HALF_BLOCKS_PER_CU)
 k_verify_main_half(uint8_t* ok, const uint32_t* hdigits, const uint32_t* table, const uint32_t* rtable,
                    const uint32_t* base16, const uint8_t* flags, size_t n, int exact_offcurve) {
   const size_t i = (size_t)blockIdx.x * MAIN_HALF_BLOCK + threadIdx.x;   // < workspace capacity
-  const uint32_t* hd = hdigits + HALF_DIGIT_WORDS * i;
-  const bool neutral = verify_half_main_lane<false, WINDOWS>(hd, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
-                                             rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16, false);
+  const uint32_t* hd = hdigits + HALF_DIGIT_WORDS * (WITH_LONG && i >= n ? n - 1 : i);   // (an idle lane's own words are whatever the last pass left)
+  const bool long_loop = WITH_LONG && __any((hd[24] & 2u) != 0);
+  const bool neutral = verify_half_main_lane<WITH_LONG, WINDOWS>(hd, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
+                                             rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16, long_loop);
   if (i >= n) return;
   const uint8_t fl = flags[i];
   if ((fl & 1) == 0) {                           // the exact path owns this verdict (or, in reject mode, nobody does)
@@ -473,6 +476,10 @@ constexpr size_t QUAD_MAIN_MAX_N = (size_t)1 << 14;   // measured: 0.57 vs 0.86 
 // k_verify_prepare_pair + k_verify_main_half_quad up to here.  Measured (tools/verify_small.py, valid signatures, ms per pass):
 // 2^15 items 0.74 against 1.12 with one lane per item, 2^16 items 1.15 against 1.30 but 1.59 against 1.27 on the config-2 mix
 constexpr size_t HALF_QUAD_MAX_N = (size_t)1 << HALF_QUAD_LOG2;
+// Between 2^14 and 2^18 items: k_verify_prepare_pair, then the ONE-lane evaluation with the long loop in place.  Measured
+// (tools/verify_mid.py, valid signatures, ms): 2^15 0.68 (four-lane evaluation) / 0.70 (one lane per item throughout) -> 0.58,
+// 2^16 0.71-0.76 -> 0.66, 2^17 1.30 -> 1.28; the config-2 mix, whose floor is the exact path: 2^16 1.16 -> 1.11, else equal.
+constexpr size_t PAIR_ONE_MIN_N = (size_t)1 << 14;
 constexpr size_t HALF_WIDE_MIN_N = (size_t)1 << 18;   // one-lane passes below this search pairs up to 2^138 (see edk_verify)
 __global__ void __launch_bounds__(QUAD_BLOCK, 2)
 k_verify_main_quad(const uint32_t* digits, const uint32_t* table, const uint32_t* base16, uint32_t* accout, size_t n) {
@@ -769,6 +776,7 @@ k_sk_to_x(uint8_t* out, const uint8_t* in, size_t n) {
 // a single item's 0.13 ms became 0.09) - and k_verify_main_half_quad is verify_half_main_lane with a coordinate per
 // lane (quad_lanes.h).  Two kernels, 132 doublings and no inversion instead of three, 252 and one.
 // ---------------------------------------------------------------------------------------------
+template <int BITS>
 __global__ void __launch_bounds__(BLOCK, 2)
 k_verify_prepare_pair(edk_verify_src src, size_t n, uint32_t* digits, uint32_t* hdigits, uint32_t* table, uint32_t* rtable,
                       uint8_t* flags, uint32_t* offlist, uint32_t* offcount, int all_exact, unsigned point_blocks) {
@@ -782,7 +790,7 @@ k_verify_prepare_pair(edk_verify_src src, size_t n, uint32_t* digits, uint32_t* 
     verify_item(rw, sw, aw, m, mlen, src, i);
     verify_hash_lane(tw, rw, aw, m, mlen);
     verify_s_lane(sw);
-    verify_half_scalars_lane(hd, tw, sw);
+    verify_half_scalars_lane<BITS>(hd, tw, sw);
     uint4* d = reinterpret_cast<uint4*>(digits + 16 * i);
     d[0] = make_uint4(tw[0], tw[1], tw[2], tw[3]); d[1] = make_uint4(tw[4], tw[5], tw[6], tw[7]);
     d[2] = make_uint4(sw[0], sw[1], sw[2], sw[3]); d[3] = make_uint4(sw[4], sw[5], sw[6], sw[7]);
@@ -931,15 +939,25 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   const unsigned blocks = (unsigned)((n + BLOCK - 1) / BLOCK);
   (void)hipMemsetAsync(ws->offcount, 0, sizeof(uint32_t), stream);
   if (marks) (void)hipEventRecord(marks[0], stream);
-  // algo 0: half-length scalars - one lane per item above QUAD_MAIN_MAX_N items, lane pairs and quads below;
+  // algo 0: half-length scalars - lane pairs and quads up to 2^14 items, the pairs' preparation and one lane per item up to 2^18, one lane per item above;
+  // 3: the mid-size arrangement at any size below 2^18;
   // 1: full-length windows (one lane per item above QUAD_MAIN_MAX_N items, quads below); 2: half-length, one lane per item
   const bool small = n <= QUAD_MAIN_MAX_N;
   const bool small_half = n <= HALF_QUAD_MAX_N;
   const int algo = ws->exact_offcurve ? ws->algo : 1;   // the half-length route relies on the exact path for its give-ups
-  const bool half = algo == 2 || (algo == 0 && !small_half);
-  const bool half_quad = algo == 0 && small_half;
-  if (half_quad)
-    hipLaunchKernelGGL(k_verify_prepare_pair, dim3((unsigned)((2 * n + BLOCK - 1) / BLOCK + (n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, src, n,
+  const bool wide = n < HALF_WIDE_MIN_N;
+  // mid-size passes: the three-lane preparation of the small route (its blocks fill the SIMDs that one lane per item leaves
+  // with a single wave) and the one-lane evaluation; algo 3 forces it for measurements
+  const bool pair_one = wide && (algo == 3 || (algo == 0 && n > PAIR_ONE_MIN_N));
+  const bool half = !pair_one && (algo == 2 || (algo == 0 && !small_half));
+  const bool half_quad = !pair_one && algo == 0 && small_half;
+  const unsigned pair_point_blocks = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
+  if (pair_one)
+    hipLaunchKernelGGL(k_verify_prepare_pair<HALF_BITS_SMALL>, dim3(pair_point_blocks + blocks), dim3(BLOCK), 0, stream, src, n,
+                       ws->digits, ws->hdigits, ws->table, ws->rtable, ws->flags, ws->offlist, ws->offcount, ws->exact_offcurve == 2,
+                       pair_point_blocks);
+  else if (half_quad)
+    hipLaunchKernelGGL(k_verify_prepare_pair<HALF_BITS>, dim3((unsigned)((2 * n + BLOCK - 1) / BLOCK + (n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, src, n,
                        ws->digits, ws->hdigits, ws->table, ws->rtable, ws->flags, ws->offlist, ws->offcount, ws->exact_offcurve == 2,
                        (unsigned)((2 * n + BLOCK - 1) / BLOCK));
   else
@@ -948,7 +966,6 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   // Below HALF_WIDE_MIN_N items the main kernel is shorter than the exact path's two (about 1 ms for however few items), so an
   // item without a short pair would set the time of the pass: such passes search up to 2^138 and run 35 windows (2 t in
   // 10^7 without a pair instead of 8.5 in 10^5; 3 % more instructions in the main kernel)
-  const bool wide = n < HALF_WIDE_MIN_N;
   if (half && wide)
     hipLaunchKernelGGL(k_verify_halve<HALF_BITS_SMALL>, dim3(blocks), dim3(BLOCK), 0, stream, src.sigs, src.sig_stride, n, ws->digits,
                        ws->hdigits, ws->rtable, ws->flags, ws->offlist, ws->offcount);
@@ -978,14 +995,17 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
     hipLaunchKernelGGL(k_verify_main_half_quad, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, stream,
                        ok, ws->hdigits, ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
     if (marks) { (void)hipEventRecord(marks[2], stream); (void)hipEventRecord(marks[3], stream); }
-  } else if (half) {
+  } else if (half || pair_one) {
 #ifdef MAIN_HALF_LDS_KB
     constexpr unsigned half_lds = MAIN_HALF_LDS_KB * 1024;
 #else
     constexpr unsigned half_lds = MAIN_LDS_RESERVE;
 #endif
     const unsigned hblocks = (blocks * BLOCK + MAIN_HALF_BLOCK - 1) / MAIN_HALF_BLOCK;
-    if (wide)
+    if (pair_one)
+      hipLaunchKernelGGL((k_verify_main_half<HALF_WINDOWS_SMALL, true>), dim3(hblocks), dim3(MAIN_HALF_BLOCK), half_lds, stream, ok, ws->hdigits,
+                         ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
+    else if (wide)
       hipLaunchKernelGGL(k_verify_main_half<HALF_WINDOWS_SMALL>, dim3(hblocks), dim3(MAIN_HALF_BLOCK), half_lds, stream, ok, ws->hdigits,
                          ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
     else

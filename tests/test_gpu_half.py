@@ -28,7 +28,7 @@ def restore(engine):
     engine.set_offcurve_mode(True)
 
 
-@pytest.mark.parametrize("algo", [0, 1, 2])
+@pytest.mark.parametrize("algo", [0, 1, 2, 3])
 def test_edge_and_torsion_vectors_on_either_evaluation(engine, golden, algo):
     """verify_edges.json (S + k l, non-canonical / small-order / off-curve A, non-canonical R, flipped bits) and
     verify_torsion.json (A = a B + T, R = r B + T' for all 64 pairs of points of order dividing 8: accepted
@@ -62,7 +62,7 @@ def test_half_full_and_oracle_agree_on_a_large_seeded_batch(engine, oracle):
     want = oracle.verify_batch(sig, pk, msg, msg.shape[1])
     assert np.array_equal(want, expect)
     d = dev(sig), dev(pk), dev(msg)
-    for algo in (0, 2, 1):
+    for algo in (0, 2, 3, 1):
         engine.set_verify_algo(algo)
         got = engine.ed25519_verify_batch(*d, msg_len=msg.shape[1]).cpu().numpy()
         assert np.array_equal(got, want), (algo, np.nonzero(got != want)[0][:10])
@@ -86,7 +86,7 @@ def test_forced_half_length_on_small_and_ragged_passes(engine, oracle, n):
     pk[g] = rng.integers(0, 256, (len(g), 32), dtype=np.uint8)
     want = np.array([oracle.verify(sig[i].tobytes(), pk[i].tobytes(), msgs[int(off[i]):int(off[i + 1])].tobytes())
                      for i in range(n)], np.uint8)
-    for algo in (0, 2, 1):
+    for algo in (0, 2, 3, 1):
         engine.set_verify_algo(algo)
         assert np.array_equal(engine.ed25519_verify_batch(sig, pk, msgs, msg_off=off), want), algo
 
@@ -122,7 +122,7 @@ def test_commitments_that_only_decode_permissively(engine, oracle):
     sig, pub, msg = arr(sigs), arr(pubs), arr(msgs)
     want = np.array([oracle.verify(s, p, m) for s, p, m in zip(sigs, pubs, msgs)], np.uint8)
     assert want[:12].sum() >= 8 and want[12:24].sum() == 0          # canonical identity accepted, its signed spelling never
-    for algo in (0, 2, 1):                         # 0: lane pairs and quads at this size
+    for algo in (0, 2, 3, 1):                         # 0: lane pairs and quads at this size
         engine.set_verify_algo(algo)
         assert np.array_equal(engine.ed25519_verify_batch(sig, pub, msg, msg_len=msg.shape[1]), want), algo
 
