@@ -8,7 +8,9 @@ CSRC    := libeddsa_amd/csrc
 BUILD   := build
 LIB     := libeddsa_amd/libeddsa_amd.so
 
-HIPFLAGS := -O3 --offload-arch=$(ARCH) -fPIC -fvisibility=hidden -DEDDSA_BUILD -Iinclude -I$(CSRC)
+# -amdgpu-dpp-combine=false: the combiner's v_subrev_u32_dpp computes dpp(src1) - src0 on this hardware instead of
+# src1 - dpp(src0) (tools/microbench/dpp_subrev.hip); the lane exchanges of quad_lanes.h stay separate v_mov_b32_dpp
+HIPFLAGS := -O3 --offload-arch=$(ARCH) -fPIC -fvisibility=hidden -DEDDSA_BUILD -Iinclude -I$(CSRC) -mllvm -amdgpu-dpp-combine=false
 CFLAGS   := -std=c11 -O2 -fPIC -fvisibility=hidden -Wall -Wextra -DEDDSA_BUILD -Iinclude -I$(CSRC) -I$(ROCM)/include
 
 all: $(LIB) oracle

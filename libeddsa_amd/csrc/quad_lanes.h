@@ -485,7 +485,7 @@ ED_DEV bool verify_half_main_sums_quad(const uint32_t* hd, const uint32_t* sums,
 //   stage 1   (da + cb)^2        | (da - cb)^2        | aa bb | 121665 (aa - bb)
 //   stage 2         -            | e (121665 e + aa)  |   -   | (da - cb)^2 x1
 // Same field expressions as x25519.c:60-94 (montgomery) and the same swap logic as the one-lane form, so the
-// same (x2 : z2); about 740 dependent instructions per step instead of 1260.  Leaves x2 in lane 0 and z2 in
+// same (x2 : z2); about 760 instructions per step instead of 1260.  Leaves x2 in lane 0 and z2 in
 // lane 1 of the quad.
 // ---------------------------------------------------------------------------------------------
 ED_DEV void x25519_ladder_quad(fe& r, uint32_t s[8], const uint32_t pt[8], int q) {
@@ -506,38 +506,42 @@ ED_DEV void x25519_ladder_quad(fe& r, uint32_t s[8], const uint32_t pt[8], int q
       cur = w == 6 ? s[6] : w == 5 ? s[5] : w == 4 ? s[4] : w == 3 ? s[3] : w == 2 ? s[2] : w == 1 ? s[1] : s[0];
     }
     swap ^= bit;
-    fe x2, z2, x3, z3, a, b, c, d, u, v, m1;
-    fe_quad_perm<0, 0, 0, 0>(x2, r); fe_quad_perm<1, 1, 1, 1>(z2, r);
-    fe_quad_perm<2, 2, 2, 2>(x3, r); fe_quad_perm<3, 3, 3, 3>(z3, r);
-    fe_add(a, x2, z2);                           // 2u
-    fe_sub(b, x2, z2);                           // 3u
-    fe_add(c, x3, z3);                           // 2u
-    fe_sub(d, x3, z3);                           // 3u
-    // stage 0: lane 0: d * a, lane 1: c * b, lane 2: P * P, lane 3: Q * Q  (the point to double: slot 3 when exchanged)
-    u = d; v = a;
-    fe_cmov(u, c, q == 1); fe_cmov(v, b, q == 1);
-    { fe p2 = a, q2 = b; fe_cmov(p2, c, swap != 0); fe_cmov(q2, d, swap != 0);
-      fe_cmov(u, p2, q == 2); fe_cmov(v, p2, q == 2); fe_cmov(u, q2, q == 3); fe_cmov(v, q2, q == 3); }
+    // lanes 0, 1 hold the pair (x2, z2), lanes 2, 3 the pair (x3, z3): sum and difference of the lane's OWN pair, and the
+    // other pair's through one exchange (every operand below is one of those four, picked by the lane's role)
+    fe X, Z, S, D, So, Do, u, v, m1;
+    fe_quad_perm<0, 0, 2, 2>(X, r); fe_quad_perm<1, 1, 3, 3>(Z, r);
+    fe_add(S, X, Z);                             // 2u: lanes 0, 1: a = x2 + z2, lanes 2, 3: c = x3 + z3
+    fe_sub(D, X, Z);                             // 3u: lanes 0, 1: b = x2 - z2, lanes 2, 3: d = x3 - z3
+    fe_quad_perm<2, 3, 0, 1>(So, S); fe_quad_perm<2, 3, 0, 1>(Do, D);
+    // stage 0: lane 0: d * a, lane 1: c * b, lane 2: P * P, lane 3: Q * Q  (P, Q: the point to double - (a, b), or (c, d) when exchanged)
+    {
+      fe ts = So, td = Do;
+      fe_cmov(ts, S, swap != 0); fe_cmov(td, D, swap != 0);
+      u = ts;
+      fe_cmov(u, Do, q == 0); fe_cmov(u, So, q == 1); fe_cmov(u, td, q == 3);
+      v = u;
+      fe_cmov(v, S, q == 0); fe_cmov(v, D, q == 1);
+    }
     swap = bit;
     fe_mul(m1, u, v);                            // (da, cb, aa, bb)
-    fe da, cb, aa, bb, e, m2;
-    fe_quad_perm<0, 0, 0, 0>(da, m1); fe_quad_perm<1, 1, 1, 1>(cb, m1);
-    fe_quad_perm<2, 2, 2, 2>(aa, m1); fe_quad_perm<3, 3, 3, 3>(bb, m1);
-    fe_sub(e, aa, bb);                           // 3u
-    // stage 1: lane 0: (da + cb)^2, lane 1: (da - cb)^2, lane 2: aa * bb, lane 3: e * 121665
-    fe_add(u, da, cb);                           // 2u
+    // stage 1: lane 0: (da + cb)^2, lane 1: (da - cb)^2, lane 2: aa * bb, lane 3: e * 121665 - own value and the neighbour's
+    fe pm, s1, d1, m2;
+    fe_quad_perm<1, 0, 3, 2>(pm, m1);            // (cb, da, bb, aa)
+    fe_add(s1, m1, pm);                          // 2u: lane 0: da + cb
+    fe_sub(d1, pm, m1);                          // 3u: lane 1: da - cb, lane 3: e = aa - bb
+    u = s1;
+    fe_cmov(u, d1, (q & 1) != 0); fe_cmov(u, m1, q == 2);
     v = u;
-    { fe t1; fe_sub(t1, da, cb); fe_cmov(u, t1, q == 1); fe_cmov(v, t1, q == 1); }       // 3u
-    fe_cmov(u, aa, q == 2); fe_cmov(v, bb, q == 2);
-    fe_cmov(u, e, q == 3); fe_cmov(v, k121665, q == 3);
+    fe_cmov(v, pm, q == 2); fe_cmov(v, k121665, q == 3);
     fe_mul(m2, u, v);                            // (x3', (da - cb)^2, x2', 121665 e)
-    // stage 2: lane 1: e * (121665 e + aa), lane 3: (da - cb)^2 * x1; lanes 0 and 2 idle (they compute lane 1's product too)
-    fe w, tsq, m3;
-    fe_add(w, m2, aa);                           // lane 3: 121665 e + aa, 2u
-    fe_quad_perm<3, 3, 3, 3>(w, w);
-    fe_quad_perm<1, 1, 1, 1>(tsq, m2);
-    u = e; v = w;
-    fe_cmov(u, tsq, q == 3); fe_cmov(v, x1, q == 3);
+    // stage 2: lane 1: e * (121665 e + aa), lane 3: (da - cb)^2 * x1; lanes 0 and 2 idle.  Lane 3 has e and aa (its
+    // neighbour's m1), lane 1 the square: one exchange of e, one of (sum | square)
+    fe w3, ex, wx, m3;
+    fe_add(w3, m2, pm);                          // lane 3: 121665 e + aa, 2u
+    fe_quad_perm<0, 3, 2, 1>(ex, d1);            // lane 1: e
+    { fe t = m2; fe_cmov(t, w3, q == 3); fe_quad_perm<0, 3, 2, 1>(wx, t); }   // lane 1: the sum, lane 3: the square
+    u = ex; fe_cmov(u, wx, q == 3);
+    v = wx; fe_cmov(v, x1, q == 3);
     fe_mul(m3, u, v);                            // lane 1: z2', lane 3: z3'
     // (x2', z2', x3', z3') = (m2 of lane 2, m3, m2 of lane 0, m3)
     fe_quad_perm<2, 1, 0, 3>(r, m2);

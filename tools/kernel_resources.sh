@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.."
 SRCS=${@:-libeddsa_amd/csrc/*.hip}
 for f in $SRCS; do
-  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -fvisibility=hidden -DEDDSA_BUILD -Iinclude -Ilibeddsa_amd/csrc \
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -fvisibility=hidden -DEDDSA_BUILD -Iinclude -Ilibeddsa_amd/csrc -mllvm -amdgpu-dpp-combine=false \
     -S --cuda-device-only $f -o /tmp/kres.$$.s 2>/dev/null
   python3 - /tmp/kres.$$.s <<'PY'
 import re, sys
