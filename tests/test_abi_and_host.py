@@ -66,6 +66,26 @@ def test_product_does_not_reference_the_oracle():
     assert "oracle" not in out
 
 
+def test_device_code_has_no_folded_dpp_operations(tmp_path):
+    """hipcc's DPP combiner can emit v_subrev_u32_dpp, which this hardware executes as dpp(src1) - src0 instead of
+    src1 - dpp(src0) (tools/microbench/dpp_subrev.hip).  The product is built with the combiner off: in the
+    device code of the shipped library every DPP instruction is a plain v_mov_b32_dpp"""
+    import shutil
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump in this image")
+    so = tmp_path / "lib.so"
+    shutil.copy(_lib_path(), so)
+    subprocess.run([objdump, "--offloading", str(so)], check=True, capture_output=True)     # writes the bundles next to the input
+    objs = [f for f in os.listdir(tmp_path) if "amdgcn" in f]
+    assert objs, os.listdir(tmp_path)
+    dpp = []
+    for f in objs:
+        dis = subprocess.run([objdump, "-d", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
+        dpp += [ln.split()[0] for ln in dis.splitlines() if "_dpp" in ln and ln.strip().startswith("v_")]
+    assert len(dpp) > 500 and set(dpp) == {"v_mov_b32_dpp"}, sorted(set(dpp))
+
+
 def test_argument_validation():
     import libeddsa_amd as ed
     with pytest.raises(ValueError):
