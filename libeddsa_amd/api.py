@@ -106,8 +106,8 @@ def set_offcurve_mode(exact=True):
 
 
 def set_verify_algo(algo=0):
-    """0 (default): half-length scalars (four lanes per item up to 2^14 items, one above); 1: always full-length;
-    2: half-length with one lane per item whatever the size; 3: the arrangement of 2^14 .. 2^18 items (three-lane
+    """0 (default): half-length scalars (four lanes per item up to 24 576 items, one above); 1: always full-length;
+    2: half-length with one lane per item whatever the size; 3: the arrangement of 24 577 .. 2^18 items (three-lane
     preparation, one-lane evaluation) at any size below 2^18.  Same verdicts; a measurement and test aid."""
     library().eddsa_amd_set_verify_algo(int(algo))
 

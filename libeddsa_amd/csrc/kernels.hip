@@ -476,10 +476,10 @@ constexpr size_t QUAD_MAIN_MAX_N = (size_t)1 << 14;   // measured: 0.57 vs 0.86 
 // k_verify_prepare_pair + k_verify_main_half_quad up to here.  Measured (tools/verify_small.py, valid signatures, ms per pass):
 // 2^15 items 0.74 against 1.12 with one lane per item, 2^16 items 1.15 against 1.30 but 1.59 against 1.27 on the config-2 mix
 constexpr size_t HALF_QUAD_MAX_N = (size_t)1 << HALF_QUAD_LOG2;
-// Between 2^14 and 2^18 items: k_verify_prepare_pair, then the ONE-lane evaluation with the long loop in place.  Measured
+// Between 24 576 and 2^18 items: k_verify_prepare_pair, then the ONE-lane evaluation with the long loop in place.  Measured
 // (tools/verify_mid.py, valid signatures, ms): 2^15 0.68 (four-lane evaluation) / 0.70 (one lane per item throughout) -> 0.58,
 // 2^16 0.71-0.76 -> 0.66, 2^17 1.30 -> 1.28; the config-2 mix, whose floor is the exact path: 2^16 1.16 -> 1.11, else equal.
-constexpr size_t PAIR_ONE_MIN_N = (size_t)1 << 14;
+constexpr size_t PAIR_ONE_MIN_N = (size_t)3 << 13;   // the four-lane evaluation steps up with every 8192 items (0.35 / 0.51 / 0.69 ms: tools/verify_cross.py), this one stays at 0.58
 constexpr size_t HALF_WIDE_MIN_N = (size_t)1 << 18;   // one-lane passes below this search pairs up to 2^138 (see edk_verify)
 __global__ void __launch_bounds__(QUAD_BLOCK, 2)
 k_verify_main_quad(const uint32_t* digits, const uint32_t* table, const uint32_t* base16, uint32_t* accout, size_t n) {

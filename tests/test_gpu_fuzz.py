@@ -12,7 +12,7 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-SIZES = [1, 2, 3, 63, 64, 65, 255, 256, 257, 511, 777, 1024, 2047, 2048, 2049, 4099, 16383, 16384, 16385, 20011, 32768, 32769, 33000]
+SIZES = [1, 2, 3, 63, 64, 65, 255, 256, 257, 511, 777, 1024, 2047, 2048, 2049, 4099, 24576, 24577, 16383, 16384, 16385, 20011, 32768, 32769, 33000]
 
 
 @pytest.fixture(scope="module")
