@@ -134,7 +134,7 @@ ED_DEV void fe_quad_perm(fe& o, const fe& a) {
   constexpr int ctrl = P0 | (P1 << 2) | (P2 << 4) | (P3 << 6);
 #pragma unroll
   for (int j = 0; j < 10; j++)
-    o.v[j] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.v[j], ctrl, 0xf, 0xf, false);
+    o.v[j] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[j], ctrl, 0xf, 0xf, true);   // (bound_ctrl: no `old` value to set up - every lane of a quad is a valid source)
 }
 
 // the first factor of stage A: (Y - X, Y + X, T, Z); r tight, result < 3u
@@ -226,7 +226,7 @@ ED_DEV bool verify_exact_chain_quad(const uint32_t rw[8], const uint32_t* item, 
   fe_mul(aff, r, zi);
   uint32_t wd[8];
   fe_tobytes(wd, aff);
-  const uint32_t xpar = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wd[0], 0, 0xf, 0xf, false) & 1u;
+  const uint32_t xpar = (uint32_t)__builtin_amdgcn_mov_dpp((int)wd[0], 0, 0xf, 0xf, true) & 1u;
   wd[7] |= xpar << 31;
   uint32_t diff = 0;
 #pragma unroll
