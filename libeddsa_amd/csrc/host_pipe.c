@@ -411,7 +411,7 @@ static int g_fail_next_host_call;      /* eddsa_amd_debug_fail_next_host_call */
 
 /* measurement aid: host-side time stamps of the last host-pointer call (eddsa_amd_debug_pipe_trace) */
 #define TRACE_MAX 512
-static struct { int on, n; int tag[TRACE_MAX]; unsigned chunk[TRACE_MAX]; double t[TRACE_MAX]; } g_trace;
+static struct { int on, n, seen; int tag[TRACE_MAX]; unsigned chunk[TRACE_MAX]; double t[TRACE_MAX]; } g_trace;
 static double trace_now(void)
 {
     struct timespec ts;
@@ -423,13 +423,15 @@ static double trace_now(void)
 /* on != 0: record host-side time stamps in every host-pointer call from now on; returns the number of stamps of the last
  * call and copies up to `max` of them: tag (0 call start, 1 lane drained, 2 inputs staged and queued, 3 kernels queued,
  * 4 download queued, 5 all lanes drained, 6 call end; of a combined launch also 7 leader elected, 8 callers gathered,
- * 9 requests packed, 10 results handed back), chunk index, milliseconds since the call started */
+ * 9 requests packed, 10 results handed back), chunk index, milliseconds since the call started.  on = 2: recording stops
+ * by itself after the 20th combined launch of 32 calls or more, so that a typical launch under load can be read */
 int eddsa_amd_debug_pipe_trace(int on, int *tags, unsigned *chunks, double *ms, int max)
 {
     pthread_rwlock_wrlock(&g_table);
     const int n = g_trace.n < max ? g_trace.n : max;
     for (int i = 0; i < n; i++) { tags[i] = g_trace.tag[i]; chunks[i] = g_trace.chunk[i]; ms[i] = g_trace.t[i] - g_trace.t[0]; }
     g_trace.on = on;
+    g_trace.seen = 0;
     pthread_rwlock_unlock(&g_table);
     return n;
 }
@@ -670,6 +672,7 @@ static int combiner_run(struct engine *e, struct comb_kind *K, struct creq *batc
     if (j0->wipe & WIPE_IN0) memset(K->h_in[0], 0, total * j0->in_w[0]);
     if (j0->wipe & WIPE_OUT) memset(K->h_out, 0, total * j0->out_w);
     TRACE(10, (unsigned)total);
+    if (g_trace.on == 2 && total >= 32 && ++g_trace.seen == 20) g_trace.on = 0;   /* on = 2: keep the 20th launch that carried 32 calls or more */
     return rc;
 }
 

@@ -111,7 +111,7 @@ int main(int argc, char **argv)
     int tags[64]; unsigned chunks[64]; double ms[64];
     g_mode = 0;
     bad |= run(1, "ed25519_verify, one caller");
-    if (trace) eddsa_amd_debug_pipe_trace(1, tags, chunks, ms, 0);
+    if (trace) eddsa_amd_debug_pipe_trace(2, tags, chunks, ms, 0);   /* the 20th launch that carries 32 calls or more */
     bad |= run(threads, "ed25519_verify");
     if (trace) {
         const int k = eddsa_amd_debug_pipe_trace(0, tags, chunks, ms, 64);
