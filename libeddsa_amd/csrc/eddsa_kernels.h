@@ -51,7 +51,7 @@ typedef struct edk_verify_ws {
   uint32_t* sums;     /* EDK_SUMS_BYTES: the windows' sums of a small pass */
   hipStream_t side;   /* the exact path runs here, beside the main kernel */
   hipEvent_t ev_prepared, ev_exact;
-  int algo;           /* 0: half-length scalars (four lanes per item up to 2^15 items, one above); 1: always full-length; 2: half-length, one lane per item */
+  int algo;           /* 0: half-length scalars (four lanes per item up to 24 576 items, one above); 1: always full-length; 2: half-length, one lane per item; 3: the mid-size arrangement below 2^18 items */
   int exact_offcurve; /* 1: replay the reference's chain for off-curve keys (default); 0: reject them; 2: replay for every item */
 } edk_verify_ws;
 

@@ -473,8 +473,8 @@ constexpr size_t QUAD_MAIN_MAX_N = (size_t)1 << 14;   // measured: 0.57 vs 0.86 
 #ifndef HALF_QUAD_LOG2
 #define HALF_QUAD_LOG2 15
 #endif
-// k_verify_prepare_pair + k_verify_main_half_quad up to here.  Measured (tools/verify_small.py, valid signatures, ms per pass):
-// 2^15 items 0.74 against 1.12 with one lane per item, 2^16 items 1.15 against 1.30 but 1.59 against 1.27 on the config-2 mix
+// the upper bound of k_verify_prepare_pair + k_verify_main_half_quad when the mid-size arrangement below is switched off
+// (algo 0 takes that one above PAIR_ONE_MIN_N items, so the four-lane evaluation serves passes of up to 24 576 items)
 constexpr size_t HALF_QUAD_MAX_N = (size_t)1 << HALF_QUAD_LOG2;
 // Between 24 576 and 2^18 items: k_verify_prepare_pair, then the ONE-lane evaluation with the long loop in place.  Measured
 // (tools/verify_mid.py, valid signatures, ms): 2^15 0.68 (four-lane evaluation) / 0.70 (one lane per item throughout) -> 0.58,
@@ -939,7 +939,7 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   const unsigned blocks = (unsigned)((n + BLOCK - 1) / BLOCK);
   (void)hipMemsetAsync(ws->offcount, 0, sizeof(uint32_t), stream);
   if (marks) (void)hipEventRecord(marks[0], stream);
-  // algo 0: half-length scalars - lane pairs and quads up to 2^14 items, the pairs' preparation and one lane per item up to 2^18, one lane per item above;
+  // algo 0: half-length scalars - the three-lane preparation and four lanes per item up to 24 576 items, the same preparation and one lane per item up to 2^18, one lane per item above;
   // 3: the mid-size arrangement at any size below 2^18;
   // 1: full-length windows (one lane per item above QUAD_MAIN_MAX_N items, quads below); 2: half-length, one lane per item
   const bool small = n <= QUAD_MAIN_MAX_N;
