@@ -28,7 +28,7 @@ def always_combine(engine):
     engine.set_rlc_min_items(3 << 17)
 
 
-@pytest.mark.parametrize("case", range(24))
+@pytest.mark.parametrize("case", range(len(SIZES) + 5))
 def test_fuzz_against_the_oracle(engine, oracle, device_set, case):
     rng = np.random.default_rng(1000 + case)
     n = int(SIZES[case % len(SIZES)]) if case < len(SIZES) else int(rng.integers(1, 9000))
