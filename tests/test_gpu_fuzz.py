@@ -28,10 +28,11 @@ def always_combine(engine):
     engine.set_rlc_min_items(3 << 17)
 
 
-@pytest.mark.parametrize("case", range(len(SIZES) + 5))
+# EDDSA_FUZZ_EXTRA=k adds k more random cases (a longer soak after kernel changes)
+@pytest.mark.parametrize("case", range(len(SIZES) + 5 + int(__import__("os").environ.get("EDDSA_FUZZ_EXTRA", "0"))))
 def test_fuzz_against_the_oracle(engine, oracle, device_set, case):
     rng = np.random.default_rng(1000 + case)
-    n = int(SIZES[case % len(SIZES)]) if case < len(SIZES) else int(rng.integers(1, 9000))
+    n = int(SIZES[case % len(SIZES)]) if case < len(SIZES) else int(rng.integers(1, 9000 if case < len(SIZES) + 5 else 70000))
     sk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
     ragged = case % 3 == 1
     if ragged:
