@@ -1,3 +1,4 @@
+"""Latency of one call of each single-item function (batch of one, host buffers) and of small verify batches."""
 import time, numpy as np, sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import libeddsa_amd as ed

@@ -1,3 +1,4 @@
+"""Host buffer to host buffer rates of verify / x25519 / sign for several chunk schedules and kernel orderings of the host pipeline (eddsa_amd_set_pipeline, eddsa_amd_set_pipeline_chain)."""
 import os, sys, time
 import numpy as np
 ROOT = "/root/repo"

@@ -1,3 +1,4 @@
+"""Mid-size verify passes: the default routes (algo 0), the mid-size arrangement forced (3) and one lane per item throughout (2) - verdicts against the constructed ones, then ms per pass."""
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tools"))
 import libeddsa_amd as ed, workload

@@ -1,3 +1,4 @@
+"""One verify pass (config-2 mix, device-resident) by size: SIZES=19,18,17 python tools/verify_sizes.py"""
 import os, sys, time
 import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")

@@ -1,3 +1,4 @@
+"""Time of one x25519 pass for small and mid-size batches, device-resident, back to back."""
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tools"))
 import libeddsa_amd as ed, workload
