@@ -159,6 +159,18 @@ ED_DEV void ge_to_cached(ge_cached& c, const ge& p) {
 }
 
 // -q for table entries (ed.c:386-390: swap diff/sum, negate prod), applied when flag is set
+// r = the affine point (x, y) of a niels entry (y-x, y+x, 2dxy), i.e. the neutral element plus the entry, as
+// (X : Y : Z : T) = (4x : 4y : 4 : 4xy): one multiplication where the general addition has seven.  The neutral entry
+// (1, 1, 0) gives (0 : 4 : 4 : 0).
+ED_DEV void ge_from_niels(ge& r, const ge_niels& q) {
+  fe e, h;
+  fe_sub(e, q.ypx, q.ymx);                       // 2x, 3u
+  fe_add(h, q.ypx, q.ymx);                       // 2y, 2u
+  fe_mul(r.T, e, h);                             // 4xy
+  fe_add(r.X, e, e); fe_carry(r.X);              // 4x, tight
+  fe_add(r.Y, h, h); fe_carry(r.Y);              // 4y, tight
+  fe_set(r.Z, 4);
+}
 ED_DEV void ge_cached_cneg(ge_cached& q, bool flag) {
   fe_cswap(q.ymx, q.ypx, flag);
   fe n;

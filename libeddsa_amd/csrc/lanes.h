@@ -899,7 +899,6 @@ ED_DEV void scale_base_lane(ge& out, const uint32_t xw[8], const uint32_t* comb,
     y[8] = go ? y[8] >> (2 * COMB_W) : y[8];
   }
   ge r0, r1;
-  ge_neutral(r0); ge_neutral(r1);
 #pragma unroll 1
   for (int i = 0; i < (COMB_ROWS + PARTS - 1) / PARTS; i++) {
     const int row = PARTS * i + part;
@@ -913,9 +912,9 @@ ED_DEV void scale_base_lane(ge& out, const uint32_t xw[8], const uint32_t* comb,
     }
     ge_niels e;
     comb_select(e, comb, valid ? row : 0, valid ? two & ((1u << COMB_W) - 1u) : (uint32_t)COMB_HALF);
-    ge_add_niels(r0, r0, e, true);
+    if (i == 0) ge_from_niels(r0, e); else ge_add_niels(r0, r0, e, true);      // (the first entry IS the sum so far: one multiplication instead of seven)
     comb_select(e, comb, valid ? row : 0, valid ? two >> COMB_W : (uint32_t)COMB_HALF);
-    ge_add_niels(r1, r1, e, true);
+    if (i == 0) ge_from_niels(r1, e); else ge_add_niels(r1, r1, e, true);
   }
 #pragma unroll 1
   for (int k = 0; k < COMB_W; k++) ge_dbl(r1, r1, k == COMB_W - 1);
