@@ -480,6 +480,7 @@ constexpr size_t HALF_QUAD_MAX_N = (size_t)1 << HALF_QUAD_LOG2;
 // (tools/verify_mid.py, valid signatures, ms): 2^15 0.68 (four-lane evaluation) / 0.70 (one lane per item throughout) -> 0.58,
 // 2^16 0.71-0.76 -> 0.66, 2^17 1.30 -> 1.28; the config-2 mix, whose floor is the exact path: 2^16 1.16 -> 1.11, else equal.
 constexpr size_t PAIR_ONE_MIN_N = (size_t)3 << 13;   // the four-lane evaluation steps up with every 8192 items (0.35 / 0.51 / 0.69 ms: tools/verify_cross.py), this one stays at 0.58
+constexpr size_t QUAD_WIDE_MIN_N = 256;               // four-lane passes above this search pairs up to 2^138 as well (see edk_verify)
 constexpr size_t HALF_WIDE_MIN_N = (size_t)1 << 18;   // one-lane passes below this search pairs up to 2^138 (see edk_verify)
 __global__ void __launch_bounds__(QUAD_BLOCK, 2)
 k_verify_main_quad(const uint32_t* digits, const uint32_t* table, const uint32_t* base16, uint32_t* accout, size_t n) {
@@ -825,13 +826,14 @@ k_verify_prepare_pair(edk_verify_src src, size_t n, uint32_t* digits, uint32_t* 
   }
 }
 
+template <int WINDOWS>
 __global__ void __launch_bounds__(QUAD_BLOCK, 2)
 k_verify_main_half_quad(uint8_t* ok, const uint32_t* hdigits, const uint32_t* table, const uint32_t* rtable,
                         const uint32_t* base16, const uint8_t* flags, size_t n, int exact_offcurve) {
   const size_t i = ((size_t)blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;      // quads are all-or-nothing
   if (i >= n) return;
   const int q = (int)(threadIdx.x & 3u);
-  const bool neutral = verify_half_main_quad(hdigits + HALF_DIGIT_WORDS * i, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
+  const bool neutral = verify_half_main_quad<WINDOWS>(hdigits + HALF_DIGIT_WORDS * i, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
                                              rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16, q);
   if (q != 0) return;
   const uint8_t fl = flags[i];
@@ -844,21 +846,23 @@ k_verify_main_half_quad(uint8_t* ok, const uint32_t* hdigits, const uint32_t* ta
 
 // The smallest passes (quad_lanes.h: verify_half_window_sum_quad): block i adds up the 64 windows of item i, one quad each;
 // then the chain over the sums.
+template <int WINDOWS>
 __global__ void __launch_bounds__(QUAD_BLOCK, 2)
 k_verify_window_sums(uint32_t* sums, const uint32_t* hdigits, const uint32_t* table, const uint32_t* rtable, const uint32_t* base16) {
   const size_t i = blockIdx.x;
   const int w = (int)(threadIdx.x >> 2), q = (int)(threadIdx.x & 3u);
-  verify_half_window_sum_quad(sums + (i * HALF_LONG_WINDOWS + (size_t)w) * HALF_SUM_WORDS, hdigits + HALF_DIGIT_WORDS * i,
+  verify_half_window_sum_quad<WINDOWS>(sums + (i * HALF_LONG_WINDOWS + (size_t)w) * HALF_SUM_WORDS, hdigits + HALF_DIGIT_WORDS * i,
                               table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
                               base16, w, q);
 }
 
+template <int WINDOWS>
 __global__ void __launch_bounds__(QUAD_BLOCK, 2)
 k_verify_main_sums_quad(uint8_t* ok, const uint32_t* hdigits, const uint32_t* sums, const uint8_t* flags, size_t n, int exact_offcurve) {
   const size_t i = ((size_t)blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;      // quads are all-or-nothing
   if (i >= n) return;
   const int q = (int)(threadIdx.x & 3u);
-  const bool neutral = verify_half_main_sums_quad(hdigits + HALF_DIGIT_WORDS * i, sums + i * (HALF_LONG_WINDOWS * HALF_SUM_WORDS), q);
+  const bool neutral = verify_half_main_sums_quad<WINDOWS>(hdigits + HALF_DIGIT_WORDS * i, sums + i * (HALF_LONG_WINDOWS * HALF_SUM_WORDS), q);
   if (q != 0) return;
   const uint8_t fl = flags[i];
   if ((fl & 1) == 0) {                           // the exact path owns this verdict
@@ -952,14 +956,22 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   const bool half = !pair_one && (algo == 2 || (algo == 0 && !small_half));
   const bool half_quad = !pair_one && algo == 0 && small_half;
   const unsigned pair_point_blocks = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
+  // The four-lane evaluation runs 64 windows in the wave of an item without a short pair, and the pass waits for that wave:
+  // with pairs up to 2^134 (8.5 items in 10^5) a pass of 2048 items has such an item one time in six, one of 2^14 three
+  // times in four.  Above QUAD_WIDE_MIN_N items the search goes up to 2^138 (2 in 10^7) for a 35th window in every item.
+  const bool quad_wide = half_quad && n > QUAD_WIDE_MIN_N;
   if (pair_one)
     hipLaunchKernelGGL(k_verify_prepare_pair<HALF_BITS_SMALL>, dim3(pair_point_blocks + blocks), dim3(BLOCK), 0, stream, src, n,
                        ws->digits, ws->hdigits, ws->table, ws->rtable, ws->flags, ws->offlist, ws->offcount, ws->exact_offcurve == 2,
                        pair_point_blocks);
-  else if (half_quad)
-    hipLaunchKernelGGL(k_verify_prepare_pair<HALF_BITS>, dim3((unsigned)((2 * n + BLOCK - 1) / BLOCK + (n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, src, n,
+  else if (quad_wide)
+    hipLaunchKernelGGL(k_verify_prepare_pair<HALF_BITS_SMALL>, dim3(pair_point_blocks + blocks), dim3(BLOCK), 0, stream, src, n,
                        ws->digits, ws->hdigits, ws->table, ws->rtable, ws->flags, ws->offlist, ws->offcount, ws->exact_offcurve == 2,
-                       (unsigned)((2 * n + BLOCK - 1) / BLOCK));
+                       pair_point_blocks);
+  else if (half_quad)
+    hipLaunchKernelGGL(k_verify_prepare_pair<HALF_BITS>, dim3(pair_point_blocks + blocks), dim3(BLOCK), 0, stream, src, n,
+                       ws->digits, ws->hdigits, ws->table, ws->rtable, ws->flags, ws->offlist, ws->offcount, ws->exact_offcurve == 2,
+                       pair_point_blocks);
   else
     hipLaunchKernelGGL(k_verify_prepare, dim3(blocks), dim3(BLOCK), 0, stream, src, n, ws->digits, ws->table, ws->flags, ws->offlist, ws->offcount,
                        ws->exact_offcurve == 2);
@@ -987,13 +999,23 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   }
   if (half_quad && n <= EDK_SUMS_MAX_ITEMS) {
     static_assert(QUAD_BLOCK == 4 * HALF_LONG_WINDOWS, "a block of k_verify_window_sums is the windows of one item");
-    hipLaunchKernelGGL(k_verify_window_sums, dim3((unsigned)n), dim3(QUAD_BLOCK), 0, stream, ws->sums, ws->hdigits, ws->table, ws->rtable, base16);
-    hipLaunchKernelGGL(k_verify_main_sums_quad, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, stream,
-                       ok, ws->hdigits, ws->sums, ws->flags, n, ws->exact_offcurve);
+    if (quad_wide) {
+      hipLaunchKernelGGL(k_verify_window_sums<HALF_WINDOWS_SMALL>, dim3((unsigned)n), dim3(QUAD_BLOCK), 0, stream, ws->sums, ws->hdigits, ws->table, ws->rtable, base16);
+      hipLaunchKernelGGL(k_verify_main_sums_quad<HALF_WINDOWS_SMALL>, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, stream,
+                         ok, ws->hdigits, ws->sums, ws->flags, n, ws->exact_offcurve);
+    } else {
+      hipLaunchKernelGGL(k_verify_window_sums<HALF_WINDOWS>, dim3((unsigned)n), dim3(QUAD_BLOCK), 0, stream, ws->sums, ws->hdigits, ws->table, ws->rtable, base16);
+      hipLaunchKernelGGL(k_verify_main_sums_quad<HALF_WINDOWS>, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, stream,
+                         ok, ws->hdigits, ws->sums, ws->flags, n, ws->exact_offcurve);
+    }
     if (marks) { (void)hipEventRecord(marks[2], stream); (void)hipEventRecord(marks[3], stream); }
   } else if (half_quad) {
-    hipLaunchKernelGGL(k_verify_main_half_quad, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, stream,
-                       ok, ws->hdigits, ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
+    if (quad_wide)
+      hipLaunchKernelGGL(k_verify_main_half_quad<HALF_WINDOWS_SMALL>, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, stream,
+                         ok, ws->hdigits, ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
+    else
+      hipLaunchKernelGGL(k_verify_main_half_quad<HALF_WINDOWS>, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, stream,
+                         ok, ws->hdigits, ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
     if (marks) { (void)hipEventRecord(marks[2], stream); (void)hipEventRecord(marks[3], stream); }
   } else if (half || pair_one) {
 #ifdef MAIN_HALF_LDS_KB

@@ -328,11 +328,12 @@ ED_DEV void verify_main_quad(fe& r, const uint32_t* digits, const uint32_t* tab,
 // lanes.h: verify_half_main_lane (the half-length evaluation, halve.h) with four lanes per item, for small passes:
 // same digits, tables and field expressions, so the same projective result; returns, in every lane of the quad,
 // whether that result is the neutral element.
+template <int WINDOWS = HALF_WINDOWS>
 ED_DEV bool verify_half_main_quad(const uint32_t* hd, const uint32_t* tab_a, const uint32_t* tab_r, const uint32_t* base16, int q) {
   fe r;
   fe_set(r, (uint32_t)(q & 1));                  // neutral element (0, 1, 0, 1) as (X, Y, T, Z)
   const bool uneg = (hd[24] & 1u) != 0, is_long = (hd[24] & 2u) != 0;
-  const int top = (__any(is_long) ? HALF_LONG_WINDOWS : HALF_WINDOWS) - 1;   // the wave's loop (lanes.h: verify_half_main_lane)
+  const int top = (__any(is_long) ? HALF_LONG_WINDOWS : WINDOWS) - 1;   // the wave's loop (lanes.h: verify_half_main_lane)
 #pragma unroll 1
   for (int w = top; w >= 0; w--) {
     // the lane's coordinate of the window's two per-item entries: requested before the doublings, consumed after them
@@ -398,11 +399,12 @@ ED_DEV bool verify_half_main_quad(const uint32_t* hd, const uint32_t* tab_a, con
 #define HALF_SUM_WORDS 40                              /* a sum as its four stage-A multipliers y-x | y+x | 2d*t | 2z, ten limbs each */
 
 // S_w of one item as multipliers at `out`; q = lane & 3.  hd, tab_a, tab_r as for verify_half_main_quad.
+template <int WINDOWS = HALF_WINDOWS>
 ED_DEV void verify_half_window_sum_quad(uint32_t* out, const uint32_t* hd, const uint32_t* tab_a, const uint32_t* tab_r,
                                         const uint32_t* base16, int w, int q) {
   const bool uneg = (hd[24] & 1u) != 0, is_long = (hd[24] & 2u) != 0;
   fe r;
-  if (w >= (is_long ? HALF_LONG_WINDOWS : HALF_WINDOWS)) {
+  if (w >= (is_long ? HALF_LONG_WINDOWS : WINDOWS)) {
     fe_set(r, q == 3 ? 2u : q == 2 ? 0u : 1u);   // the neutral element's multipliers (1, 1, 0, 2): a wave with a long item runs 64 windows
   } else {
     {                                            // the neutral element plus an entry: stage A is (y-x, y+x, 0, 2z) itself
@@ -451,11 +453,12 @@ ED_DEV void verify_half_window_sum_quad(uint32_t* out, const uint32_t* hd, const
 }
 
 // the chain over the sums; returns, in every lane of the quad, whether the result is the neutral element
+template <int WINDOWS = HALF_WINDOWS>
 ED_DEV bool verify_half_main_sums_quad(const uint32_t* hd, const uint32_t* sums, int q) {
   fe r;
   fe_set(r, (uint32_t)(q & 1));                  // neutral element (0, 1, 0, 1) as (X, Y, T, Z)
   const bool is_long = (hd[24] & 2u) != 0;
-  const int top = (__any(is_long) ? HALF_LONG_WINDOWS : HALF_WINDOWS) - 1;
+  const int top = (__any(is_long) ? HALF_LONG_WINDOWS : WINDOWS) - 1;
 #pragma unroll 1
   for (int w = top; w >= 0; w--) {
     fe mult, first, m;
