@@ -12,6 +12,9 @@ echo
 echo "== tools/verify_small.py: one pass, device-resident, ms"
 python3 tools/verify_small.py 2>&1 | grep "algo 0"
 echo
+echo "== tools/verify_long_items.py: small passes over twelve different batches of genuine signatures"
+python3 tools/verify_long_items.py 2>&1 | grep "n="
+echo
 echo "== tools/fixed_small.py: one pass of the fixed-base operations, device-resident, ms"
 python3 tools/fixed_small.py 2>&1 | grep -v amdgpu.ids
 echo
