@@ -143,9 +143,9 @@ EDDSA_AMD_DECL int eddsa_amd_dump_tables(uint32_t *base16_words, uint32_t *comb_
 EDDSA_AMD_DECL void eddsa_amd_set_offcurve_mode(int exact);
 /* Which evaluation ed25519_verify* uses; the verdicts are the same.  0 (default): every pass checks
  * u*(S*B - t*A - R) = 0 with half-length u, v = u*t mod 8l (132 doublings instead of 252; csrc/halve.h) - passes of
- * up to 24 576 items with four lanes per item, larger ones with one (below 2^18 items with u, v < 2^138 and 35
- * windows, so that hardly any item needs the slower reference-order path, and with the small passes' three-lane
- * preparation); 1: the full-length evaluation of S*B - t*A (four lanes per item up to 2^14 items); 2: the half-length
+ * up to 24 576 items with four lanes per item, larger ones with one (passes of 257 .. 2^18 - 1 items with u, v < 2^138
+ * and 35 windows, so that hardly any item is left without a short pair - such an item costs its wave 64 windows or a
+ * trip through the reference-order path - and passes below 2^18 items with a three-lane preparation); 1: the full-length evaluation of S*B - t*A (four lanes per item up to 2^14 items); 2: the half-length
  * one with one lane per item whatever the size; 3: the arrangement of 24 577 .. 2^18 items at any size below 2^18.
  * A measurement and test aid. */
 EDDSA_AMD_DECL void eddsa_amd_set_verify_algo(int algo);
