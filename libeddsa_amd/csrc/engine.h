@@ -89,6 +89,7 @@ struct pipe {
 struct creq;
 #define COMB_KINDS 8                  /* hjob.kind: 1 verify, 2 sign, 3 x25519, 4 genpub, 5 x25519_base, 6 pk->x, 7 sk->x; 0: never combined */
 struct comb_kind {
+    uint32_t gen;                     /* bumped when a launch of this operation completes; its waiters sleep on it (futex) */
     int active;                       /* some thread is packing / running a launch of this operation */
     unsigned queued, last_reqs, waiting_at_end;   /* requests waiting; calls the last launch carried; requests waiting when it ended */
     void *h_in[PIPE_MAX_IN]; size_t h_in_cap[PIPE_MAX_IN];     /* pinned: the packed batch */
@@ -98,7 +99,6 @@ struct comb_kind {
 };
 struct combiner {
     pthread_mutex_t lk;
-    uint32_t gen;                     /* bumped when a launch completes; waiters sleep on it (futex) */
     struct creq *head, *tail;
     struct comb_kind kind[COMB_KINDS];
     unsigned long batches, items;     /* statistics: combined launches, calls they carried */
