@@ -31,7 +31,9 @@ point (for the record; `value` never includes transfers), `secondary.verify_smal
 call and of a batch of 256 through the same entry points, and `secondary.verify_sustained` repeats the config-2 pass back to back for --sustained seconds (default 10)
 and reports the rate of the last half with the power and clock rocm-smi shows: the headline region lasts 0.2 s,
 which a power-bound chip runs above its steady-state clock.  At N > 1 `per_rank` breaks the step down by rank
-(kernel ms, gather ms, wall ms, the slowest rank), so that a scaling point can be attributed.
+(device, kernel ms, gather ms, wall ms, clock and power, the slowest rank) and `rccl` states what the result gather ran over
+(world size == N, backend, RCCL version, every rank on a device of its own - the run exits non-zero otherwise), so that a
+scaling point can be attributed.
 """
 import argparse
 import ctypes
@@ -263,6 +265,53 @@ def sustained_verify(w, n, seconds, local, burst_rate):
                     "clock it can hold; this is the steady state"}
 
 
+def garbage_keys(w, m, steps, device):
+    """The worst case a caller can construct: the config's genuine signatures under RANDOM 32-byte keys.  ed_import never
+    fails (reference lib/ed.c:100-149), about half of all strings are no curve point, and for those the reference's bytes
+    depend on its exact sequence of formulas - so half the batch goes through the reference-order chain
+    (k_verify_exact_quad, four lanes per item, strided over the whole work list) on top of the windowed pass.  Verdicts
+    checked against the compiled reference (else the oracle) on a sample."""
+    g = torch.Generator(device="cpu").manual_seed(20250104)
+    keys = torch.randint(0, 256, (m, 32), dtype=torch.uint8, generator=g)
+    keep = torch.arange(m) % 16 == 3                          # one genuine key in sixteen stays: some accepts to check
+    keys[keep] = w["valid"][1][:m].cpu()[keep]
+    dk = keys.to(device)
+    sig, msg = w["valid"][0][:m], w["valid"][2][:m]
+    for _ in range(2):
+        ok = ed.ed25519_verify_batch(sig, dk, msg, msg_len=32)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        ok = ed.ed25519_verify_batch(sig, dk, msg, msg_len=32)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    sample = min(4096, m)
+    hs, hk, hm = (np.ascontiguousarray(t[:sample].cpu().numpy()) for t in (sig, dk, msg))
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    want = np.zeros(sample, np.uint8)
+    refdrv = os.path.join(ROOT, "oracle", "_ref", "libref_driver.so")
+    if os.path.exists(refdrv):
+        ctypes.CDLL(refdrv).refdrv_verify_batch(P(want), P(hs), P(hk), P(hm), ctypes.c_size_t(32), ctypes.c_size_t(sample), usable_cores())
+    else:
+        ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so")).orc_ed25519_verify_batch(
+            P(want), P(hs), P(hk), P(hm), ctypes.c_size_t(32), ctypes.c_size_t(sample), usable_cores())
+    got = ok.cpu().numpy()
+    p, d = 2**255 - 19, (-121665 * pow(121666, 2**255 - 21, 2**255 - 19)) % (2**255 - 19)
+    off = 0
+    for row in hk[:1024]:                                     # which keys are no curve point: (y^2 - 1) / (d y^2 + 1) is no square
+        y = int.from_bytes(row.tobytes(), "little") % 2**255 % p
+        x2 = (y * y - 1) * pow(d * y * y + 1, p - 2, p) % p
+        off += x2 != 0 and pow(x2, (p - 1) // 2, p) != 1
+    good = bool(np.array_equal(got[:sample], want)) and int(got.sum()) == int(keep.sum()) and bool(np.array_equal(got.astype(bool), keep.numpy()))
+    return {"metric": "ed25519 verifies/sec, worst case: genuine signatures under random 32-byte keys (one genuine key in 16 kept)",
+            "value": m / (ms * 1e-3), "unit": UNIT["verify"], "ms_per_step": ms, "items": m, "accepted": int(got.sum()),
+            "off_curve_fraction_of_1024_keys": off / min(1024, sample), "outputs_correct": good,
+            "note": "keys that are no curve point take the reference-order chain (bit-exactness needs the reference's own "
+                    "sequence of formulas there); checked against the reference on the first 4096 items"}
+
+
 def gather_results(out, world, everywhere=True):
     """N > 1: the final result gather, the only exchange of the path.  Verdict bytes (1 B per item) are
     all-gathered, so that every rank holds the whole vector; the 32- and 64-byte results of x25519 and sign are
@@ -317,7 +366,9 @@ def per_rank_breakdown(world, rank, steps, k_ms, g_ms):
     """N > 1: every rank's kernel ms, gather ms and wall ms per step, collected at rank 0 over the host group"""
     if world == 1:
         return None
-    mine = {"rank": rank, "kernel_ms": k_ms, "gather_ms": g_ms, "wall_ms_per_step": LOCAL_ELAPSED[0] / steps * 1e3}
+    smi = SmiSampler(torch.cuda.current_device()).read()     # one sample right after the region: boxes (and ranks) differ in the clock they hold
+    mine = {"rank": rank, "device": torch.cuda.current_device(), "kernel_ms": k_ms, "gather_ms": g_ms,
+            "wall_ms_per_step": LOCAL_ELAPSED[0] / steps * 1e3, "power_w": smi[1] if smi else None, "sclk_mhz": smi[2] if smi else None}
     rows = [None] * world
     dist.all_gather_object(rows, mine, group=HOST_GROUP[0])
     slow = max(rows, key=lambda r: r["kernel_ms"])       # (the walls agree: every step ends in the gather, which waits for this one)
@@ -326,6 +377,29 @@ def per_rank_breakdown(world, rank, steps, k_ms, g_ms):
             "gather_ms_max": max(r["gather_ms"] for r in rows),
             "note": "kernel_ms: HIP events around the pass on the rank's stream; gather_ms: from the kernels' end to the end of the "
                     "result gather on that stream (includes waiting for the slowest rank's kernels)"}
+
+
+def devices_distinct(devs, world, shared_gpu):
+    """every rank on a device of its own?  Otherwise exit non-zero - unless the one-GPU test hook asked for sharing"""
+    distinct = len(devs) == world and len(set(devs)) == world
+    if not distinct and not shared_gpu:
+        raise SystemExit(f"bench.py: {world} ranks on devices {devs}: one rank per GPU is the contract")
+    return distinct
+
+
+def collective_facts(world, backend, shared_gpu):
+    """N > 1: what the result gather ran over, and that every rank owns a device of its own.  Exits non-zero when two
+    ranks sit on one device (a scaling point measured that way would be meaningless) - unless the one-GPU test hook
+    EDDSA_BENCH_SHARE_GPU asked for exactly that, which the line then says."""
+    devs = [None] * world
+    dist.all_gather_object(devs, torch.cuda.current_device(), group=HOST_GROUP[0])
+    distinct = devices_distinct(devs, world, shared_gpu)
+    try:
+        ver = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
+    except Exception:                                       # noqa: BLE001  (a version string is not worth a failed run)
+        ver = None
+    return {"world": dist.get_world_size(), "backend": dist.get_backend(), "version": ver, "is_rccl": backend == "nccl",
+            "devices": devs, "devices_distinct": distinct, "shared_gpu_test_hook": bool(shared_gpu)}
 
 
 def all_ranks_agree(flag, world, device):
@@ -508,6 +582,10 @@ def main():
     }
     if per_rank:
         line["per_rank"] = per_rank
+    if world > 1:
+        line["rccl"] = collective_facts(world, backend, os.environ.get("EDDSA_BENCH_SHARE_GPU") == "1")
+        if line["rccl"]["world"] != args.gpus:
+            raise SystemExit(f"bench.py: the process group has {line['rccl']['world']} ranks, --gpus says {args.gpus}")
     secondary = {}
     if args.op == "all" and main_op == "verify":
         # SURVEY 8(f)-3, opt-in: the same items BEFORE corruption through ed25519_verify_batch_rlc (groups of 8192
@@ -574,6 +652,9 @@ def main():
             "metric": "latency of host-pointer calls, one caller in a loop", "single_ed25519_verify_ms": t_one * 1e3,
             "verify_batch_256_valid_ms": t_256 * 1e3, "outputs_correct": good,
             "note": "concurrent single-item calls are merged into one launch (tests/c/threaded_callers.c measures that)"}
+    if args.op == "all" and main_op == "verify" and world == 1:
+        secondary["verify_garbage_keys"] = garbage_keys(w, min(n, 1 << 20), args.steps, device)
+        correct = correct and secondary["verify_garbage_keys"]["outputs_correct"]
     if args.op == "all" and main_op == "verify" and world == 1 and args.sustained > 0:
         secondary["verify_sustained"] = sustained_verify(w, n, args.sustained, local, line["value"])
         correct = correct and secondary["verify_sustained"]["outputs_correct"]

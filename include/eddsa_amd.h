@@ -48,6 +48,8 @@
  * Host memory: ordinary (malloc) memory is staged through page-locked buffers by a few copier threads
  * (eddsa_amd_set_host_threads); page-locked caller memory (eddsa_amd_host_alloc, hipHostMalloc,
  * hipHostRegister) is used in place.
+ * Test and measurement hooks (fault injection, route selection, probes, traces) are NOT part of this contract: they are
+ * declared in eddsa_amd_debug.h and inert unless a test arms them.
  * Secrets: the staging copies of secret keys / scalars / shared secrets and the secret scalars that
  * cross kernel boundaries are zeroed in HBM before a call's stream work completes (the reference
  * wipes its stack after the same operations, lib/ed25519-sha512.c:77,136, lib/x25519.c:208,221).
@@ -111,28 +113,8 @@ EDDSA_AMD_DECL void eddsa_amd_host_free(void *p);
 /* helper threads that copy ordinary caller memory into the staging buffers beside the calling thread (default 6, at
  * most 16; 0 = the caller copies alone) */
 EDDSA_AMD_DECL void eddsa_amd_set_host_threads(int n);
-/* tuning (a measurement aid): items of the first chunk of a host-pointer call and of its later stages; 0 = the defaults
- * (2^17, then doubling up to 2^19 for verify and 2^18 for the other operations) */
-EDDSA_AMD_DECL void eddsa_amd_set_pipeline(size_t first_chunk, size_t stage_chunk);
-/* tuning (a measurement aid): how the kernels of consecutive chunks of a host-pointer call are ordered.  -1 (default):
- * each operation's own setting; 0: side by side; 1: in chunk order; 2: in chunk order, a verify chunk starting beside the
- * previous chunk's main kernel */
-EDDSA_AMD_DECL void eddsa_amd_set_pipeline_chain(int mode);
-/* measurement aid: host-side time stamps of the host-pointer pipeline (csrc/host_pipe.c); on != 0 switches recording on for
- * the calls that follow; returns the stamps of the last call: tag (0 call start, 1 lane drained, 2 inputs staged and
- * queued, 3 kernels queued, 4 download queued, 5 all lanes drained, 6 call end), chunk index, ms since the call started */
-EDDSA_AMD_DECL int eddsa_amd_debug_pipe_trace(int on, int *tags, unsigned *chunks, double *ms, int max);
-/* diagnostic: out[0] = launches the combiner of small host-pointer calls has made on the default device, out[1] = the
- * calls they carried (equal when no two calls ever met) */
-EDDSA_AMD_DECL int eddsa_amd_combiner_stats(uint64_t out[2]);
 /* human-readable text for a negative return value */
 EDDSA_AMD_DECL const char *eddsa_amd_strerror(int err);
-/* copy the device's generated tables out for inspection: base16 = 32769 entries k*B; comb = 704
- * entries comb[i][k] = (k+1)*4096^i*B, i < 22, k < 32 (the reference's ed_lookup[i][k], lib/ed.c:41-43,
- * is (k+1)*256^i*B: the same comb with 4-bit windows; row 0 coincides for k < 8); each entry 32
- * words: 10 radix-2^25.5 limbs of y-x, y+x, 2dxy, then 2 words of padding. */
-EDDSA_AMD_DECL int eddsa_amd_dump_tables(uint32_t *base16_words, uint32_t *comb_words);
-
 /* How ed25519_verify* treats a public key that does not decode to a curve point (the reference's
  * ed_import never fails, lib/ed.c:100-149).  exact != 0 (default): such items are evaluated in the
  * reference's own order of operations -- the only way to reproduce its bytes for them.  exact == 0:
@@ -141,42 +123,7 @@ EDDSA_AMD_DECL int eddsa_amd_dump_tables(uint32_t *base16_words, uint32_t *comb_
  * reference's order of operations (JSF/Shamir chain, lib/ed.c:455-507) and the windowed kernel's
  * result is ignored -- same verdicts, latency-bound, meant for self-checks. */
 EDDSA_AMD_DECL void eddsa_amd_set_offcurve_mode(int exact);
-/* Which evaluation ed25519_verify* uses; the verdicts are the same.  0 (default): every pass checks
- * u*(S*B - t*A - R) = 0 with half-length u, v = u*t mod 8l (132 doublings instead of 252; csrc/halve.h) - passes of
- * up to 24 576 items with four lanes per item, larger ones with one (passes of 257 .. 2^18 - 1 items with u, v < 2^138
- * and 35 windows, so that hardly any item is left without a short pair - such an item costs its wave 64 windows or a
- * trip through the reference-order path - and passes below 2^18 items with a three-lane preparation); 1: the full-length evaluation of S*B - t*A (four lanes per item up to 2^14 items); 2: the half-length
- * one with one lane per item whatever the size; 3: the arrangement of 24 577 .. 2^18 items at any size below 2^18.
- * A measurement and test aid. */
-EDDSA_AMD_DECL void eddsa_amd_set_verify_algo(int algo);
 EDDSA_AMD_DECL void eddsa_amd_set_rlc_min_items(size_t items);   /* see ed25519_verify_batch_rlc */
-/* diagnostic for the tests: the device's search for the half-length pair (u, v), v = u*t mod 8l, on n given scalars
- * t < l (32 bytes each, host memory); out48 per item: v (20 bytes, little-endian) | |u| (20) | u < 0 (1) | found (1) |
- * 6 bytes of padding.  wide != 0: |u|, v < 2^138 (what passes below 2^18 items use) instead of 2^134. */
-EDDSA_AMD_DECL int eddsa_amd_debug_halve(uint8_t *out48, const uint8_t *t32, size_t n, int wide);
-
-/* diagnostic for the tests: the half-length route re-verifies every pair with integers before it is used (u t = v mod 8 l)
- * and falls back to (u, v) = (1, t) when the check fails; *count = how often that has happened on the default device since
- * its workspaces were allocated.  Waits for the device.  Expected, and observed over the 2^24-item batch: 0. */
-EDDSA_AMD_DECL int eddsa_amd_halve_rejected(uint64_t *count);
-
-/* test hook: the next host-pointer call fails with hipErrorUnknown after its inputs were staged and its kernels launched
- * (exercises the error path: the staging copies of secrets are wiped there as on success) */
-EDDSA_AMD_DECL void eddsa_amd_debug_fail_next_host_call(void);
-
-/* measurement aid: when on, HIP events are recorded on the launch stream around the kernels
- * of every verify pass (up to 256 passes); eddsa_amd_verify_phase_ms() waits for them and returns
- * the average duration of each phase in milliseconds: out[0] k_verify_prepare (+ k_verify_halve), out[1] the main
- * kernel, out[2] k_verify_finish (the half-length route has none: 0). */
-EDDSA_AMD_DECL void eddsa_amd_set_profiling(int on);
-EDDSA_AMD_DECL int eddsa_amd_verify_phase_ms(float out[3]);
-/* diagnostic for the secret-hygiene tests: waits for the default device to go idle and counts the
- * non-zero bytes left in out[0] the scalar workspace (sign's secret scalars a, r between its two
- * kernels), out[1] the point workspace (x25519's (x2 : z2); public for the other operations),
- * out[2] the host pipeline's first input staging buffers (secret keys / scalars), out[3] its output
- * staging buffer. */
-EDDSA_AMD_DECL int eddsa_amd_secret_residue(uint64_t out[4]);
-
 /* ---- host-pointer entry points ---- */
 EDDSA_AMD_DECL int ed25519_verify_batch(uint8_t *ok, const uint8_t *sigs, const uint8_t *pubs,
                                         const uint8_t *msgs, const uint64_t *msg_off, size_t msg_len,

@@ -1,7 +1,7 @@
 """libeddsa_amd - Python host mirror of the MI355X Ed25519 / X25519 engine.
 
 Thin ctypes binding over the C-ABI library ``libeddsa_amd.so`` (include/eddsa.h,
-include/eddsa_amd.h).  Names, argument meaning and error behaviour mirror the reference's
+include/eddsa_amd.h; the test and measurement surface of include/eddsa_amd_debug.h is bound too).  Names, argument meaning and error behaviour mirror the reference's
 public header (reference lib/eddsa.h:44-113); the ``*_batch`` functions are the batched
 forms.  There is no CPU implementation behind any of them: importing works anywhere, but the
 first call that needs the GPU raises :class:`EddsaAmdError` if the library or a gfx950
@@ -10,7 +10,13 @@ device is missing.
 from .api import (  # noqa: F401
     EddsaAmdError,
     DH,
+    HOOKS_OFF,
+    debug_fail_hip_call,
+    debug_fail_next_host_call,
     debug_halve,
+    debug_hip_calls,
+    debug_init,
+    debug_layer,
     halve_rejected,
     host_array,
     host_free,

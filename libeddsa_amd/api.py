@@ -86,8 +86,50 @@ def init(device=None):
 
 
 def shutdown():
-    """release every device resource of the engine; the next call initialises it again"""
+    """release every device resource of the engine; the next call initialises it again (and disarms the test hooks)"""
     library().eddsa_amd_shutdown()
+
+
+# ---------------------------------------------------------------------------------------------
+# the test and measurement surface (include/eddsa_amd_debug.h); not part of the product contract
+# ---------------------------------------------------------------------------------------------
+
+HOOKS_OFF = -100002
+LAYER_OPS = {"fe_mul": 1, "fe_sq": 2, "fe_inv": 3, "fe_pow2523": 4, "fe_mul_loose": 5, "sc_reduce32": 6, "sc_reduce64": 7,
+             "sc_muladd": 8, "sha512": 9, "ed_import_export": 10, "ed_scale_base": 11, "ed_dual_scale": 12, "ge_dbl_add": 13}
+
+
+def debug_init(device=0, hooks=True):
+    """eddsa_amd_init(device), then arm (or disarm) the fault injectors and the layer probe"""
+    _check(library().eddsa_amd_debug_init(int(device), ctypes.c_uint(1 if hooks else 0)), "eddsa_amd_debug_init")
+
+
+def debug_fail_next_host_call():
+    """the next host-pointer call fails after its kernels were launched; returns HOOKS_OFF when the hooks are not armed"""
+    return int(library().eddsa_amd_debug_fail_next_host_call())
+
+
+def debug_fail_hip_call(nth):
+    """the nth checked HIP call of the verify passes from now on fails (0 disarms); HOOKS_OFF when not armed"""
+    return int(library().eddsa_amd_debug_fail_hip_call(int(nth)))
+
+
+def debug_hip_calls():
+    return int(library().eddsa_amd_debug_hip_calls())
+
+
+def debug_layer(op, items, out_w, form=0):
+    """run one layer of the device code (include/eddsa_amd_debug.h) on `items` (equal-length byte strings): -> list of
+    out_w-byte results.  Needs debug_init(hooks=True)."""
+    code = LAYER_OPS[op] if isinstance(op, str) else int(op)
+    n = len(items)
+    in_w = len(items[0]) if n else 32
+    assert all(len(x) == in_w for x in items)
+    buf = np.frombuffer(b"".join(items), np.uint8).copy() if n else np.zeros(1, np.uint8)
+    out = np.zeros(max(n, 1) * out_w, np.uint8)
+    _check(library().eddsa_amd_debug_layer(ctypes.c_int(code), ctypes.c_int(form), _np_ptr(out), _c_size(out_w), _np_ptr(buf),
+                                           _c_size(in_w), _c_size(n)), f"eddsa_amd_debug_layer({op})")
+    return [out[out_w * i:out_w * (i + 1)].tobytes() for i in range(n)]
 
 
 def verify_phase_ms():

@@ -26,6 +26,7 @@ static int g_offcurve_mode = 1;       /* eddsa_amd_set_offcurve_mode: 0 reject, 
 static int g_profiling;               /* record marks around the three verify kernels */
 static size_t g_rlc_min_items = (size_t)3 << 17;   /* eddsa_amd_set_rlc_min_items: smaller calls go to the per-item kernels */
 
+int g_hooks_armed;                     /* eddsa_amd_debug_init: read and written atomically */
 struct multi g_multi;                  /* the device set of the *_multi entry points (eddsa_amd_init_devices) */
 static pthread_mutex_t g_rccl_lk = PTHREAD_MUTEX_INITIALIZER;   /* one grouped RCCL call at a time (taken after g_table) */
 #define NCCL_UINT8 1                   /* ncclUint8, rccl.h */
@@ -340,9 +341,61 @@ void eddsa_amd_shutdown(void)
         g_eng[d] = NULL;
     }
     g_default = -1;
-    if (saved >= 0) (void)hipSetDevice(saved);
+    __atomic_store_n(&g_hooks_armed, 0, __ATOMIC_RELEASE);
+    (void)edk_debug_fail_in(0);
+    if (saved >= 0) (void)hipSetDevice(saved);   /* teardown: nothing to report to */
     pthread_rwlock_unlock(&g_table);
     host_pool_stop();
+}
+
+/* ------------------------------------------------------------------------------------------
+ * the test surface (include/eddsa_amd_debug.h): inert unless armed
+ * ---------------------------------------------------------------------------------------- */
+
+int eddsa_amd_debug_init(int device, unsigned flags)
+{
+    const int rc = eddsa_amd_init(device);
+    if (rc) return rc;
+    __atomic_store_n(&g_hooks_armed, (flags & EDDSA_AMD_TEST_HOOKS) != 0, __ATOMIC_RELEASE);
+    if (!(flags & EDDSA_AMD_TEST_HOOKS)) (void)edk_debug_fail_in(0);
+    return 0;
+}
+
+int eddsa_amd_debug_fail_hip_call(int nth)
+{
+    if (!__atomic_load_n(&g_hooks_armed, __ATOMIC_ACQUIRE)) return EDDSA_AMD_HOOKS_OFF;
+    (void)edk_debug_fail_in(nth < 0 ? 0 : nth);
+    return 0;
+}
+
+int eddsa_amd_debug_hip_calls(void)
+{
+    return edk_debug_fail_in(-1);
+}
+
+/* one layer of the device code on caller-given inputs (host memory): see include/eddsa_amd_debug.h */
+int eddsa_amd_debug_layer(int op, int form, uint8_t *out, size_t out_w, const uint8_t *in, size_t in_w, size_t n)
+{
+    struct call c;
+    uint8_t *d_in = NULL, *d_out = NULL;
+    int rc;
+    if (!__atomic_load_n(&g_hooks_armed, __ATOMIC_ACQUIRE)) return EDDSA_AMD_HOOKS_OFF;
+    if (!edk_debug_layer_widths_ok(op, form, in_w, out_w)) return -(int)hipErrorInvalidValue;
+    rc = enter(&c, -1);
+    if (rc) return rc;
+    if (n == 0) goto out;
+    TRY(hipMalloc((void **)&d_in, n * in_w));
+    TRY(hipMalloc((void **)&d_out, n * out_w));
+    TRY(hipMemcpy(d_in, in, n * in_w, hipMemcpyHostToDevice));
+    TRY(hipMemset(d_out, 0, n * out_w));
+    TRY(edk_debug_layer(op, form, d_out, out_w, d_in, in_w, n, c.e->base16, c.e->comb_img, NULL));
+    TRY(hipStreamSynchronize(NULL));
+    TRY(hipMemcpy(out, d_out, n * out_w, hipMemcpyDeviceToHost));
+out:
+    if (d_in) (void)hipFree(d_in);     /* probe buffers: public test data */
+    if (d_out) (void)hipFree(d_out);
+    leave(&c);
+    return rc;
 }
 
 int eddsa_amd_dump_tables(uint32_t *base16_words, uint32_t *comb_words)

@@ -33,7 +33,8 @@ hipError_t edk_init_tables(uint32_t* base16, uint32_t* comb, uint32_t* comb_img,
 
 #define EDK_SUMS_MAX_ITEMS ((size_t)1 << 11)          /* passes of up to this many items add their windows' sums first (kernels.hip: k_verify_window_sums) */
 #define EDK_SUMS_BYTES (EDK_SUMS_MAX_ITEMS * 64 * 40 * sizeof(uint32_t))   /* 64 windows x four multipliers of ten limbs per item */
-#define EDK_EXACT_PAD_BYTES ((size_t)65536 * 1536)   /* 65536 work-list entries x (four addends x five factors + two digit strings), >= the one-lane kernel's 1024 x 64 lanes x 292 words */
+#define EDK_EXACT_SLOTS 65536                        /* items k_verify_exact_quad has in flight at once (4096 waves of 16); a longer work list is walked in strides of this */
+#define EDK_EXACT_PAD_BYTES ((size_t)EDK_EXACT_SLOTS * 960)   /* per slot: four addends x five factors x 12 words (quad_lanes.h: QUAD_ITEM_WORDS) */
 
 /* verify workspace for up to `capacity` items (a multiple of VERIFY_TILE), all in HBM */
 typedef struct edk_verify_ws {
@@ -105,6 +106,13 @@ hipError_t edk_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, con
 hipError_t edk_x25519_base(uint8_t* out, const uint8_t* scalars, size_t n, const uint32_t* comb,
                            const edk_fixed_ws* ws, hipStream_t stream);
 hipError_t edk_debug_halve(uint8_t* out /* 48 bytes per item, device */, const uint8_t* t /* 32 per item, device */, size_t n, int wide, hipStream_t stream);
+/* test surface (include/eddsa_amd_debug.h).  edk_debug_fail_in: nth > 0 arms the fault (the nth checked HIP call of the
+ * verify passes from now on reports hipErrorUnknown instead of being made) and restarts the count; 0 disarms; < 0 only
+ * returns the number of checked calls made since the count was restarted */
+int edk_debug_fail_in(int nth);
+int edk_debug_layer_widths_ok(int op, int form, size_t in_w, size_t out_w);
+hipError_t edk_debug_layer(int op, int form, uint8_t* out, size_t out_w, const uint8_t* in, size_t in_w, size_t n,
+                           const uint32_t* base16, const uint32_t* comb_img, hipStream_t stream);
 hipError_t edk_pk_to_x(uint8_t* out, const uint8_t* in, size_t n, hipStream_t stream);
 hipError_t edk_sk_to_x(uint8_t* out, const uint8_t* in, size_t n, hipStream_t stream);
 

@@ -28,6 +28,7 @@
 
 #include "eddsa.h"
 #include "eddsa_amd.h"
+#include "eddsa_amd_debug.h"
 #include "eddsa_kernels.h"
 
 #define CHUNK_MAX ((size_t)1 << 20)   /* verify items per workspace pass: 1.6 GB of HBM workspace */
@@ -137,6 +138,7 @@ struct multi {
 extern pthread_rwlock_t g_table;
 extern struct engine *g_eng[MAX_DEVICES];
 extern struct multi g_multi;
+extern int g_hooks_armed;            /* eddsa_amd_debug_init(.., EDDSA_AMD_TEST_HOOKS): the fault injectors and the layer probe act (atomic) */
 
 /* Every call brackets its work with enter()/leave(): enter() resolves the engine (creating it on first use),
  * holds g_table for reading and makes the engine's device current for the calling thread; leave() restores the

@@ -88,9 +88,12 @@ void eddsa_amd_set_host_threads(int n)
     pthread_mutex_unlock(&g_pool.lk);
 }
 
+/* (two threads may shut the library down at once: the second waits for the first one's joins instead of joining the
+ * same threads again) */
 void host_pool_stop(void)
 {
     pthread_mutex_lock(&g_pool.lk);
+    while (g_pool.stop) pthread_cond_wait(&g_pool.done_cv, &g_pool.lk);
     const int n = g_pool.started;
     g_pool.stop = 1;
     pthread_cond_broadcast(&g_pool.work_cv);
@@ -99,6 +102,7 @@ void host_pool_stop(void)
     pthread_mutex_lock(&g_pool.lk);
     g_pool.started = 0;
     g_pool.stop = 0;
+    pthread_cond_broadcast(&g_pool.done_cv);
     pthread_mutex_unlock(&g_pool.lk);
 }
 
@@ -186,12 +190,18 @@ void eddsa_amd_host_free(void *p)
     if (p) (void)hipHostFree(p);
 }
 
-/* is [p, p + bytes) page-locked memory the DMA engines can read directly? */
-static int is_pinned(const void *p)
+/* is [p, p + bytes) page-locked memory the DMA engines can read directly?  Both ends must lie in the SAME page-locked
+ * allocation (an array whose head is registered and whose tail is pageable is staged like ordinary memory) */
+static int is_pinned(const void *p, size_t bytes)
 {
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    return a.type == hipMemoryTypeHost;
+    hipPointerAttribute_t a, b;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return 0; }   /* "not registered" is an answer, not a failure */
+    if (a.type != hipMemoryTypeHost) return 0;
+    if (bytes <= 1) return 1;
+    if (hipPointerGetAttributes(&b, (const uint8_t *)p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    /* the same allocation: its host base pointer is the same distance below both ends */
+    return b.type == hipMemoryTypeHost && a.hostPointer && b.hostPointer &&
+           (const uint8_t *)b.hostPointer - (const uint8_t *)a.hostPointer == (ptrdiff_t)(bytes - 1);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -412,18 +422,23 @@ out:
     return rc;
 }
 
-static int g_fail_next_host_call;      /* eddsa_amd_debug_fail_next_host_call */
+static int g_fail_next_host_call;      /* eddsa_amd_debug_fail_next_host_call: set and consumed atomically */
 
 /* measurement aid: host-side time stamps of the last host-pointer call (eddsa_amd_debug_pipe_trace) */
 #define TRACE_MAX 512
+/* one trace per process; stamps of concurrent calls interleave.  Slots are reserved atomically (leaders of different
+ * operations stamp at the same time), on / n / seen are read and written atomically */
 static struct { int on, n, seen; int tag[TRACE_MAX]; unsigned chunk[TRACE_MAX]; double t[TRACE_MAX]; } g_trace;
+#define TRACE_ON() __atomic_load_n(&g_trace.on, __ATOMIC_RELAXED)
 static double trace_now(void)
 {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double)ts.tv_sec * 1e3 + 1e-6 * (double)ts.tv_nsec;
 }
-#define TRACE(tag_, k_) do { if (g_trace.on && g_trace.n < TRACE_MAX) { g_trace.tag[g_trace.n] = (tag_); g_trace.chunk[g_trace.n] = (k_); g_trace.t[g_trace.n++] = trace_now(); } } while (0)
+#define TRACE(tag_, k_) do { if (TRACE_ON()) { const int i_ = __atomic_fetch_add(&g_trace.n, 1, __ATOMIC_RELAXED); \
+    if (i_ >= 0 && i_ < TRACE_MAX) { g_trace.tag[i_] = (tag_); g_trace.chunk[i_] = (k_); g_trace.t[i_] = trace_now(); } } } while (0)
+#define TRACE_RESTART() __atomic_store_n(&g_trace.n, 0, __ATOMIC_RELAXED)
 
 /* on != 0: record host-side time stamps in every host-pointer call from now on; returns the number of stamps of the last
  * call and copies up to `max` of them: tag (0 call start, 1 lane drained, 2 inputs staged and queued, 3 kernels queued,
@@ -432,22 +447,25 @@ static double trace_now(void)
  * by itself after the 20th combined launch of 32 calls or more, so that a typical launch under load can be read */
 int eddsa_amd_debug_pipe_trace(int on, int *tags, unsigned *chunks, double *ms, int max)
 {
-    pthread_rwlock_wrlock(&g_table);
-    const int n = g_trace.n < max ? g_trace.n : max;
+    pthread_rwlock_wrlock(&g_table);       /* no call in flight: nobody is stamping */
+    int n = __atomic_load_n(&g_trace.n, __ATOMIC_RELAXED);
+    n = n > TRACE_MAX ? TRACE_MAX : n;
+    n = n < max ? n : max;
     for (int i = 0; i < n; i++) { tags[i] = g_trace.tag[i]; chunks[i] = g_trace.chunk[i]; ms[i] = g_trace.t[i] - g_trace.t[0]; }
-    g_trace.on = on;
-    g_trace.seen = 0;
+    __atomic_store_n(&g_trace.on, on, __ATOMIC_RELAXED);
+    __atomic_store_n(&g_trace.seen, 0, __ATOMIC_RELAXED);
     pthread_rwlock_unlock(&g_table);
     return n;
 }
 
-/* test hook: the next host-pointer call fails (hipErrorUnknown) after its inputs were staged and its kernels launched,
- * so that the error path's clean-up (the staging copies of secrets are wiped there too) can be exercised */
-void eddsa_amd_debug_fail_next_host_call(void)
+/* test hook (inert unless armed, include/eddsa_amd_debug.h): the next host-pointer call fails (hipErrorUnknown) after its
+ * inputs were staged and its kernels launched, so that the error path's clean-up (the staging copies of secrets are wiped
+ * there too) can be exercised */
+int eddsa_amd_debug_fail_next_host_call(void)
 {
-    pthread_rwlock_wrlock(&g_table);
-    g_fail_next_host_call = 1;
-    pthread_rwlock_unlock(&g_table);
+    if (!__atomic_load_n(&g_hooks_armed, __ATOMIC_ACQUIRE)) return EDDSA_AMD_HOOKS_OFF;
+    __atomic_store_n(&g_fail_next_host_call, 1, __ATOMIC_RELEASE);
+    return 0;
 }
 
 /* One host-pointer job on engine e (its device is current).
@@ -471,20 +489,20 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
     const int tunable = j->stats == NULL;                       /* (a combination covers a fixed number of items) */
     const size_t stage = tunable && g_pipe_stage ? g_pipe_stage : j->chunk ? j->chunk : PIPE_CHUNK;
     const size_t first = tunable && g_pipe_first ? g_pipe_first : j->first_chunk ? j->first_chunk : PIPE_FIRST_CHUNK;
-    const size_t msg_total = !j->has_msgs ? 0 : ragged ? (size_t)j->msg_off[n] : n * j->msg_len;
+    const size_t msg_total = !j->has_msgs ? 0 : ragged ? (size_t)(j->msg_off[n] - j->msg_off[0]) : n * j->msg_len;
     /* one chunk, one lane (any); several chunks - and the batch verification, whose statistics live in the pipe - all of them */
-    const int all = j->stats != NULL || (!ragged && n > first);
+    const int all = j->stats != NULL || n > first;
     const int base = lanes_acquire(e, all);
     if (base < 0) return base;
 #define LANE_OF(k) (&p->lane[all ? (k) % PIPE_LANES : (unsigned)base])
-    if (g_trace.on && !j->traced) g_trace.n = 0;
+    if (TRACE_ON() && !j->traced) TRACE_RESTART();
     TRACE(0, 0);
     {
         struct lane *prev = NULL;
         for (int i = 0; i < j->n_in; i++)
-            staged_in[i] = !j->src_pinned && !(n * j->in_w[i] >= PIN_CHECK_MIN && is_pinned(j->in[i]));
-        staged_msgs = !j->src_pinned && !(msg_total >= PIN_CHECK_MIN && is_pinned(j->msgs));
-        staged_out = !j->src_pinned && !(n * j->out_w >= PIN_CHECK_MIN && is_pinned(j->out));
+            staged_in[i] = !j->src_pinned && !(n * j->in_w[i] >= PIN_CHECK_MIN && is_pinned(j->in[i], n * j->in_w[i]));
+        staged_msgs = !j->src_pinned && !(msg_total >= PIN_CHECK_MIN && is_pinned(ragged ? j->msgs + j->msg_off[0] : j->msgs, msg_total));
+        staged_out = !j->src_pinned && !(n * j->out_w >= PIN_CHECK_MIN && is_pinned(j->out, n * j->out_w));
         if (j->stats) {
             TRY(hipMemsetAsync(p->d_stats, 0, 16, p->lane[0].st));
             TRY(hipStreamSynchronize(p->lane[0].st));           /* the other lanes' kernels add to it too */
@@ -494,7 +512,7 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
             struct lane *L = LANE_OF(k);
             size_t m = first << (k < 8 ? k : 8);
             if (m > stage) m = stage;
-            if (ragged || !all || m > n - lo || n - lo - m < m / 2) m = n - lo;   /* (a short tail travels with the last chunk) */
+            if (!all || m > n - lo || n - lo - m < m / 2) m = n - lo;   /* (a short tail travels with the last chunk) */
             /* the lane's previous chunk (k - 3): the two chunks after it keep the GPU busy meanwhile */
             if (k >= PIPE_LANES && (rc = lane_drain(L, j->wipe, NULL))) goto out;    /* (every call leaves its lanes drained) */
             TRACE(1, k);
@@ -504,15 +522,26 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
             }
             if (staged_in[0]) L->used_in0 = m * j->in_w[0];
             if (j->has_msgs) {
-                const size_t bytes = ragged ? msg_total : m * j->msg_len;
-                const uint8_t *src = ragged ? j->msgs : j->msgs + lo * j->msg_len;
+                /* ragged messages: the chunk's own bytes, msg_off[lo] .. msg_off[lo + m) */
+                const size_t bytes = ragged ? (size_t)(j->msg_off[lo + m] - j->msg_off[lo]) : m * j->msg_len;
+                const uint8_t *src = ragged ? j->msgs + j->msg_off[lo] : j->msgs + lo * j->msg_len;
                 if ((rc = dev_grow(&L->d_msgs, &L->d_msgs_cap, bytes, L->st))) goto out;
                 if ((rc = lane_upload(L, L->d_msgs, &L->h_msgs, &L->h_msgs_cap, src, bytes, staged_msgs))) goto out;
             }
             if (ragged) {
-                if ((rc = dev_grow(&L->d_off, &L->d_off_cap, (n + 1) * sizeof(uint64_t), L->st))) goto out;
-                if ((rc = lane_upload(L, L->d_off, &L->h_off, &L->h_off_cap, (const uint8_t *)j->msg_off, (n + 1) * sizeof(uint64_t),
-                                      !j->src_pinned))) goto out;
+                /* ... and its own offset table, rebased to the chunk's first byte (the kernels index it by the item's
+                 * number inside the chunk).  A table that starts at 0 in page-locked memory - the combiner's - goes as it is. */
+                const size_t ob = (m + 1) * sizeof(uint64_t);
+                if ((rc = dev_grow(&L->d_off, &L->d_off_cap, ob, L->st))) goto out;
+                if (j->src_pinned && j->msg_off[lo] == 0) {
+                    TRY(hipMemcpyAsync(L->d_off, j->msg_off + lo, ob, hipMemcpyHostToDevice, L->st));
+                } else {
+                    if ((rc = host_grow(&L->h_off, &L->h_off_cap, ob))) goto out;
+                    uint64_t *ho = (uint64_t *)L->h_off;
+                    const uint64_t base0 = j->msg_off[lo];
+                    for (size_t t = 0; t <= m; t++) ho[t] = j->msg_off[lo + t] - base0;
+                    TRY(hipMemcpyAsync(L->d_off, ho, ob, hipMemcpyHostToDevice, L->st));
+                }
             }
             if ((rc = dev_grow(&L->d_out, &L->d_out_cap, m * j->out_w, L->st))) goto out;
             TRACE(2, k);
@@ -525,7 +554,7 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
             }
             prev = L;
             TRACE(3, k);
-            if (!rc && g_fail_next_host_call) { g_fail_next_host_call = 0; rc = -(int)hipErrorUnknown; }
+            if (!rc && __atomic_exchange_n(&g_fail_next_host_call, 0, __ATOMIC_ACQ_REL)) rc = -(int)hipErrorUnknown;
             if (rc) goto out;
             /* the download: queued by lane_drain, once the kernels are done */
             L->pend_via = NULL;
@@ -585,6 +614,7 @@ out:
 #define COMBINE_MAX_N 64                     /* items of a call that may be merged */
 #define COMBINE_MAX_BYTES ((size_t)1 << 20)  /* ... and its message bytes */
 #define COMBINE_MAX_BATCH 16384              /* items per combined launch */
+#define COMBINE_MAX_BATCH_BYTES ((size_t)64 << 20)   /* ... and its message bytes (pinned staging of the packed batch) */
 #define COMBINE_GATHER_NS 80000              /* how long a leader elected under contention waits for the callers of the previous batch */
 
 struct creq { const struct hjob *j; size_t n; int rc, done; struct creq *next; };
@@ -677,7 +707,8 @@ static int combiner_run(struct engine *e, struct comb_kind *K, struct creq *batc
     if (j0->wipe & WIPE_IN0) memset(K->h_in[0], 0, total * j0->in_w[0]);
     if (j0->wipe & WIPE_OUT) memset(K->h_out, 0, total * j0->out_w);
     TRACE(10, (unsigned)total);
-    if (g_trace.on == 2 && total >= 32 && ++g_trace.seen == 20) g_trace.on = 0;   /* on = 2: keep the 20th launch that carried 32 calls or more */
+    if (TRACE_ON() == 2 && total >= 32 && __atomic_add_fetch(&g_trace.seen, 1, __ATOMIC_RELAXED) == 20)
+        __atomic_store_n(&g_trace.on, 0, __ATOMIC_RELAXED);   /* on = 2: keep the 20th launch that carried 32 calls or more */
     return rc;
 }
 
@@ -719,7 +750,7 @@ static int combiner_submit(struct engine *e, const struct hjob *j, size_t n)
             continue;
         }
         K->active = 1;
-        if (g_trace.on) g_trace.n = 0;
+        if (TRACE_ON()) TRACE_RESTART();
         TRACE(7, 0);
         /* Under contention the callers of the launch that has just finished are about to queue again (they do within
          * microseconds of being woken): give them a moment, or the callers split into two camps that take turns and
@@ -742,15 +773,16 @@ static int combiner_submit(struct engine *e, const struct hjob *j, size_t n)
          * then it leads again) */
         TRACE(8, K->queued);
         struct creq *batch = NULL, *btail = NULL, **pp = &q->head, *last = NULL;
-        size_t total = 0, reqs = 0;
+        size_t total = 0, reqs = 0, bytes = 0;
         while (*pp) {
             struct creq *r = *pp;
-            if (r->j->kind == j->kind && total + r->n <= COMBINE_MAX_BATCH) {
+            const size_t rb = r->j->has_msgs ? r->n * r->j->msg_len : 0;
+            if (r->j->kind == j->kind && total + r->n <= COMBINE_MAX_BATCH && (reqs == 0 || bytes + rb <= COMBINE_MAX_BATCH_BYTES)) {
                 *pp = r->next;
                 r->next = NULL;
                 if (btail) btail->next = r; else batch = r;
                 btail = r;
-                total += r->n; reqs++;
+                total += r->n; reqs++; bytes += rb;
                 K->queued--;
             } else {
                 last = r;
@@ -762,13 +794,23 @@ static int combiner_submit(struct engine *e, const struct hjob *j, size_t n)
         struct hjob own = *j;
         own.traced = 1;
         const int rc = reqs == 1 && batch == &me ? pipe_run_on(e, &own, n) : combiner_run(e, K, batch, total);
+        for (struct creq *r = batch; r; r = r->next) r->rc = rc;
+        if (rc && reqs > 1) {
+            /* A merged launch shares one status, and the eddsa.h callers abort() on failure: before anybody is told, every
+             * request gets a run of its own (a transient error, or the packed batch's staging allocation, need not concern
+             * the others; a request that is itself the cause fails again, alone) */
+            for (struct creq *r = batch; r; r = r->next) {
+                struct hjob alone = *r->j;
+                alone.traced = 1;
+                r->rc = pipe_run_on(e, &alone, r->n);
+            }
+        }
         pthread_mutex_lock(&q->lk);
         q->batches++; q->items += reqs;
         K->last_reqs = (unsigned)reqs;
         K->waiting_at_end = K->queued;
         for (struct creq *r = batch; r;) {             /* a caller may return (and its request vanish) the moment `done` is set */
             struct creq *nx = r->next;
-            r->rc = rc;
             __atomic_store_n(&r->done, 1, __ATOMIC_RELEASE);
             r = nx;
         }
@@ -805,6 +847,7 @@ static int pipe_run(const struct hjob *j, size_t n)
 /* verify: two residencies per stage, so that the exact path's chain for off-curve keys stays hidden behind
  * the main kernel as it is in one big pass */
 #define PIPE_CHUNK_VERIFY ((size_t)1 << 19)
+#define PIPE_FIRST_CHUNK_VERIFY ((size_t)1 << 16)   /* the first chunk of a verify call (the other operations: PIPE_FIRST_CHUNK) */
 
 #define RUN_ARGS struct engine *e, const struct hjob *j, uint8_t *d_out, uint8_t *const d_in[PIPE_MAX_IN], \
                  const uint8_t *d_msgs, const uint64_t *d_off, size_t msg_len, size_t m, hipStream_t st, hipEvent_t kdone
@@ -865,26 +908,30 @@ static struct hjob job_verify(uint8_t *ok, const uint8_t *sigs, const uint8_t *p
     /* Measured (tools/pipe_sweep.py, 2^20 items from malloc memory): the three kernels of a verify chunk leave ramps and
      * tails that the neighbouring chunks' kernels fill when the lanes run side by side (95.7 M/s; in chunk order 79-86),
      * and the small first chunk gets the chip working 0.2 ms after the call. */
-    struct hjob j = { 2, { sigs, pubs, NULL }, { 64, 32, 0 }, 1, msgs, msg_off, msg_len, ok, 1, run_verify, 0, 0, 0,
-                      PIPE_CHUNK_VERIFY, WIPE_NONE, NULL, (size_t)1 << 16, 0, 1, 0 };   /* kind 1 */
+    const struct hjob j = { .n_in = 2, .in = { sigs, pubs, NULL }, .in_w = { 64, 32, 0 }, .has_msgs = 1, .msgs = msgs,
+                            .msg_off = msg_off, .msg_len = msg_len, .out = ok, .out_w = 1, .run = run_verify,
+                            .chunk = PIPE_CHUNK_VERIFY, .wipe = WIPE_NONE, .first_chunk = PIPE_FIRST_CHUNK_VERIFY,
+                            .chain = 0, .kind = 1 };
     return j;
 }
 static struct hjob job_sign(uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs, const uint8_t *msgs,
                             const uint64_t *msg_off, size_t msg_len)
 {
-    struct hjob j = { 2, { secs, pubs, NULL }, { 32, 32, 0 }, 1, msgs, msg_off, msg_len, sigs, 64, run_sign, 0, 0, 0, 0,
-                      WIPE_IN0, NULL, 0, 1, 2, 0 };
+    const struct hjob j = { .n_in = 2, .in = { secs, pubs, NULL }, .in_w = { 32, 32, 0 }, .has_msgs = 1, .msgs = msgs,
+                            .msg_off = msg_off, .msg_len = msg_len, .out = sigs, .out_w = 64, .run = run_sign,
+                            .wipe = WIPE_IN0, .chain = 1, .kind = 2 };
     return j;
 }
 static struct hjob job_x25519(uint8_t *out, const uint8_t *scalars, const uint8_t *points)
 {
-    struct hjob j = { 2, { scalars, points, NULL }, { 32, 32, 0 }, 0, NULL, NULL, 0, out, 32, run_x25519, 0, 0, 0, 0,
-                      WIPE_IN0 | WIPE_OUT, NULL, 0, 1, 3, 0 };
+    const struct hjob j = { .n_in = 2, .in = { scalars, points, NULL }, .in_w = { 32, 32, 0 }, .out = out, .out_w = 32,
+                            .run = run_x25519, .wipe = WIPE_IN0 | WIPE_OUT, .chain = 1, .kind = 3 };
     return j;
 }
 static struct hjob job_1in(int (*run)(RUN_ARGS), uint8_t *out, const uint8_t *in, int wipe, int kind)
 {
-    struct hjob j = { 1, { in, NULL, NULL }, { 32, 0, 0 }, 0, NULL, NULL, 0, out, 32, run, 0, 0, 0, 0, wipe, NULL, 0, 1, kind, 0 };
+    const struct hjob j = { .n_in = 1, .in = { in, NULL, NULL }, .in_w = { 32, 0, 0 }, .out = out, .out_w = 32, .run = run,
+                            .wipe = wipe, .chain = 1, .kind = kind };
     return j;
 }
 
@@ -917,8 +964,9 @@ int ed25519_verify_records(uint8_t *ok, const uint8_t *records, size_t stride, s
                            size_t msg_off, size_t msg_len, size_t n)
 {
     if (!records_ok(stride, sig_off, pub_off, msg_off, msg_len)) return -(int)hipErrorInvalidValue;
-    struct hjob j = { 1, { records, NULL, NULL }, { stride, 0, 0 }, 0, NULL, NULL, msg_len, ok, 1, run_verify_records,
-                      sig_off, pub_off, msg_off, PIPE_CHUNK_VERIFY, WIPE_NONE, NULL, (size_t)1 << 16, 0, 0, 0 };
+    const struct hjob j = { .n_in = 1, .in = { records, NULL, NULL }, .in_w = { stride, 0, 0 }, .msg_len = msg_len, .out = ok,
+                            .out_w = 1, .run = run_verify_records, .rec_sig = sig_off, .rec_pub = pub_off, .rec_msg = msg_off,
+                            .chunk = PIPE_CHUNK_VERIFY, .wipe = WIPE_NONE, .first_chunk = PIPE_FIRST_CHUNK_VERIFY };
     return pipe_run(&j, n);
 }
 

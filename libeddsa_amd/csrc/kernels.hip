@@ -15,8 +15,11 @@
 //   k_sk_to_x        ed25519-sha512.c:239-256 sk_ed25519_to_x25519
 //   k_init_tables    generates what the reference ships as lib/ed_lookup64.h
 #include "eddsa_kernels.h"
+#include "edk_checked.h"
 #include "lanes.h"
 #include "quad_lanes.h"
+
+#include <atomic>
 
 namespace ed {
 
@@ -143,15 +146,15 @@ __global__ void __launch_bounds__(64) k_init_comb_image(uint32_t* img, const uin
 //   k_verify_prepare  hash, scalars -> digit words, decompress -A, table of 0..8 * -A
 //   k_verify_main     the 252 doublings + 80 additions            (~85 % of the time)
 //   k_verify_finish   invert Z (shared by 8 items per lane), encode, compare with R
-//   k_verify_exact_quad (side stream, beside main; k_verify_exact for lists beyond 65536 entries) the reference's own
-//                     chain for the items whose key is not a curve point; owns their verdict bytes
+//   k_verify_exact_quad (side stream, beside main) the reference's own chain for the items whose key is not a curve
+//                     point; owns their verdict bytes
 // Workspace (HBM; tile = 256 items):
 //   digits [item][16]                  t + 0x88.., S + 0x80.. as little-endian words
 //   table  [item][entry 9][word 32]    1152 contiguous bytes per item; an entry = ymx | ypx | t2d | z2 packed into 255 bits each
 //                                      (fe_pack), one 128-byte line
 //   acc    [tile][word 30][lane 256]   X, Y, Z of the result
 //   flags  [item]                      bit 0: A decoded to a curve point; bit 1: Z usable (set by finish)
-//   offlist[..], offcount              items whose A is off the curve, for k_verify_exact
+//   offlist[..], offcount              items whose A is off the curve, for k_verify_exact_quad
 // ---------------------------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(BLOCK, 2)
@@ -179,39 +182,11 @@ k_verify_prepare(edk_verify_src src, size_t n, uint32_t* digits,
   if (!windowed && i < n) offlist[atomicAdd(offcount, 1u)] = (uint32_t)i;
 }
 
-// ed25519-sha512.c:148-181 replayed in the reference's own order (lanes.h verify_exact_lane) for
-// the items listed by k_verify_prepare.  Each item is one long serial chain (261 add + double
-// steps), so the work is latency-bound.  This one-lane, one-kernel form (everything per item,
-// spilling, strided over the list) serves work lists beyond the QUAD_MAX_ITEMS entries that the
-// four-lane chain below takes.
-constexpr int EXACT_BLOCK = 64;
-constexpr int EXACT_MAX_BLOCKS = 1024;
-constexpr int EXACT_PAD_WORDS = 160 + 2 * ((REF_JSF_LEN + 3) / 4);   /* per lane: 4 addends + 2 digit strings */
-
-__global__ void __launch_bounds__(EXACT_BLOCK, 4)
-k_verify_exact(uint8_t* ok, edk_verify_src src, const uint32_t* offlist, const uint32_t* offcount,
-               const uint32_t* base16, uint32_t* pad, size_t first) {
-  const size_t count = *offcount;
-  // this wave's scratchpad, lane-interleaved (element k of lane t at [k * 64 + t]: coalesced)
-  uint32_t* base = pad + (size_t)blockIdx.x * (EXACT_PAD_WORDS * EXACT_BLOCK);
-  uint32_t* pts = base + threadIdx.x;
-  int8_t* ux = reinterpret_cast<int8_t*>(base + 160 * EXACT_BLOCK) + threadIdx.x;
-  int8_t* uy = ux + REF_JSF_LEN * EXACT_BLOCK;
-  for (size_t g = first + (size_t)blockIdx.x * EXACT_BLOCK + threadIdx.x; g < count; g += (size_t)gridDim.x * EXACT_BLOCK) {
-    const size_t i = offlist[g];
-    uint32_t rw[8], sw[8], aw[8];
-    const uint8_t* m; size_t mlen;
-    verify_item(rw, sw, aw, m, mlen, src, i);
-    ok[i] = (uint8_t)verify_exact_lane(rw, sw, aw, m, mlen, base16 + TABLE_ENTRY_WORDS, ux, uy, pts, EXACT_BLOCK);
-  }
-}
-
-// The fast route of the exact path, for the first QUAD_MAX_ITEMS entries of the work list (the rest, if any:
-// k_verify_exact above, strided, after the main kernel): four lanes per item (quad_lanes.h), so that a chain
-// step is a squaring and a multiplication deep.  Set-up (joint sparse form of the two scalars and the addends
-// Q, B, Q+B, Q-B, all from what k_verify_prepare left in the workspace) and chain are one kernel,
-// k_verify_exact_quad, on the side stream beside k_verify_main, which is launched with MAIN_LDS_RESERVE and
-// therefore leaves wave slots, registers and a little LDS free on every CU.
+// The exact path: ed25519-sha512.c:148-181 replayed in the reference's own order for the items k_verify_prepare (and, on
+// the half-length route, k_verify_halve) listed, with four lanes per item (quad_lanes.h), so that a chain step is a
+// squaring and a multiplication deep.  Set-up (joint sparse form of the two scalars and the addends Q, B, Q+B, Q-B, all
+// from what k_verify_prepare left in the workspace) and chain are one kernel on the side stream beside k_verify_main,
+// which is launched with MAIN_LDS_RESERVE and therefore leaves wave slots, registers and a little LDS free on every CU.
 // Why this shape (tools/exact_path_time.py, tools/exact_trace.py timelines, profiles/r02_verify_ab.txt):
 // k_verify_main's grid for 2^20 items is an exact number of rounds of resident blocks, so it has no slack:
 // whatever holds up ONE of its blocks -- a displaced tile (round 1: chain blocks of four waves at 149 VGPRs
@@ -219,12 +194,16 @@ k_verify_exact(uint8_t* ok, edk_verify_src src, const uint32_t* offlist, const u
 // costs the latency of one tile at the end (0.7 ms), for 512 off-curve keys as for 65536.  The remedy is to
 // disturb every SIMD a little instead of a few a lot: single-wave chain blocks (16 items) spread over the
 // whole chip, the short four-lane chain, no displacement.  Cost of the exact path on config 2: 0.94 ms in
-// round 1, 0.4 ms now.
-constexpr int QUAD_MAX_ITEMS = 65536;
+// round 1, 0.4 ms in round 2, 0.05 ms now (profiles/r04_small_grid.txt has what it costs passes of one or two rounds).
+// The work list may be as long as the pass (a caller can send nothing but garbage keys: ed_import never fails, ed.c:100-149):
+// at most EDK_EXACT_SLOTS items are in flight - 4096 waves of 16, one scratchpad slot each - and a longer list is walked
+// in strides of the grid.  (Until round 4 the entries beyond 65536 went to a one-lane kernel that spilled 518 registers.)
 constexpr int QUAD_BLOCK = 256;                  // k_verify_main_quad
 constexpr int QUAD_CHAIN_BLOCK = 64;             // k_verify_exact_quad: one wave, up to 16 items
+constexpr int QUAD_CHAIN_ITEMS = QUAD_CHAIN_BLOCK / 4;
 constexpr int QUAD_SPREAD_WAVES = 256;           // a short work list is spread over this many waves, a long one packed 16 items to the wave
-static_assert((size_t)QUAD_MAX_ITEMS * QUAD_ITEM_WORDS * 4 <= EDK_EXACT_PAD_BYTES, "scratchpad too small");
+static_assert((size_t)EDK_EXACT_SLOTS * QUAD_ITEM_WORDS * 4 <= EDK_EXACT_PAD_BYTES, "scratchpad too small");
+static_assert(EDK_EXACT_SLOTS % QUAD_CHAIN_ITEMS == 0, "whole waves");
 
 // Set-up and chain in ONE kernel (round 2 had two, 0.37-0.75 + 0.75 ms however few the items: a pass of 2^14 items
 // with a handful of off-curve keys took 1.02 ms instead of 0.39; now 0.79).  A wave carries 16 items when the list is
@@ -232,29 +211,34 @@ static_assert((size_t)QUAD_MAX_ITEMS * QUAD_ITEM_WORDS * 4 <= EDK_EXACT_PAD_BYTE
 // QUAD_SPREAD_WAVES waves: a small pass waits for this kernel, and a wave with one item skips the addition of every step
 // without digits, quad_lanes.h; spreading 540 items of a 2^16-item pass one to the wave was measured slower than 34
 // full waves - 1.28 against 1.18 ms - their instructions are taken from the main kernel's waves).  The digit pairs
-// live in LDS (33 words per item), the addends in the HBM scratchpad.
+// live in LDS (33 words per item), the addends in the HBM scratchpad, one slot per quad of the grid.
 __global__ void __launch_bounds__(QUAD_CHAIN_BLOCK, 2)
 k_verify_exact_quad(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const uint32_t* digits, const uint32_t* table,
                     const uint32_t* offlist, const uint32_t* offcount, const uint32_t* base16, uint32_t* pad) {
-  __shared__ uint32_t lds_dig[(QUAD_CHAIN_BLOCK / 4) * QUAD_DIGIT_WORDS];
+  __shared__ uint32_t lds_dig[QUAD_CHAIN_ITEMS * QUAD_DIGIT_WORDS];
   __builtin_amdgcn_s_setprio(3);                 // small passes wait for the chain: 1-3 % there; no difference beside a full k_verify_main
-  const size_t listed = *offcount;
-  const size_t count = listed < (size_t)QUAD_MAX_ITEMS ? listed : (size_t)QUAD_MAX_ITEMS;
+  const size_t count = *offcount;
   size_t per = (count + QUAD_SPREAD_WAVES - 1) / QUAD_SPREAD_WAVES;               // items per wave: 1 .. 16
-  per = per > (size_t)(QUAD_CHAIN_BLOCK / 4) ? (size_t)(QUAD_CHAIN_BLOCK / 4) : per;
+  per = per > (size_t)QUAD_CHAIN_ITEMS ? (size_t)QUAD_CHAIN_ITEMS : per;
   const size_t quad = threadIdx.x >> 2;          // quads are all-or-nothing
-  const size_t g = (size_t)blockIdx.x * per + quad;
-  if (quad >= per || g >= count) return;
+  if (quad >= per) return;
   const int q = (int)(threadIdx.x & 3u);
-  const size_t i = offlist[g];
-  uint32_t* item = pad + g * QUAD_ITEM_WORDS;
+  uint32_t* item = pad + ((size_t)blockIdx.x * QUAD_CHAIN_ITEMS + quad) * QUAD_ITEM_WORDS;   // this quad's slot
   uint32_t* dig = lds_dig + quad * QUAD_DIGIT_WORDS;
-  verify_exact_setup_quad(digits + 16 * i, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16 + TABLE_ENTRY_WORDS, item, dig, q);
-  __syncthreads();                               // one wave: orders the quad's stores (LDS digits, HBM addends) before the other lanes' loads
-  uint32_t rw[8];
-  load32(rw, sigs, i, sig_stride);
-  const bool same = verify_exact_chain_quad(rw, item, dig, q);
-  if (q == 1) ok[i] = (uint8_t)same;
+  // rounds are uniform over the wave (its quads meet at the barriers): a quad whose entry lies beyond the end of the list
+  // redoes the last entry into its own slot and keeps the verdict to itself
+  for (size_t base = (size_t)blockIdx.x * per; base < count; base += (size_t)gridDim.x * per) {
+    const size_t g = base + quad;
+    const bool live = g < count;
+    const size_t i = offlist[live ? g : count - 1];
+    verify_exact_setup_quad(digits + 16 * i, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16 + TABLE_ENTRY_WORDS, item, dig, q);
+    __syncthreads();                             // one wave: orders the quad's stores (LDS digits, HBM addends) before the other lanes' loads
+    uint32_t rw[8];
+    load32(rw, sigs, i, sig_stride);
+    const bool same = verify_exact_chain_quad(rw, item, dig, q);
+    if (live && q == 1) ok[i] = (uint8_t)same;
+    __syncthreads();                             // ... and this round's loads before the next round's stores
+  }
 }
 
 __global__ void __launch_bounds__(BLOCK, 4)
@@ -481,7 +465,8 @@ constexpr size_t HALF_QUAD_MAX_N = (size_t)1 << HALF_QUAD_LOG2;
 // 2^16 0.71-0.76 -> 0.66, 2^17 1.30 -> 1.28; the config-2 mix, whose floor is the exact path: 2^16 1.16 -> 1.11, else equal.
 constexpr size_t PAIR_ONE_MIN_N = (size_t)3 << 13;   // the four-lane evaluation steps up with every 8192 items (0.35 / 0.51 / 0.69 ms: tools/verify_cross.py), this one stays at 0.58
 constexpr size_t QUAD_WIDE_MIN_N = 256;               // four-lane passes above this search pairs up to 2^138 as well (see edk_verify)
-constexpr size_t HALF_WIDE_MIN_N = (size_t)1 << 18;   // one-lane passes below this search pairs up to 2^138 (see edk_verify)
+constexpr size_t PAIR_ONE_MAX_N = (size_t)1 << 18;    // the mid-size arrangement (three-lane preparation, one-lane evaluation with the long loop in place) ends here
+constexpr size_t HALF_WIDE_MIN_N = (size_t)1 << 19;   // one-lane passes below this search pairs up to 2^138 (see edk_verify)
 __global__ void __launch_bounds__(QUAD_BLOCK, 2)
 k_verify_main_quad(const uint32_t* digits, const uint32_t* table, const uint32_t* base16, uint32_t* accout, size_t n) {
   const size_t i = ((size_t)blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;       // quads are all-or-nothing
@@ -889,6 +874,183 @@ __global__ void __launch_bounds__(BLOCK) k_debug_halve(uint8_t* out, const uint8
   o[11] = 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Layer probes (include/eddsa_amd_debug.h: eddsa_amd_debug_layer): ONE layer of the device code on caller-given inputs,
+// so that the golden layer vectors (tests/golden/layer_kats.json, pinned to the reference's static library) reach the
+// GPU as such and not only as parts of whole operations - what the device toolchain makes of the limb arithmetic and of
+// the DPP exchanges is the one thing the host build of this source (tests/host_check/) cannot vouch for.
+// One lane per item; the four-lane forms below.  The op codes are those of the header.
+// ---------------------------------------------------------------------------------------------
+enum { L_FE_MUL = 1, L_FE_SQ, L_FE_INV, L_FE_POW2523, L_FE_MUL_LOOSE, L_SC_REDUCE32, L_SC_REDUCE64, L_SC_MULADD, L_SHA512,
+       L_ED_IMPORT_EXPORT, L_ED_SCALE_BASE, L_ED_DUAL_SCALE, L_GE_DBL_ADD };
+
+ED_DEV void ldw(uint32_t w[8], const uint8_t* p) { load32(w, p, 0, 0); }
+ED_DEV void stw(uint8_t* p, const uint32_t w[8]) { store32(p, 0, 0, w); }
+
+// scratch (EDL_ED_DUAL_SCALE only): per item 2 x REF_JSF_LEN digit bytes + 160 words (form 2: the uniform chain's storage)
+constexpr size_t LAYER_SCRATCH_BYTES = 2 * ((REF_JSF_LEN + 3) / 4 * 4) + 160 * 4;
+
+__global__ void __launch_bounds__(64)
+k_debug_layer(int op, int form, uint8_t* out, size_t out_w, const uint8_t* in, size_t in_w, size_t n, const uint32_t* base16,
+              uint8_t* scratch) {
+  const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* a = in + i * in_w;
+  uint8_t* o = out + i * out_w;
+  uint32_t w[8], r[8];
+  fe x, y;
+  if (op == L_FE_MUL || op == L_FE_MUL_LOOSE) {
+    ldw(w, a); fe_frombytes(x, w); ldw(w, a + 32); fe_frombytes(y, w);
+    if (op == L_FE_MUL_LOOSE) {                  // f = ka a (ka <= 7), g = kb b (kb <= 3): the documented operand limits
+      const int ka = a[64], kb = a[65];
+      fe fx, gy;
+      fe_set(fx, 0); fe_set(gy, 0);
+      for (int k = 0; k < ka; k++) fe_add(fx, fx, x);
+      for (int k = 0; k < kb; k++) fe_add(gy, gy, y);
+      x = fx; y = gy;
+    }
+    fe_mul(x, x, y);
+    fe_tobytes(r, x); stw(o, r);
+  } else if (op == L_FE_SQ || op == L_FE_INV || op == L_FE_POW2523) {
+    ldw(w, a); fe_frombytes(x, w);
+    if (op == L_FE_SQ) fe_sq(x, x); else if (op == L_FE_INV) fe_inv(x, x); else fe_pow2523(x, x);
+    fe_tobytes(r, x); stw(o, r);
+  } else if (op == L_SC_REDUCE32 || op == L_SC_REDUCE64) {
+    uint32_t w16[16];
+    sc t;
+    ldw(w16, a);
+    if (op == L_SC_REDUCE64) { ldw(w16 + 8, a + 32); sc_from_words<16>(t, w16); } else sc_from_words<8>(t, w16);
+    sc_to_words(r, t); stw(o, r);
+  } else if (op == L_SC_MULADD) {
+    sc p, q, c;
+    ldw(w, a); sc_from_words<8>(p, w); ldw(w, a + 32); sc_from_words<8>(q, w); ldw(w, a + 64); sc_from_words<8>(c, w);
+    sc_mul(p, p, q); sc_add(p, c, p);
+    sc_to_words(r, p); stw(o, r);
+  } else if (op == L_SHA512) {
+    uint32_t d[16];
+    size_t len = 0;
+    for (int k = 7; k >= 0; k--) len = (len << 8) | a[k];
+    sha512_prefix_msg<0>(d, nullptr, a + 8, len);
+    stw(o, d); stw(o + 32, d + 8);
+  } else if (op == L_ED_IMPORT_EXPORT) {
+    ge p; bool oc;
+    ldw(w, a);
+    ge_frombytes(p, oc, w, false);
+    ge_tobytes(r, p); stw(o, r);
+    o[32] = oc ? 1 : 0;
+  } else if (op == L_ED_DUAL_SCALE) {            // forms 0 (the literal chain) and 2 (uniform control flow); form 1 is k_debug_dual_scale_quad
+    uint32_t sw[8], tw[8];
+    sc s, t;
+    ldw(w, a); sc_from_words<8>(s, w); sc_to_words(sw, s);
+    ldw(w, a + 32); sc_from_words<8>(t, w); sc_to_words(tw, t);
+    ldw(w, a + 64);
+    ge Q, R; bool oc;
+    ge_frombytes(Q, oc, w, false);
+    ge_niels pcB;
+    niels_load(pcB, base16 + TABLE_ENTRY_WORDS);
+    if (form == 2) {
+      uint8_t* sp = scratch + i * LAYER_SCRATCH_BYTES;
+      int8_t* ux = reinterpret_cast<int8_t*>(sp);
+      int8_t* uy = ux + (REF_JSF_LEN + 3) / 4 * 4;
+      uint32_t* pts = reinterpret_cast<uint32_t*>(sp + 2 * ((REF_JSF_LEN + 3) / 4 * 4));
+      ref_dual_scale_uniform(R, sw, tw, Q, pcB, ux, uy, pts, 1);
+    } else {
+      ref_dual_scale(R, sw, tw, Q, pcB);
+    }
+    ge_tobytes(r, R); stw(o, r);
+  } else if (op == L_GE_DBL_ADD) {               // enc(2 P + k B), k < 65536 from the k B table: the windowed evaluation's two steps
+    ge P; bool oc;
+    ldw(w, a);
+    ge_frombytes(P, oc, w, false);
+    const uint32_t k = (uint32_t)a[32] | ((uint32_t)a[33] << 8);
+    ge_dbl(P, P, true);
+    ge_niels nb;
+    niels_load(nb, base16 + TABLE_ENTRY_WORDS * (k > 32768u ? 32768u : k));
+    ge_add_niels(P, P, nb, false);
+    ge_tobytes(r, P); stw(o, r);
+  }
+}
+
+// ed_scale_base with the comb staged in LDS and the shuffle lookup, as the point kernels run it (every lane of a wave
+// active: idle lanes redo the last item)
+__global__ void __launch_bounds__(POINT_BLOCK, 512 / POINT_BLOCK)
+k_debug_scale_base(uint8_t* out, const uint8_t* in, size_t n, const uint32_t* comb) {
+  __shared__ alignas(16) uint32_t lds_comb[COMB_IMG_WORDS];
+  stage_table(lds_comb, comb, COMB_IMG_WORDS);
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t w[8], xw[8], r[8];
+  load32(w, in, i < n ? i : n - 1, 32);
+  sc x;
+  sc_from_words<8>(x, w); sc_to_words(xw, x);
+  ge p;
+  scale_base_lane<1>(p, xw, lds_comb, 0);
+  if (i >= n) return;
+  ge_tobytes(r, p);
+  store32(out, i, 32, r);
+}
+
+// The four-lane forms (quad_lanes.h), one wave per block, 16 items per wave.
+// EDL_ED_DUAL_SCALE: set-up and chain of the exact path on a given (s, t, q): the lanes first build what k_verify_prepare
+// would have left - the digit words and entry 1 of the item's table, here the cached form of Q itself - in scratch.
+// scratch per item: 16 digit words | 2 table entries (64 words) | the chain's slot (QUAD_ITEM_WORDS)
+constexpr size_t LAYER_QUAD_SCRATCH_WORDS = 16 + 2 * VERIFY_ENTRY_WORDS + QUAD_ITEM_WORDS;
+__global__ void __launch_bounds__(QUAD_CHAIN_BLOCK, 2)
+k_debug_dual_scale_quad(uint8_t* out, const uint8_t* in, size_t n, const uint32_t* base16, uint32_t* scratch) {
+  __shared__ uint32_t lds_dig[QUAD_CHAIN_ITEMS * QUAD_DIGIT_WORDS];
+  const size_t quad = threadIdx.x >> 2;
+  const size_t g = (size_t)blockIdx.x * QUAD_CHAIN_ITEMS + quad;
+  const bool live = g < n;
+  const size_t i = live ? g : n - 1;             // (whole waves run: a quad past the end redoes the last item into its own slot)
+  const int q = (int)(threadIdx.x & 3u);
+  uint32_t* sp = scratch + g * LAYER_QUAD_SCRATCH_WORDS;
+  uint32_t* digits = sp; uint32_t* tab = sp + 16; uint32_t* item = sp + 16 + 2 * VERIFY_ENTRY_WORDS;
+  const uint8_t* a = in + i * 96;
+  if (q == 0) {
+    uint32_t w[8], sw[8], tw[8];
+    sc s, t;
+    ldw(w, a); sc_from_words<8>(s, w); sc_to_words(sw, s);
+    ldw(w, a + 32); sc_from_words<8>(t, w); sc_to_words(tw, t);
+    words_add_pattern(tw, 0x88888888u);
+    words_add_pattern(sw, 0x80008000u);
+    for (int k = 0; k < 8; k++) { digits[k] = tw[k]; digits[8 + k] = sw[k]; }
+  } else if (q == 1) {
+    uint32_t w[8];
+    ge Q; bool oc;
+    ldw(w, a + 64);
+    ge_frombytes(Q, oc, w, false);
+    ge_cached c;
+    ge_to_cached(c, Q);
+    cached_store(tab, 1, c);
+  }
+  __syncthreads();
+  uint32_t* dig = lds_dig + quad * QUAD_DIGIT_WORDS;
+  verify_exact_setup_quad(digits, tab, base16 + TABLE_ENTRY_WORDS, item, dig, q);
+  __syncthreads();
+  uint32_t wd[8];
+  exact_chain_encode_quad(wd, item, dig, q);
+  if (live && q == 1) store32(out, g, 32, wd);
+}
+
+// EDL_GE_DBL_ADD with a coordinate per lane: quad_dbl, then quad_add_entry from the k B table
+__global__ void __launch_bounds__(QUAD_CHAIN_BLOCK, 2)
+k_debug_dbl_add_quad(uint8_t* out, const uint8_t* in, size_t n, const uint32_t* base16) {
+  const size_t g = ((size_t)blockIdx.x * QUAD_CHAIN_BLOCK + threadIdx.x) >> 2;
+  const bool live = g < n;
+  const uint8_t* a = in + (live ? g : n - 1) * 40;
+  const int q = (int)(threadIdx.x & 3u);
+  uint32_t w[8];
+  ge P; bool oc;
+  ldw(w, a);
+  ge_frombytes(P, oc, w, false);
+  const uint32_t k = (uint32_t)a[32] | ((uint32_t)a[33] << 8);
+  fe r = q == 0 ? P.X : q == 1 ? P.Y : q == 2 ? P.T : P.Z;
+  quad_dbl(r, q);
+  quad_add_entry(r, base16 + TABLE_ENTRY_WORDS * (k > 32768u ? 32768u : k), false, false, q);
+  uint32_t wd[8];
+  quad_encode(wd, r);
+  if (live && q == 1) store32(out, g, 32, wd);
+}
+
 }  // namespace ed
 
 // =============================================================================================
@@ -936,13 +1098,31 @@ hipError_t edk_debug_halve(uint8_t* out, const uint8_t* t, size_t n, int wide, h
   return hipGetLastError();
 }
 
+// the test hook of edk_checked.h: checked calls made since the count was restarted, and the call that is to fail
+static std::atomic<int> g_checked{0}, g_fail_at{0};
+int edk_fault_tick(void) {
+  const int k = g_checked.fetch_add(1, std::memory_order_relaxed) + 1;
+  int at = g_fail_at.load(std::memory_order_relaxed);
+  return at != 0 && k == at && g_fail_at.compare_exchange_strong(at, 0);
+}
+int edk_debug_fail_in(int nth) {
+  if (nth < 0) return g_checked.load();
+  g_fail_at.store(0);
+  g_checked.store(0);
+  g_fail_at.store(nth);
+  return 0;
+}
+
+// Every HIP call below that orders work or moves data is checked (edk_checked.h): the first failure ends the pass with
+// that error.  What has been queued by then still runs; eddsa_amd.c: verify_on waits for it (both streams) before the
+// workspace can be handed out again, and the caller learns that the outputs are unspecified.
 hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const uint32_t* base16,
                       const edk_verify_ws* ws, hipEvent_t* marks, hipEvent_t bulk_done, int bulk_early, hipStream_t stream) {
   const edk_verify_src src = *srcp;
   if (n == 0) return hipSuccess;
   const unsigned blocks = (unsigned)((n + BLOCK - 1) / BLOCK);
-  (void)hipMemsetAsync(ws->offcount, 0, sizeof(uint32_t), stream);
-  if (marks) (void)hipEventRecord(marks[0], stream);
+  EDK_DO(hipMemsetAsync(ws->offcount, 0, sizeof(uint32_t), stream));
+  if (marks) EDK_DO(hipEventRecord(marks[0], stream));
   // algo 0: half-length scalars - the three-lane preparation and four lanes per item up to 24 576 items, the same preparation and one lane per item up to 2^18, one lane per item above;
   // 3: the mid-size arrangement at any size below 2^18;
   // 1: full-length windows (one lane per item above QUAD_MAIN_MAX_N items, quads below); 2: half-length, one lane per item
@@ -952,7 +1132,7 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   const bool wide = n < HALF_WIDE_MIN_N;
   // mid-size passes: the three-lane preparation of the small route (its blocks fill the SIMDs that one lane per item leaves
   // with a single wave) and the one-lane evaluation; algo 3 forces it for measurements
-  const bool pair_one = wide && (algo == 3 || (algo == 0 && n > PAIR_ONE_MIN_N));
+  const bool pair_one = n < PAIR_ONE_MAX_N && (algo == 3 || (algo == 0 && n > PAIR_ONE_MIN_N));
   const bool half = !pair_one && (algo == 2 || (algo == 0 && !small_half));
   const bool half_quad = !pair_one && algo == 0 && small_half;
   const unsigned pair_point_blocks = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
@@ -960,63 +1140,59 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   // with pairs up to 2^134 (8.5 items in 10^5) a pass of 2048 items has such an item one time in six, one of 2^14 three
   // times in four.  Above QUAD_WIDE_MIN_N items the search goes up to 2^138 (2 in 10^7) for a 35th window in every item.
   const bool quad_wide = half_quad && n > QUAD_WIDE_MIN_N;
-  if (pair_one)
-    hipLaunchKernelGGL(k_verify_prepare_pair<HALF_BITS_SMALL>, dim3(pair_point_blocks + blocks), dim3(BLOCK), 0, stream, src, n,
-                       ws->digits, ws->hdigits, ws->table, ws->rtable, ws->flags, ws->offlist, ws->offcount, ws->exact_offcurve == 2,
-                       pair_point_blocks);
-  else if (quad_wide)
-    hipLaunchKernelGGL(k_verify_prepare_pair<HALF_BITS_SMALL>, dim3(pair_point_blocks + blocks), dim3(BLOCK), 0, stream, src, n,
-                       ws->digits, ws->hdigits, ws->table, ws->rtable, ws->flags, ws->offlist, ws->offcount, ws->exact_offcurve == 2,
-                       pair_point_blocks);
+  if (pair_one || quad_wide)
+    EDK_LAUNCH(k_verify_prepare_pair<HALF_BITS_SMALL>, dim3(pair_point_blocks + blocks), dim3(BLOCK), 0, stream, src, n,
+               ws->digits, ws->hdigits, ws->table, ws->rtable, ws->flags, ws->offlist, ws->offcount, ws->exact_offcurve == 2,
+               pair_point_blocks);
   else if (half_quad)
-    hipLaunchKernelGGL(k_verify_prepare_pair<HALF_BITS>, dim3(pair_point_blocks + blocks), dim3(BLOCK), 0, stream, src, n,
-                       ws->digits, ws->hdigits, ws->table, ws->rtable, ws->flags, ws->offlist, ws->offcount, ws->exact_offcurve == 2,
-                       pair_point_blocks);
+    EDK_LAUNCH(k_verify_prepare_pair<HALF_BITS>, dim3(pair_point_blocks + blocks), dim3(BLOCK), 0, stream, src, n,
+               ws->digits, ws->hdigits, ws->table, ws->rtable, ws->flags, ws->offlist, ws->offcount, ws->exact_offcurve == 2,
+               pair_point_blocks);
   else
-    hipLaunchKernelGGL(k_verify_prepare, dim3(blocks), dim3(BLOCK), 0, stream, src, n, ws->digits, ws->table, ws->flags, ws->offlist, ws->offcount,
-                       ws->exact_offcurve == 2);
-  // Below HALF_WIDE_MIN_N items the main kernel is shorter than the exact path's two (about 1 ms for however few items), so an
-  // item without a short pair would set the time of the pass: such passes search up to 2^138 and run 35 windows (2 t in
-  // 10^7 without a pair instead of 8.5 in 10^5; 3 % more instructions in the main kernel)
+    EDK_LAUNCH(k_verify_prepare, dim3(blocks), dim3(BLOCK), 0, stream, src, n, ws->digits, ws->table, ws->flags, ws->offlist, ws->offcount,
+               ws->exact_offcurve == 2);
+  // Below HALF_WIDE_MIN_N items the pass searches pairs up to 2^138 and runs 35 windows (2 t in 10^7 without a pair instead
+  // of 8.5 in 10^5; 3 % more instructions in the main kernel): an item without a short pair goes through the exact path's
+  // chain, and beside a main kernel of one or two rounds of resident blocks that chain costs the pass 0.3-0.4 ms (the
+  // SIMDs its waves sit on finish their tiles that much later and the grid has no slack: profiles/r04_small_grid.txt)
   if (half && wide)
-    hipLaunchKernelGGL(k_verify_halve<HALF_BITS_SMALL>, dim3(blocks), dim3(BLOCK), 0, stream, src.sigs, src.sig_stride, n, ws->digits,
-                       ws->hdigits, ws->rtable, ws->flags, ws->offlist, ws->offcount);
+    EDK_LAUNCH(k_verify_halve<HALF_BITS_SMALL>, dim3(blocks), dim3(BLOCK), 0, stream, src.sigs, src.sig_stride, n, ws->digits,
+               ws->hdigits, ws->rtable, ws->flags, ws->offlist, ws->offcount);
   else if (half)
-    hipLaunchKernelGGL(k_verify_halve<HALF_BITS>, dim3(blocks), dim3(BLOCK), 0, stream, src.sigs, src.sig_stride, n, ws->digits,
-                       ws->hdigits, ws->rtable, ws->flags, ws->offlist, ws->offcount);
-  if (marks) (void)hipEventRecord(marks[1], stream);
-  if (bulk_done && bulk_early) (void)hipEventRecord(bulk_done, stream);   // the next pass may start beside this one's main kernel
-  // the exact path depends only on what came before: both of its kernels run beside the main kernel on the side stream
-  const size_t fast_items = (size_t)QUAD_MAX_ITEMS;
+    EDK_LAUNCH(k_verify_halve<HALF_BITS>, dim3(blocks), dim3(BLOCK), 0, stream, src.sigs, src.sig_stride, n, ws->digits,
+               ws->hdigits, ws->rtable, ws->flags, ws->offlist, ws->offcount);
+  if (marks) EDK_DO(hipEventRecord(marks[1], stream));
+  if (bulk_done && bulk_early) EDK_DO(hipEventRecord(bulk_done, stream));   // the next pass may start beside this one's main kernel
+  // the exact path depends only on what came before: it runs beside the main kernel on the side stream
   if (ws->exact_offcurve) {
-    const size_t qi = n < fast_items ? n : fast_items;
-    (void)hipEventRecord(ws->ev_prepared, stream);
-    (void)hipStreamWaitEvent(ws->side, ws->ev_prepared, 0);
-    const size_t dense = (qi + QUAD_CHAIN_BLOCK / 4 - 1) / (QUAD_CHAIN_BLOCK / 4), spread = qi < (size_t)QUAD_SPREAD_WAVES ? qi : (size_t)QUAD_SPREAD_WAVES;
-    hipLaunchKernelGGL(k_verify_exact_quad, dim3((unsigned)(dense > spread ? dense : spread)), dim3(QUAD_CHAIN_BLOCK), 0, ws->side, ok,
-                       src.sigs, src.sig_stride, ws->digits, ws->table, ws->offlist, ws->offcount, base16, ws->exact_pad);
-    (void)hipEventRecord(ws->ev_exact, ws->side);
+    const size_t qi = n < (size_t)EDK_EXACT_SLOTS ? n : (size_t)EDK_EXACT_SLOTS;
+    EDK_DO(hipEventRecord(ws->ev_prepared, stream));
+    EDK_DO(hipStreamWaitEvent(ws->side, ws->ev_prepared, 0));
+    const size_t dense = (qi + QUAD_CHAIN_ITEMS - 1) / QUAD_CHAIN_ITEMS, spread = qi < (size_t)QUAD_SPREAD_WAVES ? qi : (size_t)QUAD_SPREAD_WAVES;
+    EDK_LAUNCH(k_verify_exact_quad, dim3((unsigned)(dense > spread ? dense : spread)), dim3(QUAD_CHAIN_BLOCK), 0, ws->side, ok,
+               src.sigs, src.sig_stride, ws->digits, ws->table, ws->offlist, ws->offcount, base16, ws->exact_pad);
+    EDK_DO(hipEventRecord(ws->ev_exact, ws->side));
   }
   if (half_quad && n <= EDK_SUMS_MAX_ITEMS) {
     static_assert(QUAD_BLOCK == 4 * HALF_LONG_WINDOWS, "a block of k_verify_window_sums is the windows of one item");
     if (quad_wide) {
-      hipLaunchKernelGGL(k_verify_window_sums<HALF_WINDOWS_SMALL>, dim3((unsigned)n), dim3(QUAD_BLOCK), 0, stream, ws->sums, ws->hdigits, ws->table, ws->rtable, base16);
-      hipLaunchKernelGGL(k_verify_main_sums_quad<HALF_WINDOWS_SMALL>, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, stream,
-                         ok, ws->hdigits, ws->sums, ws->flags, n, ws->exact_offcurve);
+      EDK_LAUNCH(k_verify_window_sums<HALF_WINDOWS_SMALL>, dim3((unsigned)n), dim3(QUAD_BLOCK), 0, stream, ws->sums, ws->hdigits, ws->table, ws->rtable, base16);
+      EDK_LAUNCH(k_verify_main_sums_quad<HALF_WINDOWS_SMALL>, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, stream,
+                 ok, ws->hdigits, ws->sums, ws->flags, n, ws->exact_offcurve);
     } else {
-      hipLaunchKernelGGL(k_verify_window_sums<HALF_WINDOWS>, dim3((unsigned)n), dim3(QUAD_BLOCK), 0, stream, ws->sums, ws->hdigits, ws->table, ws->rtable, base16);
-      hipLaunchKernelGGL(k_verify_main_sums_quad<HALF_WINDOWS>, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, stream,
-                         ok, ws->hdigits, ws->sums, ws->flags, n, ws->exact_offcurve);
+      EDK_LAUNCH(k_verify_window_sums<HALF_WINDOWS>, dim3((unsigned)n), dim3(QUAD_BLOCK), 0, stream, ws->sums, ws->hdigits, ws->table, ws->rtable, base16);
+      EDK_LAUNCH(k_verify_main_sums_quad<HALF_WINDOWS>, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, stream,
+                 ok, ws->hdigits, ws->sums, ws->flags, n, ws->exact_offcurve);
     }
-    if (marks) { (void)hipEventRecord(marks[2], stream); (void)hipEventRecord(marks[3], stream); }
+    if (marks) { EDK_DO(hipEventRecord(marks[2], stream)); EDK_DO(hipEventRecord(marks[3], stream)); }
   } else if (half_quad) {
     if (quad_wide)
-      hipLaunchKernelGGL(k_verify_main_half_quad<HALF_WINDOWS_SMALL>, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, stream,
-                         ok, ws->hdigits, ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
+      EDK_LAUNCH(k_verify_main_half_quad<HALF_WINDOWS_SMALL>, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, stream,
+                 ok, ws->hdigits, ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
     else
-      hipLaunchKernelGGL(k_verify_main_half_quad<HALF_WINDOWS>, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, stream,
-                         ok, ws->hdigits, ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
-    if (marks) { (void)hipEventRecord(marks[2], stream); (void)hipEventRecord(marks[3], stream); }
+      EDK_LAUNCH(k_verify_main_half_quad<HALF_WINDOWS>, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0, stream,
+                 ok, ws->hdigits, ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
+    if (marks) { EDK_DO(hipEventRecord(marks[2], stream)); EDK_DO(hipEventRecord(marks[3], stream)); }
   } else if (half || pair_one) {
 #ifdef MAIN_HALF_LDS_KB
     constexpr unsigned half_lds = MAIN_HALF_LDS_KB * 1024;
@@ -1025,36 +1201,74 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
 #endif
     const unsigned hblocks = (blocks * BLOCK + MAIN_HALF_BLOCK - 1) / MAIN_HALF_BLOCK;
     if (pair_one)
-      hipLaunchKernelGGL((k_verify_main_half<HALF_WINDOWS_SMALL, true>), dim3(hblocks), dim3(MAIN_HALF_BLOCK), half_lds, stream, ok, ws->hdigits,
-                         ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
+      EDK_LAUNCH((k_verify_main_half<HALF_WINDOWS_SMALL, true>), dim3(hblocks), dim3(MAIN_HALF_BLOCK), half_lds, stream, ok, ws->hdigits,
+                 ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
     else if (wide)
-      hipLaunchKernelGGL(k_verify_main_half<HALF_WINDOWS_SMALL>, dim3(hblocks), dim3(MAIN_HALF_BLOCK), half_lds, stream, ok, ws->hdigits,
-                         ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
+      EDK_LAUNCH(k_verify_main_half<HALF_WINDOWS_SMALL>, dim3(hblocks), dim3(MAIN_HALF_BLOCK), half_lds, stream, ok, ws->hdigits,
+                 ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
     else
-      hipLaunchKernelGGL(k_verify_main_half<HALF_WINDOWS>, dim3(hblocks), dim3(MAIN_HALF_BLOCK), half_lds, stream, ok, ws->hdigits,
-                         ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
-    if (marks) { (void)hipEventRecord(marks[2], stream); (void)hipEventRecord(marks[3], stream); }
+      EDK_LAUNCH(k_verify_main_half<HALF_WINDOWS>, dim3(hblocks), dim3(MAIN_HALF_BLOCK), half_lds, stream, ok, ws->hdigits,
+                 ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
+    if (marks) { EDK_DO(hipEventRecord(marks[2], stream)); EDK_DO(hipEventRecord(marks[3], stream)); }
   } else {
     if (small)
-      hipLaunchKernelGGL(k_verify_main_quad, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0,
-                         stream, ws->digits, ws->table, base16, ws->acc, n);
+      EDK_LAUNCH(k_verify_main_quad, dim3((unsigned)((4 * n + QUAD_BLOCK - 1) / QUAD_BLOCK)), dim3(QUAD_BLOCK), 0,
+                 stream, ws->digits, ws->table, base16, ws->acc, n);
     else
-      hipLaunchKernelGGL(k_verify_main, dim3(blocks), dim3(BLOCK), MAIN_LDS_RESERVE, stream, ws->digits, ws->table, base16, ws->acc);
-    if (marks) (void)hipEventRecord(marks[2], stream);
-    hipLaunchKernelGGL(k_verify_finish, dim3((blocks + finish_k(n) - 1) / finish_k(n)), dim3(BLOCK), 0, stream, ok, src.sigs,
-                       src.sig_stride, ws->acc, ws->flags, n, ws->exact_offcurve, (int)finish_k(n));
-    if (marks) (void)hipEventRecord(marks[3], stream);
+      EDK_LAUNCH(k_verify_main, dim3(blocks), dim3(BLOCK), MAIN_LDS_RESERVE, stream, ws->digits, ws->table, base16, ws->acc);
+    if (marks) EDK_DO(hipEventRecord(marks[2], stream));
+    EDK_LAUNCH(k_verify_finish, dim3((blocks + finish_k(n) - 1) / finish_k(n)), dim3(BLOCK), 0, stream, ok, src.sigs,
+               src.sig_stride, ws->acc, ws->flags, n, ws->exact_offcurve, (int)finish_k(n));
+    if (marks) EDK_DO(hipEventRecord(marks[3], stream));
   }
   // everything that fills the chip has been queued; what follows on this stream only waits for the exact path's few
   // latency-bound waves: a caller that pipelines passes over several workspaces starts the next pass from here
-  if (bulk_done && !bulk_early) (void)hipEventRecord(bulk_done, stream);
-  if (ws->exact_offcurve) {
-    (void)hipStreamWaitEvent(stream, ws->ev_exact, 0);   // complete when both paths are
-    if (n > fast_items)   // possibly more listed keys than the fast route takes: the rest, strided, one kernel
-      hipLaunchKernelGGL(k_verify_exact, dim3(EXACT_MAX_BLOCKS), dim3(EXACT_BLOCK), 0, stream, ok, src, ws->offlist,
-                         ws->offcount, base16, ws->exact_pad, fast_items);
+  if (bulk_done && !bulk_early) EDK_DO(hipEventRecord(bulk_done, stream));
+  if (ws->exact_offcurve) EDK_DO(hipStreamWaitEvent(stream, ws->ev_exact, 0));   // complete when both paths are
+  return hipSuccess;
+}
+
+int edk_debug_layer_widths_ok(int op, int form, size_t in_w, size_t out_w) {
+  if (form < 0 || form > 2) return 0;
+  switch (op) {
+    case L_FE_MUL: return form == 0 && in_w == 64 && out_w == 32;
+    case L_FE_SQ: case L_FE_INV: case L_FE_POW2523: case L_SC_REDUCE32: case L_ED_SCALE_BASE: return form == 0 && in_w == 32 && out_w == 32;
+    case L_FE_MUL_LOOSE: return form == 0 && in_w == 72 && out_w == 32;
+    case L_SC_REDUCE64: return form == 0 && in_w == 64 && out_w == 32;
+    case L_SC_MULADD: return form == 0 && in_w == 96 && out_w == 32;
+    case L_SHA512: return form == 0 && in_w >= 8 && out_w == 64;
+    case L_ED_IMPORT_EXPORT: return form == 0 && in_w == 32 && out_w == 33;
+    case L_ED_DUAL_SCALE: return in_w == 96 && out_w == 32;
+    case L_GE_DBL_ADD: return form <= 1 && in_w == 40 && out_w == 32;
   }
-  return hipGetLastError();
+  return 0;
+}
+
+hipError_t edk_debug_layer(int op, int form, uint8_t* out, size_t out_w, const uint8_t* in, size_t in_w, size_t n,
+                           const uint32_t* base16, const uint32_t* comb_img, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  if (!edk_debug_layer_widths_ok(op, form, in_w, out_w)) return hipErrorInvalidValue;
+  void* scratch = nullptr;
+  hipError_t e = hipSuccess;
+  const unsigned qblocks = (unsigned)((n + QUAD_CHAIN_ITEMS - 1) / QUAD_CHAIN_ITEMS);
+  if (op == L_ED_SCALE_BASE) {
+    hipLaunchKernelGGL(k_debug_scale_base, dim3((unsigned)((n + POINT_BLOCK - 1) / POINT_BLOCK)), dim3(POINT_BLOCK), 0, stream, out, in, n, comb_img);
+  } else if (op == L_ED_DUAL_SCALE && form == 1) {
+    if ((e = hipMalloc(&scratch, (size_t)qblocks * QUAD_CHAIN_ITEMS * LAYER_QUAD_SCRATCH_WORDS * 4)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_debug_dual_scale_quad, dim3(qblocks), dim3(QUAD_CHAIN_BLOCK), 0, stream, out, in, n, base16, (uint32_t*)scratch);
+  } else if (op == L_GE_DBL_ADD && form == 1) {
+    hipLaunchKernelGGL(k_debug_dbl_add_quad, dim3(qblocks), dim3(QUAD_CHAIN_BLOCK), 0, stream, out, in, n, base16);
+  } else {
+    if (op == L_ED_DUAL_SCALE && form == 2 && (e = hipMalloc(&scratch, n * LAYER_SCRATCH_BYTES)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_debug_layer, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, op, form, out, out_w, in, in_w, n, base16, (uint8_t*)scratch);
+  }
+  e = hipGetLastError();
+  if (scratch) {                                   // a probe, not a hot path: wait, then release
+    const hipError_t e2 = hipStreamSynchronize(stream);
+    if (e == hipSuccess) e = e2;
+    (void)hipFree(scratch);                        // (teardown of a test buffer: public data, nothing to report to)
+  }
+  return e;
 }
 
 #define EDK_GRID(n) dim3((unsigned)(((n) + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream

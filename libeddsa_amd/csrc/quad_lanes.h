@@ -165,11 +165,24 @@ ED_DEV void quad_stage_b(fe& out, const fe& m, int q) {
   fe_mul(out, x, y);
 }
 
-// ed.c:479-506 for one item; `item` = its addends (HBM), `dig` = its digit pairs (LDS), q = lane & 3.  Returns (in
-// every lane, but lane 1 is the one that holds y) whether the encoding of the result equals R's bytes.
+// ed_export (ed.c:155-169) of the point whose coordinates (X, Y, T, Z) sit in the four lanes of the quad: every lane
+// inverts Z (fld_inv(0) = 0 as in the reference); lane 1 ends up with the 32 encoded bytes in wd (the other lanes with
+// the encodings of x, t and 1 under the same parity bit: not used)
+ED_DEV void quad_encode(uint32_t wd[8], const fe& r) {
+  fe z, zi, aff;
+  fe_quad_perm<3, 3, 3, 3>(z, r);
+  fe_inv(zi, z);
+  fe_mul(aff, r, zi);
+  fe_tobytes(wd, aff);
+  const uint32_t xpar = (uint32_t)__builtin_amdgcn_mov_dpp((int)wd[0], 0, 0xf, 0xf, true) & 1u;
+  wd[7] |= xpar << 31;
+}
+
+// ed.c:479-506 for one item; `item` = its addends (HBM), `dig` = its digit pairs (LDS), q = lane & 3.  Leaves the
+// encoding of the result in wd (lane 1 of the quad: quad_encode).
 // A step whose digit pair is (0, 0) in EVERY item of the wave skips the addition altogether (the select would discard
 // it anyway): in a small pass, where a wave carries one or two items, that is half the additions.
-ED_DEV bool verify_exact_chain_quad(const uint32_t rw[8], const uint32_t* item, const uint32_t* dig, int q) {
+ED_DEV void exact_chain_encode_quad(uint32_t wd[8], const uint32_t* item, const uint32_t* dig, int q) {
   fe r, k;
   fe_set(r, (uint32_t)(q & 1));                  // neutral element (0, 1, 0, 1) as (X, Y, T, Z)
   fe_set(k, 1);                                  // the doubling's constants (1, 1, 2d, 2)
@@ -218,16 +231,14 @@ ED_DEV bool verify_exact_chain_quad(const uint32_t rw[8], const uint32_t* item, 
     i--;
   }
 #undef QUAD_PREPARE_STEP
-  // ed_export (ed.c:155-169): every lane inverts Z (fld_inv(0) = 0 as in the reference); lane 0
-  // ends up with x, lane 1 with y
-  fe z, zi, aff;
-  fe_quad_perm<3, 3, 3, 3>(z, r);
-  fe_inv(zi, z);
-  fe_mul(aff, r, zi);
+  quad_encode(wd, r);
+}
+
+// ... and the byte comparison with R (ed25519-sha512.c:176-180): returns (in every lane, but lane 1 is the one that
+// holds y) whether the encoding of the result equals R's bytes
+ED_DEV bool verify_exact_chain_quad(const uint32_t rw[8], const uint32_t* item, const uint32_t* dig, int q) {
   uint32_t wd[8];
-  fe_tobytes(wd, aff);
-  const uint32_t xpar = (uint32_t)__builtin_amdgcn_mov_dpp((int)wd[0], 0, 0xf, 0xf, true) & 1u;
-  wd[7] |= xpar << 31;
+  exact_chain_encode_quad(wd, item, dig, q);
   uint32_t diff = 0;
 #pragma unroll
   for (int j = 0; j < 8; j++) diff |= wd[j] ^ rw[j];

@@ -19,6 +19,7 @@
 
 #include "eddsa.h"
 #include "eddsa_amd.h"
+#include "eddsa_amd_debug.h"      /* combiner statistics, pipeline trace: the measurement surface */
 
 static uint8_t *slurp(const char *path, size_t *len)
 {

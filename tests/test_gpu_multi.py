@@ -262,8 +262,11 @@ def test_secrets_do_not_outlive_the_call_in_hbm(engine):
     engine.x25519_batch(dev(sk), dev(pt)); torch.cuda.synchronize()
     assert engine.secret_residue() == (0, 0, 0, 0)
     # a call that FAILS after staging its inputs wipes them as well (one chunk, and two)
+    assert engine.debug_fail_next_host_call() == engine.HOOKS_OFF       # (shutdown disarmed the hooks: nothing happens)
+    assert np.array_equal(engine.x25519_batch(sk[:8], pt[:8]), engine.x25519_batch(dev(sk[:8]), dev(pt[:8])).cpu().numpy())
+    engine.debug_init(0)
     for m in (1000, n):
-        engine.library().eddsa_amd_debug_fail_next_host_call()
+        assert engine.debug_fail_next_host_call() == 0
         with pytest.raises(engine.EddsaAmdError):
             engine.x25519_batch(sk[:m], pt[:m])
         assert engine.secret_residue() == (0, 0, 0, 0), m

@@ -638,3 +638,10 @@ def test_bench_two_ranks_on_one_gpu(engine):
     assert d["value"] > 0 and len(d["per_rank"]["ranks"]) == 2
     for op in ("x25519", "sign"):
         assert len(d["secondary"][op]["per_rank"]["ranks"]) == 2 and d["secondary"][op]["cpu_baseline"] is not None
+    # SCALE readiness: what the gather ran over, a device per rank (here: the test hook says they share one),
+    # and every rank's clock / power sample
+    r = d["rccl"]
+    assert r["world"] == 2 and r["backend"] == "gloo" and r["is_rccl"] is False and r["shared_gpu_test_hook"] is True
+    assert len(r["devices"]) == 2 and r["devices_distinct"] is False
+    for row in d["per_rank"]["ranks"]:
+        assert {"rank", "device", "kernel_ms", "gather_ms", "wall_ms_per_step", "power_w", "sclk_mhz"} <= set(row)
