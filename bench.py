@@ -366,8 +366,9 @@ def per_rank_breakdown(world, rank, steps, k_ms, g_ms):
     """N > 1: every rank's kernel ms, gather ms and wall ms per step, collected at rank 0 over the host group"""
     if world == 1:
         return None
-    smi = SmiSampler(torch.cuda.current_device()).read()     # one sample right after the region: boxes (and ranks) differ in the clock they hold
-    mine = {"rank": rank, "device": torch.cuda.current_device(), "kernel_ms": k_ms, "gather_ms": g_ms,
+    dev = my_device()
+    smi = SmiSampler(dev).read() if dev >= 0 else None       # one sample right after the region: boxes (and ranks) differ in the clock they hold
+    mine = {"rank": rank, "device": dev, "kernel_ms": k_ms, "gather_ms": g_ms,
             "wall_ms_per_step": LOCAL_ELAPSED[0] / steps * 1e3, "power_w": smi[1] if smi else None, "sclk_mhz": smi[2] if smi else None}
     rows = [None] * world
     dist.all_gather_object(rows, mine, group=HOST_GROUP[0])
@@ -377,6 +378,11 @@ def per_rank_breakdown(world, rank, steps, k_ms, g_ms):
             "gather_ms_max": max(r["gather_ms"] for r in rows),
             "note": "kernel_ms: HIP events around the pass on the rank's stream; gather_ms: from the kernels' end to the end of the "
                     "result gather on that stream (includes waiting for the slowest rank's kernels)"}
+
+
+def my_device():
+    """this rank's HIP device, -1 where there is none (the CPU tests of the N > 1 plumbing)"""
+    return torch.cuda.current_device() if torch.cuda.is_available() else -1
 
 
 def devices_distinct(devs, world, shared_gpu):
@@ -392,7 +398,7 @@ def collective_facts(world, backend, shared_gpu):
     ranks sit on one device (a scaling point measured that way would be meaningless) - unless the one-GPU test hook
     EDDSA_BENCH_SHARE_GPU asked for exactly that, which the line then says."""
     devs = [None] * world
-    dist.all_gather_object(devs, torch.cuda.current_device(), group=HOST_GROUP[0])
+    dist.all_gather_object(devs, my_device(), group=HOST_GROUP[0])
     distinct = devices_distinct(devs, world, shared_gpu)
     try:
         ver = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None

@@ -242,6 +242,17 @@ pr = bench.per_rank_breakdown(world, rank, 4, 10.0 * (rank + 1), 1.0 + rank)
 assert [r["rank"] for r in pr["ranks"]] == [0, 1] and pr["slowest_rank"] == 1, pr
 assert pr["kernel_ms_min_max"] == [10.0, 20.0] and pr["gather_ms_max"] == 2.0
 assert abs(pr["ranks"][rank]["wall_ms_per_step"] - bench.LOCAL_ELAPSED[0] / 4 * 1e3) < 1e-6
+# SCALE readiness: every rank's row names its device and carries a clock / power sample (None without a GPU); the line
+# states what the gather ran over, with world == N, and two ranks on one device are refused unless the test hook says so
+assert all({"device", "power_w", "sclk_mhz"} <= set(r) for r in pr["ranks"])
+facts = bench.collective_facts(world, "gloo", True)
+assert facts["world"] == world == 2 and facts["backend"] == "gloo" and facts["version"] is None and facts["is_rccl"] is False
+assert facts["devices"] == [-1, -1] and facts["devices_distinct"] is False and facts["shared_gpu_test_hook"] is True
+try:
+    bench.collective_facts(world, "gloo", False)
+    raise AssertionError("two ranks on one device were accepted")
+except SystemExit:
+    pass
 t0 = time.perf_counter()
 if rank == 0:
     time.sleep(0.3)                                      # rank 0 "times the CPU baseline"; rank 1 sleeps in the barrier
