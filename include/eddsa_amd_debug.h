@@ -106,6 +106,10 @@ EDDSA_AMD_DECL int eddsa_amd_halve_rejected(uint64_t *count);
  * none: 0) */
 EDDSA_AMD_DECL void eddsa_amd_set_profiling(int on);
 EDDSA_AMD_DECL int eddsa_amd_verify_phase_ms(float out[3]);
+/* HIP calls on teardown and clean-up paths (frees, destroys, restoring the caller's device, waiting for what a failed pass
+ * had queued) have no caller to report to: their failures are counted instead.  Returns the count since the library was
+ * loaded, *first_hip_error (may be NULL) the first hipError_t.  Expected: 0. */
+EDDSA_AMD_DECL int eddsa_amd_debug_teardown_errors(int *first_hip_error);
 /* for the secret-hygiene tests: waits for the default device to go idle and counts the non-zero bytes left in out[0]
  * the scalar workspace (sign's secret scalars a, r between its two kernels), out[1] the point workspace (x25519's
  * (x2 : z2); public for the other operations), out[2] the host pipeline's first input staging buffers (secret keys /

@@ -17,6 +17,7 @@ from .api import (  # noqa: F401
     debug_hip_calls,
     debug_init,
     debug_layer,
+    debug_teardown_errors,
     halve_rejected,
     host_array,
     host_free,

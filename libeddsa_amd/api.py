@@ -118,6 +118,12 @@ def debug_hip_calls():
     return int(library().eddsa_amd_debug_hip_calls())
 
 
+def debug_teardown_errors():
+    """(count, first hipError_t) of the HIP calls that failed on teardown / clean-up paths since the library was loaded"""
+    first = ctypes.c_int(0)
+    return int(library().eddsa_amd_debug_teardown_errors(ctypes.byref(first))), int(first.value)
+
+
 def debug_layer(op, items, out_w, form=0):
     """run one layer of the device code (include/eddsa_amd_debug.h) on `items` (equal-length byte strings): -> list of
     out_w-byte results.  Needs debug_init(hooks=True)."""

@@ -43,6 +43,29 @@ const char *eddsa_amd_strerror(int err)
     return hipGetErrorString((hipError_t)(-err));
 }
 
+static struct { int count, first; char what[96]; } g_teardown;   /* hip_note: count and first are atomic; what is written by the first */
+
+void hip_note(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return;
+    if (__atomic_fetch_add(&g_teardown.count, 1, __ATOMIC_ACQ_REL) == 0) {
+        __atomic_store_n(&g_teardown.first, (int)e, __ATOMIC_RELEASE);
+        strncpy(g_teardown.what, what, sizeof(g_teardown.what) - 1);
+    }
+    (void)hipGetLastError();               /* noted: the sticky slot is cleared (the only unchecked HIP calls of the host side are this one and hip_forget_error's) */
+}
+
+void hip_forget_error(void)
+{
+    (void)hipGetLastError();               /* the caller has handled the answer it stands for */
+}
+
+int eddsa_amd_debug_teardown_errors(int *first_hip_error)
+{
+    if (first_hip_error) *first_hip_error = __atomic_load_n(&g_teardown.first, __ATOMIC_ACQUIRE);
+    return __atomic_load_n(&g_teardown.count, __ATOMIC_ACQUIRE);
+}
+
 /* ------------------------------------------------------------------------------------------
  * engines
  * ---------------------------------------------------------------------------------------- */
@@ -52,22 +75,22 @@ const char *eddsa_amd_strerror(int err)
 void wipe_free(void *p, size_t bytes)
 {
     if (!p) return;
-    if (bytes) { (void)hipMemset(p, 0, bytes); (void)hipDeviceSynchronize(); }
-    (void)hipFree(p);
+    if (bytes) { HIP_NOTE(hipMemset(p, 0, bytes)); HIP_NOTE(hipDeviceSynchronize()); }
+    HIP_NOTE(hipFree(p));
 }
 
 static void ws_release(struct vslot *v)
 {
-    if (v->ws.digits) (void)hipFree(v->ws.digits);
-    if (v->ws.table) (void)hipFree(v->ws.table);
-    if (v->ws.acc) (void)hipFree(v->ws.acc);
-    if (v->ws.flags) (void)hipFree(v->ws.flags);
-    if (v->ws.hdigits) (void)hipFree(v->ws.hdigits);
-    if (v->ws.rtable) (void)hipFree(v->ws.rtable);
-    if (v->ws.offlist) (void)hipFree(v->ws.offlist);
-    if (v->ws.offcount) (void)hipFree(v->ws.offcount);
-    if (v->ws.exact_pad) (void)hipFree(v->ws.exact_pad);
-    if (v->ws.sums) (void)hipFree(v->ws.sums);
+    if (v->ws.digits) HIP_NOTE(hipFree(v->ws.digits));
+    if (v->ws.table) HIP_NOTE(hipFree(v->ws.table));
+    if (v->ws.acc) HIP_NOTE(hipFree(v->ws.acc));
+    if (v->ws.flags) HIP_NOTE(hipFree(v->ws.flags));
+    if (v->ws.hdigits) HIP_NOTE(hipFree(v->ws.hdigits));
+    if (v->ws.rtable) HIP_NOTE(hipFree(v->ws.rtable));
+    if (v->ws.offlist) HIP_NOTE(hipFree(v->ws.offlist));
+    if (v->ws.offcount) HIP_NOTE(hipFree(v->ws.offcount));
+    if (v->ws.exact_pad) HIP_NOTE(hipFree(v->ws.exact_pad));
+    if (v->ws.sums) HIP_NOTE(hipFree(v->ws.sums));
     v->ws.capacity = 0;
     v->ws.digits = v->ws.table = v->ws.acc = v->ws.offlist = v->ws.offcount = v->ws.exact_pad = NULL;
     v->ws.hdigits = v->ws.rtable = v->ws.sums = NULL;
@@ -83,8 +106,8 @@ static void fws_release(struct vslot *v)
 
 static void rws_release(struct vslot *v)
 {
-    if (v->rws.base) (void)hipFree(v->rws.base);
-    if (v->rws.host_gok) (void)hipHostFree(v->rws.host_gok);
+    if (v->rws.base) HIP_NOTE(hipFree(v->rws.base));
+    if (v->rws.host_gok) HIP_NOTE(hipHostFree(v->rws.host_gok));
     memset(&v->rws, 0, sizeof(v->rws));
 }
 
@@ -184,7 +207,7 @@ static struct vslot *ws_pick(struct engine *e, hipStream_t st)
  * flight) and has made e->device current. */
 static void engine_destroy(struct engine *e)
 {
-    (void)hipDeviceSynchronize();
+    HIP_NOTE(hipDeviceSynchronize());
     pipe_release(&e->pipe);
     combiner_release(&e->comb_q);
     for (int i = 0; i < VERIFY_SLOTS; i++) {
@@ -192,16 +215,16 @@ static void engine_destroy(struct engine *e)
         ws_release(v);
         fws_release(v);
         rws_release(v);
-        if (v->ws.side) (void)hipStreamDestroy(v->ws.side);
-        if (v->ws.ev_prepared) (void)hipEventDestroy(v->ws.ev_prepared);
-        if (v->ws.ev_exact) (void)hipEventDestroy(v->ws.ev_exact);
-        if (v->free) (void)hipEventDestroy(v->free);
+        if (v->ws.side) HIP_NOTE(hipStreamDestroy(v->ws.side));
+        if (v->ws.ev_prepared) HIP_NOTE(hipEventDestroy(v->ws.ev_prepared));
+        if (v->ws.ev_exact) HIP_NOTE(hipEventDestroy(v->ws.ev_exact));
+        if (v->free) HIP_NOTE(hipEventDestroy(v->free));
     }
-    if (e->base16) (void)hipFree(e->base16);
-    if (e->comb) (void)hipFree(e->comb);
-    if (e->comb_img) (void)hipFree(e->comb_img);
+    if (e->base16) HIP_NOTE(hipFree(e->base16));
+    if (e->comb) HIP_NOTE(hipFree(e->comb));
+    if (e->comb_img) HIP_NOTE(hipFree(e->comb_img));
     for (int s = 0; s < MARK_SLOTS; s++)
-        for (int i = 0; i < 4; i++) if (e->marks[s][i]) (void)hipEventDestroy(e->marks[s][i]);
+        for (int i = 0; i < 4; i++) if (e->marks[s][i]) HIP_NOTE(hipEventDestroy(e->marks[s][i]));
     pthread_mutex_destroy(&e->lk);
     pthread_mutex_destroy(&e->pipe_lk);
     pthread_cond_destroy(&e->slot_cv);
@@ -224,7 +247,7 @@ static int engine_create(int device)
     pthread_cond_init(&e->slot_cv, NULL);
     combiner_init(&e->comb_q);
     pipe_setup(&e->pipe);
-    (void)hipGetDevice(&saved);
+    HIP_NOTE(hipGetDevice(&saved));
     TRY(hipSetDevice(device));
     TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { rc = ERR_NOT_GFX950; goto out; }
@@ -251,7 +274,7 @@ static int engine_create(int device)
     e = NULL;
 out:
     if (e) engine_destroy(e);          /* a half-built engine leaks nothing */
-    if (saved >= 0) (void)hipSetDevice(saved);
+    if (saved >= 0) HIP_NOTE(hipSetDevice(saved));
     return rc;
 }
 
@@ -262,7 +285,9 @@ int enter(struct call *c, int device)
 {
     c->e = NULL;
     c->saved = -1;
-    for (int attempt = 0; attempt < 2; attempt++) {
+    /* (an engine built here can be torn down again by a concurrent eddsa_amd_shutdown before this thread holds the table
+     * for reading: then it is built once more; only a storm of shutdowns could use up the attempts) */
+    for (int attempt = 0; attempt < 16; attempt++) {
         pthread_rwlock_rdlock(&g_table);
         int dev = device >= 0 ? device : g_default;
         if (dev < 0) {                     /* never bound: the caller's current device becomes the default */
@@ -273,7 +298,7 @@ int enter(struct call *c, int device)
         if (g_eng[dev]) {
             hipError_t er;
             c->e = g_eng[dev];
-            (void)hipGetDevice(&c->saved);
+            HIP_NOTE(hipGetDevice(&c->saved));
             er = hipSetDevice(dev);
             if (er != hipSuccess) { pthread_rwlock_unlock(&g_table); return -(int)er; }
             return 0;
@@ -290,7 +315,7 @@ int enter(struct call *c, int device)
 
 void leave(struct call *c)
 {
-    if (c->saved >= 0) (void)hipSetDevice(c->saved);
+    if (c->saved >= 0) HIP_NOTE(hipSetDevice(c->saved));
     pthread_rwlock_unlock(&g_table);
 }
 
@@ -299,7 +324,7 @@ static int device_of(const void *p, int *device)
 {
     hipPointerAttribute_t a;
     hipError_t er = hipPointerGetAttributes(&a, p);
-    if (er != hipSuccess) { (void)hipGetLastError(); return -(int)hipErrorInvalidValue; }
+    if (er != hipSuccess) { hip_forget_error(); return -(int)hipErrorInvalidValue; }
     if (a.type != hipMemoryTypeDevice && a.type != hipMemoryTypeManaged) return -(int)hipErrorInvalidValue;
     *device = a.device;
     return 0;
@@ -332,18 +357,18 @@ void eddsa_amd_shutdown(void)
 {
     int saved = -1;
     pthread_rwlock_wrlock(&g_table);
-    (void)hipGetDevice(&saved);
+    HIP_NOTE(hipGetDevice(&saved));
     multi_release();
     for (int d = 0; d < MAX_DEVICES; d++) {
         if (!g_eng[d]) continue;
-        (void)hipSetDevice(d);
+        HIP_NOTE(hipSetDevice(d));
         engine_destroy(g_eng[d]);
         g_eng[d] = NULL;
     }
     g_default = -1;
     __atomic_store_n(&g_hooks_armed, 0, __ATOMIC_RELEASE);
     (void)edk_debug_fail_in(0);
-    if (saved >= 0) (void)hipSetDevice(saved);   /* teardown: nothing to report to */
+    if (saved >= 0) HIP_NOTE(hipSetDevice(saved));   /* teardown: nothing to report to */
     pthread_rwlock_unlock(&g_table);
     host_pool_stop();
 }
@@ -392,8 +417,8 @@ int eddsa_amd_debug_layer(int op, int form, uint8_t *out, size_t out_w, const ui
     TRY(hipStreamSynchronize(NULL));
     TRY(hipMemcpy(out, d_out, n * out_w, hipMemcpyDeviceToHost));
 out:
-    if (d_in) (void)hipFree(d_in);     /* probe buffers: public test data */
-    if (d_out) (void)hipFree(d_out);
+    if (d_in) HIP_NOTE(hipFree(d_in));     /* probe buffers: public test data */
+    if (d_out) HIP_NOTE(hipFree(d_out));
     leave(&c);
     return rc;
 }
@@ -436,8 +461,8 @@ int eddsa_amd_debug_halve(uint8_t *out48, const uint8_t *t32, size_t n, int wide
     TRY(edk_debug_halve(d_o, d_t, n, wide, NULL));
     TRY(hipMemcpy(out48, d_o, n * 48, hipMemcpyDeviceToHost));
 out:
-    if (d_t) (void)hipFree(d_t);
-    if (d_o) (void)hipFree(d_o);
+    if (d_t) HIP_NOTE(hipFree(d_t));
+    if (d_o) HIP_NOTE(hipFree(d_o));
     leave(&c);
     return rc;
 }
@@ -530,9 +555,9 @@ out:
  * slot can be handed out (and possibly re-allocated) again */
 static void slot_quiesce(struct vslot *v, hipStream_t st)
 {
-    (void)hipStreamSynchronize(st);
-    if (v->ws.side) (void)hipStreamSynchronize(v->ws.side);
-    (void)hipEventRecord(v->free, st);
+    HIP_NOTE(hipStreamSynchronize(st));
+    if (v->ws.side) HIP_NOTE(hipStreamSynchronize(v->ws.side));
+    HIP_NOTE(hipEventRecord(v->free, st));
 }
 
 /* both verify forms: chunks of at most CHUNK_MAX items through the workspace */
@@ -857,9 +882,9 @@ int eddsa_amd_init_devices(const int *devices, int n)
     if (!rc) rc = rccl_load();
     if (!rc) {
         int saved = -1, r;
-        (void)hipGetDevice(&saved);
+        HIP_NOTE(hipGetDevice(&saved));
         r = g_multi.CommInitAll(g_multi.comm, n, devices);     /* single process, one communicator per device */
-        if (saved >= 0) (void)hipSetDevice(saved);
+        if (saved >= 0) HIP_NOTE(hipSetDevice(saved));
         if (r) rc = ERR_RCCL_BASE - r;
     }
     if (!rc) {
@@ -902,7 +927,7 @@ int ed25519_verify_batch_multi_dev(uint8_t *const ok_full[], const uint8_t *cons
     g = g_multi.n;
     if (g == 0) { rc = -(int)hipErrorNotInitialized; goto unlock; }
     if (n_total == 0) goto unlock;
-    (void)hipGetDevice(&saved);
+    HIP_NOTE(hipGetDevice(&saved));
     /* concurrent callers must not interleave their launches or their grouped RCCL calls on the shared communicators */
     pthread_mutex_lock(&g_rccl_lk);
     locked = 1;
@@ -937,7 +962,7 @@ int ed25519_verify_batch_multi_dev(uint8_t *const ok_full[], const uint8_t *cons
     if (r && !rc) rc = ERR_RCCL_BASE - r;
 out:
     if (locked) pthread_mutex_unlock(&g_rccl_lk);
-    if (saved >= 0) (void)hipSetDevice(saved);
+    if (saved >= 0) HIP_NOTE(hipSetDevice(saved));
 unlock:
     pthread_rwlock_unlock(&g_table);
     return rc;

@@ -41,6 +41,16 @@
 
 #define TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = -(int)e_; goto out; } } while (0)
 
+/* HIP calls on teardown and clean-up paths - frees, destroys, restoring the caller's device, waiting for what a failed
+ * pass had queued - have nobody to return an error to.  They are not ignored: hip_note() counts the failures and keeps
+ * the first (eddsa_amd_debug_teardown_errors; the GPU tests require zero after shutdown / re-initialisation cycles). */
+void hip_note(hipError_t e, const char *what);
+#define HIP_NOTE(call) hip_note((call), #call)
+/* hipPointerGetAttributes / hipHostMalloc report "no such allocation" / "out of memory" through the sticky last-error
+ * slot as well; when that answer has been handled, the slot is cleared so that a later hipGetLastError() of the caller's
+ * does not see it */
+void hip_forget_error(void);
+
 /* Workspaces: a small pool, so that passes issued on DIFFERENT streams (host threads that each own a stream, the
  * lanes of the host pipeline) overlap on the GPU instead of queueing behind one workspace.  A stream keeps the
  * slot it used last (passes on one stream are ordered anyway, and the slot has the right size); another stream

@@ -22,14 +22,14 @@ namespace ed {
 
 // host test build only: how many Lehmer rounds and how many plain iterations ran (tests/test_device_source_on_host.py)
 #ifdef ED_HOST_CHECK
-inline long halve_counters[2];
+inline thread_local long halve_counters[2];   // (per thread: the sanitizer build of the host side runs this source on several threads)
 #define HALVE_COUNT(i) (++::ed::halve_counters[i])
 // fault injection (tests only): n > 0 makes the n-th working half-step from now on take a quotient that is one too
 // large - the failure the floating-point margins exist to exclude (the remainder wraps; the search then usually runs
 // into its own give-up rules) - and n < 0 makes the |n|-th working half-step update the COFACTOR with a quotient one
 // too large (remainders, hence the choice of the pair, stay right; the pair's congruence is broken).  Whatever comes
 // out, lanes.h: verify_half_scalars_lane must not let a wrong pair through.
-inline int halve_fault;
+inline thread_local int halve_fault;
 #define HALVE_FAULT(q, active) do { if ((active) && ::ed::halve_fault > 0 && --::ed::halve_fault == 0) (q) += 1u; } while (0)
 #define HALVE_FAULT_COFACTOR(q, active) do { if ((active) && ::ed::halve_fault < 0 && ++::ed::halve_fault == 0) (q) += 1u; } while (0)
 #else

@@ -180,28 +180,28 @@ void *eddsa_amd_host_alloc(size_t bytes)
     struct call c;
     void *p = NULL;
     if (enter(&c, -1)) return NULL;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = NULL; }
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { hip_forget_error(); p = NULL; }
     leave(&c);
     return p;
 }
 
 void eddsa_amd_host_free(void *p)
 {
-    if (p) (void)hipHostFree(p);
+    if (p) HIP_NOTE(hipHostFree(p));
 }
 
-/* is [p, p + bytes) page-locked memory the DMA engines can read directly?  Both ends must lie in the SAME page-locked
- * allocation (an array whose head is registered and whose tail is pageable is staged like ordinary memory) */
+/* is [p, p + bytes) page-locked memory the DMA engines can read directly?  BOTH ends are asked (an array whose head was
+ * registered and whose tail is pageable - a view that runs past a registered window - is staged like ordinary memory);
+ * the runtime has no query for "one allocation", so a range glued together from two registrations passes: each of its
+ * pages is page-locked, which is what the copy needs */
 static int is_pinned(const void *p, size_t bytes)
 {
     hipPointerAttribute_t a, b;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return 0; }   /* "not registered" is an answer, not a failure */
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { hip_forget_error(); return 0; }   /* "not registered" is an answer, not a failure */
     if (a.type != hipMemoryTypeHost) return 0;
     if (bytes <= 1) return 1;
-    if (hipPointerGetAttributes(&b, (const uint8_t *)p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    /* the same allocation: its host base pointer is the same distance below both ends */
-    return b.type == hipMemoryTypeHost && a.hostPointer && b.hostPointer &&
-           (const uint8_t *)b.hostPointer - (const uint8_t *)a.hostPointer == (ptrdiff_t)(bytes - 1);
+    if (hipPointerGetAttributes(&b, (const uint8_t *)p + bytes - 1) != hipSuccess) { hip_forget_error(); return 0; }
+    return b.type == hipMemoryTypeHost;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -261,14 +261,14 @@ static int dev_grow(void **buf, size_t *cap, size_t need, hipStream_t st)
     hipError_t e = hipMalloc(buf, need);
     if (e != hipSuccess) return -(int)e;
     e = hipMemsetAsync(*buf, 0, need, st);
-    if (e != hipSuccess) { (void)hipFree(*buf); *buf = NULL; return -(int)e; }
+    if (e != hipSuccess) { HIP_NOTE(hipFree(*buf)); *buf = NULL; return -(int)e; }
     *cap = need;
     return 0;
 }
 
 static void host_free_wiped(void **buf, size_t *cap)
 {
-    if (*buf) { memset(*buf, 0, *cap); (void)hipHostFree(*buf); }
+    if (*buf) { memset(*buf, 0, *cap); HIP_NOTE(hipHostFree(*buf)); }
     *buf = NULL; *cap = 0;
 }
 
@@ -314,11 +314,11 @@ void pipe_release(struct pipe *p)
         wipe_free(L->d_msgs, 0); host_free_wiped(&L->h_msgs, &L->h_msgs_cap);
         wipe_free(L->d_out, L->d_out_cap); host_free_wiped(&L->h_out, &L->h_out_cap);
         wipe_free(L->d_off, 0); host_free_wiped(&L->h_off, &L->h_off_cap);
-        if (L->st) (void)hipStreamDestroy(L->st);
-        if (L->kdone) (void)hipEventDestroy(L->kdone);
+        if (L->st) HIP_NOTE(hipStreamDestroy(L->st));
+        if (L->kdone) HIP_NOTE(hipEventDestroy(L->kdone));
     }
-    if (p->d_stats) (void)hipFree(p->d_stats);
-    if (p->h_stats) (void)hipHostFree(p->h_stats);
+    if (p->d_stats) HIP_NOTE(hipFree(p->d_stats));
+    if (p->h_stats) HIP_NOTE(hipHostFree(p->h_stats));
     memset(p, 0, sizeof(*p));
 }
 
@@ -427,17 +427,20 @@ static int g_fail_next_host_call;      /* eddsa_amd_debug_fail_next_host_call: s
 /* measurement aid: host-side time stamps of the last host-pointer call (eddsa_amd_debug_pipe_trace) */
 #define TRACE_MAX 512
 /* one trace per process; stamps of concurrent calls interleave.  Slots are reserved atomically (leaders of different
- * operations stamp at the same time), on / n / seen are read and written atomically */
-static struct { int on, n, seen; int tag[TRACE_MAX]; unsigned chunk[TRACE_MAX]; double t[TRACE_MAX]; } g_trace;
+ * operations stamp at the same time) and filled with atomic stores (a call that restarts the trace may hand a slot out
+ * again while its previous owner is still writing: the stamp is then a mix of two calls' - it is a diagnostic - but never a
+ * data race); on / n / seen are read and written atomically; the reader holds g_table for writing, i.e. no call is in flight */
+static struct { int on, n, seen; int tag[TRACE_MAX]; unsigned chunk[TRACE_MAX]; int64_t t_ns[TRACE_MAX]; } g_trace;
 #define TRACE_ON() __atomic_load_n(&g_trace.on, __ATOMIC_RELAXED)
-static double trace_now(void)
+static int64_t trace_now(void)
 {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
-    return (double)ts.tv_sec * 1e3 + 1e-6 * (double)ts.tv_nsec;
+    return (int64_t)ts.tv_sec * 1000000000 + ts.tv_nsec;
 }
 #define TRACE(tag_, k_) do { if (TRACE_ON()) { const int i_ = __atomic_fetch_add(&g_trace.n, 1, __ATOMIC_RELAXED); \
-    if (i_ >= 0 && i_ < TRACE_MAX) { g_trace.tag[i_] = (tag_); g_trace.chunk[i_] = (k_); g_trace.t[i_] = trace_now(); } } } while (0)
+    if (i_ >= 0 && i_ < TRACE_MAX) { __atomic_store_n(&g_trace.tag[i_], (tag_), __ATOMIC_RELAXED); \
+        __atomic_store_n(&g_trace.chunk[i_], (unsigned)(k_), __ATOMIC_RELAXED); __atomic_store_n(&g_trace.t_ns[i_], trace_now(), __ATOMIC_RELAXED); } } } while (0)
 #define TRACE_RESTART() __atomic_store_n(&g_trace.n, 0, __ATOMIC_RELAXED)
 
 /* on != 0: record host-side time stamps in every host-pointer call from now on; returns the number of stamps of the last
@@ -451,7 +454,10 @@ int eddsa_amd_debug_pipe_trace(int on, int *tags, unsigned *chunks, double *ms, 
     int n = __atomic_load_n(&g_trace.n, __ATOMIC_RELAXED);
     n = n > TRACE_MAX ? TRACE_MAX : n;
     n = n < max ? n : max;
-    for (int i = 0; i < n; i++) { tags[i] = g_trace.tag[i]; chunks[i] = g_trace.chunk[i]; ms[i] = g_trace.t[i] - g_trace.t[0]; }
+    for (int i = 0; i < n; i++) {
+        tags[i] = __atomic_load_n(&g_trace.tag[i], __ATOMIC_RELAXED); chunks[i] = __atomic_load_n(&g_trace.chunk[i], __ATOMIC_RELAXED);
+        ms[i] = 1e-6 * (double)(__atomic_load_n(&g_trace.t_ns[i], __ATOMIC_RELAXED) - __atomic_load_n(&g_trace.t_ns[0], __ATOMIC_RELAXED));
+    }
     __atomic_store_n(&g_trace.on, on, __ATOMIC_RELAXED);
     __atomic_store_n(&g_trace.seen, 0, __ATOMIC_RELAXED);
     pthread_rwlock_unlock(&g_table);
@@ -591,11 +597,11 @@ out:
         for (int l = 0; l < PIPE_LANES; l++) {
             struct lane *L = &p->lane[l];
             if (!all && l != base) continue;
-            (void)hipStreamSynchronize(L->st);
+            HIP_NOTE(hipStreamSynchronize(L->st));
             L->pend_bytes = 0; L->used_in0 = 0;
-            if ((j->wipe & WIPE_IN0) && L->d_in[0]) (void)hipMemsetAsync(L->d_in[0], 0, L->d_in_cap[0], L->st);
-            if ((j->wipe & WIPE_OUT) && L->d_out) (void)hipMemsetAsync(L->d_out, 0, L->d_out_cap, L->st);
-            if (j->wipe) (void)hipStreamSynchronize(L->st);
+            if ((j->wipe & WIPE_IN0) && L->d_in[0]) HIP_NOTE(hipMemsetAsync(L->d_in[0], 0, L->d_in_cap[0], L->st));
+            if ((j->wipe & WIPE_OUT) && L->d_out) HIP_NOTE(hipMemsetAsync(L->d_out, 0, L->d_out_cap, L->st));
+            if (j->wipe) HIP_NOTE(hipStreamSynchronize(L->st));
             if ((j->wipe & WIPE_IN0) && L->h_in[0]) pool_submit(&wipes, (uint8_t *)L->h_in[0], NULL, L->h_in_cap[0], 0);
             if ((j->wipe & WIPE_OUT) && L->h_out) pool_submit(&wipes, (uint8_t *)L->h_out, NULL, L->h_out_cap, 0);
         }

@@ -43,6 +43,7 @@
 // bytes: the same 129 per item as verify.  The per-lane arithmetic (decoding and routing flags,
 // coefficients, digit recoding) is in rlc_lanes.h, which the host-check build also compiles.
 #include "eddsa_kernels.h"
+#include "edk_checked.h"
 #include "rlc_lanes.h"
 #include "quad_lanes.h"
 
@@ -479,37 +480,37 @@ extern "C" hipError_t edk_verify_rlc(uint8_t* ok, uint32_t* stats, const edk_ver
   const unsigned blocks = (unsigned)((n + RLC_BLOCK - 1) / RLC_BLOCK);
   hipError_t e;
 
-  if ((e = hipMemsetAsync(gflags, 0, groups * 4, stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_rlc_hash, dim3(blocks), dim3(RLC_BLOCK), 0, stream, src, n, ts, leaf);
+  EDK_DO(hipMemsetAsync(gflags, 0, groups * 4, stream));
+  EDK_LAUNCH(k_rlc_hash, dim3(blocks), dim3(RLC_BLOCK), 0, stream, src, n, ts, leaf);
   // the batch seed: a SHA-512 tree of fan-in 64 over the leaves, on the side stream beside k_rlc_points
-  (void)hipEventRecord(ws->ev_prepared, stream);
-  (void)hipStreamWaitEvent(ws->side, ws->ev_prepared, 0);
+  EDK_DO(hipEventRecord(ws->ev_prepared, stream));
+  EDK_DO(hipStreamWaitEvent(ws->side, ws->ev_prepared, 0));
   const uint32_t* level = leaf;
   uint32_t* bufs[2] = {tree, tree + 8 * (rws->capacity / RLC_TREE_FAN + 2)};
   size_t count = n;
   int flip = 0;
   do {
     const size_t next = (count + RLC_TREE_FAN - 1) / RLC_TREE_FAN;
-    hipLaunchKernelGGL(k_rlc_tree, dim3((unsigned)((next + 63) / 64)), dim3(64), 0, ws->side, level, bufs[flip], count);
+    EDK_LAUNCH(k_rlc_tree, dim3((unsigned)((next + 63) / 64)), dim3(64), 0, ws->side, level, bufs[flip], count);
     level = bufs[flip];
     flip ^= 1;
     count = next;
   } while (count > 1);
   const uint32_t* seed = level;
-  (void)hipEventRecord(ws->ev_exact, ws->side);
-  hipLaunchKernelGGL(k_rlc_points, dim3(blocks), dim3(RLC_BLOCK), 0, stream, src, n, niels_a, niels_r, flags, gflags);
-  (void)hipStreamWaitEvent(stream, ws->ev_exact, 0);
-  hipLaunchKernelGGL(k_rlc_scalars, dim3((unsigned)(groups * (RLC_G / RLC_BLOCK))), dim3(RLC_BLOCK), 0, stream, n, ts, seed, flags, dig, bsum);
-  hipLaunchKernelGGL(k_rlc_group_scalar, dim3((unsigned)((groups + 63) / 64)), dim3(64), 0, stream, n, bsum, bdig);
-  hipLaunchKernelGGL(k_rlc_bucket, dim3((unsigned)(groups * RLC_SEGS)), dim3(RLC_BUCKETS), 0, stream, n, dig, bdig,
+  EDK_DO(hipEventRecord(ws->ev_exact, ws->side));
+  EDK_LAUNCH(k_rlc_points, dim3(blocks), dim3(RLC_BLOCK), 0, stream, src, n, niels_a, niels_r, flags, gflags);
+  EDK_DO(hipStreamWaitEvent(stream, ws->ev_exact, 0));
+  EDK_LAUNCH(k_rlc_scalars, dim3((unsigned)(groups * (RLC_G / RLC_BLOCK))), dim3(RLC_BLOCK), 0, stream, n, ts, seed, flags, dig, bsum);
+  EDK_LAUNCH(k_rlc_group_scalar, dim3((unsigned)((groups + 63) / 64)), dim3(64), 0, stream, n, bsum, bdig);
+  EDK_LAUNCH(k_rlc_bucket, dim3((unsigned)(groups * RLC_SEGS)), dim3(RLC_BUCKETS), 0, stream, n, dig, bdig,
                      niels_a, niels_r, base16, segpts);
-  hipLaunchKernelGGL(k_rlc_final, dim3((unsigned)((4 * groups + 255) / 256)), dim3(256), 0, stream, n, segpts, gflags, gok, stats);
-  hipLaunchKernelGGL(k_rlc_verdicts, dim3(blocks), dim3(RLC_BLOCK), 0, stream, n, gok, flags, ok);
-  if ((e = hipGetLastError()) != hipSuccess) return e;
+  EDK_LAUNCH(k_rlc_final, dim3((unsigned)((4 * groups + 255) / 256)), dim3(256), 0, stream, n, segpts, gflags, gok, stats);
+  EDK_LAUNCH(k_rlc_verdicts, dim3(blocks), dim3(RLC_BLOCK), 0, stream, n, gok, flags, ok);
 
   // groups the combination did not accept: the per-item kernels decide (edk_verify_rlc_fallback).  This is the
   // one place where the host looks at a result: the caller synchronises the stream once per pass.
-  return hipMemcpyAsync(rws->host_gok, gok, groups, hipMemcpyDeviceToHost, stream);
+  EDK_DO(hipMemcpyAsync(rws->host_gok, gok, groups, hipMemcpyDeviceToHost, stream));
+  return hipSuccess;
 }
 
 // Second half, once the stream has been synchronised: runs of groups that did not pass go to the per-item kernels

@@ -121,6 +121,7 @@ int main(int argc, char **argv)
     g_mode = 1;
     bad |= run(threads, "verify / sign / x25519 / genpub by thread");
     eddsa_amd_shutdown();
+    free((void *)g_et); free((void *)g_msgs); free((void *)g_xt);
     if (bad) { fprintf(stderr, "threaded_callers: WRONG RESULTS\n"); return 1; }
     printf("threaded_callers: ok\n");
     return 0;

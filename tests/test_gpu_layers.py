@@ -209,6 +209,27 @@ def test_a_failed_hip_call_inside_a_verify_pass_surfaces_as_an_error(probe, orac
             probe.ed25519_verify_batch(sig, pk, msg)
         probe.debug_fail_hip_call(0)
         assert np.array_equal(probe.ed25519_verify_batch(sig, pk, msg), expect)
+    # the opt-in batch verification checks its calls the same way (hash tree on the side stream, combination, copy of the
+    # group verdicts): a failure anywhere in it is an error return as well
+    probe.set_rlc_min_items(0)
+    try:
+        vs, vp, vm = d(sig), d(pk), d(msg)
+        probe.debug_fail_hip_call(0)
+        ok0 = probe.ed25519_verify_batch_rlc(vs, vp, vm).cpu().numpy()
+        calls = probe.debug_hip_calls()
+        assert np.array_equal(ok0, expect) and calls >= 15
+        for nth in range(1, calls + 1, 3):
+            probe.debug_fail_hip_call(nth)
+            with pytest.raises(probe.EddsaAmdError):
+                probe.ed25519_verify_batch_rlc(vs, vp, vm)
+            torch.cuda.synchronize()
+        probe.debug_fail_hip_call(0)
+        assert np.array_equal(probe.ed25519_verify_batch_rlc(vs, vp, vm).cpu().numpy(), expect)
+    finally:
+        probe.set_rlc_min_items(3 << 17)
+    # and nothing on the clean-up paths behind those failures (waiting for what was queued, releasing the slot) failed
+    # in turn: HIP calls that have nobody to report to are counted, not ignored
+    assert probe.debug_teardown_errors() == (0, 0)
 
 
 def test_garbage_keys_fill_the_exact_path_beyond_its_slots(probe, oracle):

@@ -325,6 +325,8 @@ def test_shutdown_and_implicit_reinit(engine, golden):
     engine.shutdown()
     sig = engine.ed25519_sign_batch(sk, pk, np.zeros((1, 5), np.uint8))
     assert engine.ed25519_verify_batch(sig, pk, np.zeros((1, 5), np.uint8))[0] == 1
+    # every free / destroy / device restore of those teardowns succeeded (they are counted, not ignored)
+    assert engine.debug_teardown_errors() == (0, 0)
 
 
 def test_empty_batches(engine):

@@ -1,0 +1,120 @@
+"""The product's HOST side - libeddsa_amd/csrc/eddsa_amd.c + host_pipe.c, unchanged - on the CPU under sanitizers, with
+MORE THAN ONE device.  tests/fake_hip/ is a fake HIP runtime on host memory (2, 3 or 8
+"devices", every pointer tagged with the device that owns it), CPU launchers that call the -DED_HOST_CHECK build of the
+device source, and a fake RCCL that executes the grouped collectives of one process and checks the call pattern (every
+rank takes part, buffers and streams on the communicator's device, the in-place rule sendbuff == recvbuff + rank * count).
+Test binaries only: nothing here is linked into, or loaded by, the product.
+
+Run under -fsanitize=thread and -fsanitize=address,undefined:
+  tests/c/multi_device.c      eddsa_amd_init_devices, the *_multi host-pointer forms (a host thread per device) and
+                              ed25519_verify_batch_multi_dev over 2, 3 and 8 devices - equal shards (one grouped in-place
+                              all-gather) and 2^k - 3 items (unequal shards: one broadcast per shard) - every device's
+                              gathered vector equal to the single-device verdicts
+  tests/c/threaded_callers.c  64 threads looping over the eddsa.h single-item functions: the flat combiner
+  tests/c/host_side_stress.c  multi-chunk pipelines with ragged messages, the fault hooks, the trace switched on and off
+                              under load, two concurrent shutdowns beside callers, nothing leaked
+This is the only multi-device evidence obtainable without a multi-GPU node; it says nothing about stream ordering on real
+hardware (the fake completes every operation at once)."""
+import hashlib
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE = os.path.join(ROOT, "tests", "fake_hip")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def golden_msg(i):
+    out, c = b"", 0
+    while len(out) < i:
+        out += hashlib.sha512(b"libeddsa-amd golden msg" + i.to_bytes(4, "little") + c.to_bytes(4, "little")).digest()
+        c += 1
+    return out[:i]
+
+
+@pytest.fixture(scope="module")
+def msgs(tmp_path_factory):
+    p = tmp_path_factory.mktemp("fake") / "msgs.bin"
+    p.write_bytes(b"".join(golden_msg(i) for i in range(1024)))
+    return str(p)
+
+
+@pytest.fixture(scope="module", params=["thread", "address"])
+def build(request):
+    if not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("the HIP headers (types only) are needed to compile the host side")
+    san = request.param
+    r = subprocess.run(["make", "-C", FAKE, "-j4", "SAN=" + san], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = os.path.join(FAKE, "_build", san)
+    for exe in ("multi_device", "threaded_callers", "host_side_stress"):
+        # test binaries against the fake runtime: they must not pull in the real one
+        ldd = subprocess.check_output(["ldd", os.path.join(out, exe)], text=True)
+        assert "libamdhip64" not in ldd and "libfakehip.so" in ldd, ldd
+    return san, out
+
+
+def run(out, exe, args, devices, timeout=900):
+    env = dict(os.environ, FAKE_HIP_DEVICES=str(devices), LD_LIBRARY_PATH=out,
+               TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=1:abort_on_error=0",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([os.path.join(out, exe)] + [str(a) for a in args], env=env, capture_output=True, text=True, timeout=timeout)
+    text = r.stdout + r.stderr
+    assert r.returncode == 0, text[-4000:]
+    assert "Sanitizer" not in text and "runtime error" not in text, text[-4000:]
+    return text
+
+
+@pytest.mark.parametrize("devices", [2, 3, 8])
+def test_multi_device_entry_points_over_several_devices(build, msgs, devices):
+    san, out = build
+    # 96 table entries (messages of 0 .. 95 bytes), unequal shards from 2^8 - 3 items
+    text = run(out, "multi_device", [os.path.join(GOLD, "ed25519_table.bin"), msgs, 96, 253], devices)
+    assert f"multi_device: ok ({devices} devices" in text
+    assert f"fake RCCL ran 1 all-gather and {devices} broadcasts over {devices} ranks" in text   # both forms of the gather ran
+
+
+def test_threaded_callers_through_the_combiner(build, msgs):
+    san, out = build
+    text = run(out, "threaded_callers", [os.path.join(GOLD, "ed25519_table.bin"), msgs, os.path.join(GOLD, "x25519_table.bin"),
+                                         64, 6, 48, "trace"], 2)
+    assert "threaded_callers: ok" in text and " 0 wrong" in text
+    import re
+    launches, calls = map(int, re.findall(r"(\d+) launches carried (\d+) calls so far", text)[-1])
+    assert calls > 2 * launches                                   # the calls did meet: the merging code ran
+
+
+@pytest.mark.parametrize("threads", [4, 16])
+def test_host_pipeline_faults_trace_and_concurrent_shutdown(build, msgs, threads):
+    san, out = build
+    text = run(out, "host_side_stress", [os.path.join(GOLD, "ed25519_table.bin"), msgs, os.path.join(GOLD, "x25519_table.bin"),
+                                         threads, 4], 2)
+    assert "host_side_stress: ok" in text and "nothing left allocated in the fake runtime" in text
+
+
+def test_the_fake_runtime_catches_a_buffer_on_the_wrong_device(build, tmp_path):
+    """the checker checks: a device-pointer call whose input shard lives on another device than its output aborts"""
+    san, out = build
+    src = tmp_path / "wrong_device.c"
+    src.write_text(r'''
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include "eddsa_amd.h"
+int main(void) {
+    uint8_t *out = 0, *sc = 0, *pt = 0;
+    hipSetDevice(0); hipMalloc((void **)&out, 32 * 4); hipMalloc((void **)&sc, 32 * 4);
+    hipSetDevice(1); hipMalloc((void **)&pt, 32 * 4);          /* the points live on device 1, the call runs on device 0 */
+    hipSetDevice(0);
+    return x25519_batch_dev(out, sc, pt, 4, 0) == 0 ? 0 : 3;
+}
+''')
+    exe = tmp_path / "wrong_device"
+    flags = ["-fsanitize=thread"] if san == "thread" else ["-fsanitize=address,undefined"]
+    objs = [os.path.join(out, o) for o in ("eddsa_amd.o", "host_pipe.o", "fake_kernels.o")]
+    subprocess.check_call(["g++"] + flags + ["-x", "c", "-std=c11", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", str(src),
+                                             "-x", "none"] + objs + ["-o", str(exe), "-L" + out, "-lfakehip", "-Wl,-rpath," + out, "-lpthread", "-ldl"])
+    r = subprocess.run([str(exe)], env=dict(os.environ, FAKE_HIP_DEVICES="2", LD_LIBRARY_PATH=out), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "expected device 0" in r.stderr, r.stdout + r.stderr
