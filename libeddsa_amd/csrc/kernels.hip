@@ -196,8 +196,11 @@ k_verify_prepare(edk_verify_src src, size_t n, uint32_t* digits,
 // whole chip, the short four-lane chain, no displacement.  Cost of the exact path on config 2: 0.94 ms in
 // round 1, 0.4 ms in round 2, 0.05 ms now (profiles/r04_small_grid.txt has what it costs passes of one or two rounds).
 // The work list may be as long as the pass (a caller can send nothing but garbage keys: ed_import never fails, ed.c:100-149):
-// at most EDK_EXACT_SLOTS items are in flight - 4096 waves of 16, one scratchpad slot each - and a longer list is walked
-// in strides of the grid.  (Until round 4 the entries beyond 65536 went to a one-lane kernel that spilled 518 registers.)
+// a launch takes EDK_EXACT_SLOTS entries - 4096 waves of 16 items, one scratchpad slot each - and edk_verify queues one
+// launch per stretch of that length the pass could fill, one after the other on the side stream; those that find their
+// stretch empty end at once.  (Until round 4 the entries beyond 65536 went to a one-lane kernel that spilled 518
+// registers; a loop over the stretches inside this kernel spilled 40-90 of its 128: the compiler keeps the chain's loop
+// invariants live across the next round's set-up.)
 constexpr int QUAD_BLOCK = 256;                  // k_verify_main_quad
 constexpr int QUAD_CHAIN_BLOCK = 64;             // k_verify_exact_quad: one wave, up to 16 items
 constexpr int QUAD_CHAIN_ITEMS = QUAD_CHAIN_BLOCK / 4;
@@ -214,31 +217,29 @@ static_assert(EDK_EXACT_SLOTS % QUAD_CHAIN_ITEMS == 0, "whole waves");
 // live in LDS (33 words per item), the addends in the HBM scratchpad, one slot per quad of the grid.
 __global__ void __launch_bounds__(QUAD_CHAIN_BLOCK, 2)
 k_verify_exact_quad(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const uint32_t* digits, const uint32_t* table,
-                    const uint32_t* offlist, const uint32_t* offcount, const uint32_t* base16, uint32_t* pad) {
+                    const uint32_t* offlist, const uint32_t* offcount, const uint32_t* base16, uint32_t* pad, size_t first) {
   __shared__ uint32_t lds_dig[QUAD_CHAIN_ITEMS * QUAD_DIGIT_WORDS];
   __builtin_amdgcn_s_setprio(3);                 // small passes wait for the chain: 1-3 % there; no difference beside a full k_verify_main
-  const size_t count = *offcount;
+  // this launch's stretch of the work list: entries first .. first + EDK_EXACT_SLOTS - 1 (edk_verify launches one kernel per
+  // stretch the pass could fill; all but the first find nothing to do unless the caller sent thousands of garbage keys)
+  const size_t listed = *offcount;
+  if (listed <= first) return;
+  const size_t count = listed - first < (size_t)EDK_EXACT_SLOTS ? listed - first : (size_t)EDK_EXACT_SLOTS;
   size_t per = (count + QUAD_SPREAD_WAVES - 1) / QUAD_SPREAD_WAVES;               // items per wave: 1 .. 16
   per = per > (size_t)QUAD_CHAIN_ITEMS ? (size_t)QUAD_CHAIN_ITEMS : per;
   const size_t quad = threadIdx.x >> 2;          // quads are all-or-nothing
-  if (quad >= per) return;
+  const size_t g = (size_t)blockIdx.x * per + quad;
+  if (quad >= per || g >= count) return;
   const int q = (int)(threadIdx.x & 3u);
-  uint32_t* item = pad + ((size_t)blockIdx.x * QUAD_CHAIN_ITEMS + quad) * QUAD_ITEM_WORDS;   // this quad's slot
+  const size_t i = offlist[first + g];
+  uint32_t* item = pad + g * QUAD_ITEM_WORDS;
   uint32_t* dig = lds_dig + quad * QUAD_DIGIT_WORDS;
-  // rounds are uniform over the wave (its quads meet at the barriers): a quad whose entry lies beyond the end of the list
-  // redoes the last entry into its own slot and keeps the verdict to itself
-  for (size_t base = (size_t)blockIdx.x * per; base < count; base += (size_t)gridDim.x * per) {
-    const size_t g = base + quad;
-    const bool live = g < count;
-    const size_t i = offlist[live ? g : count - 1];
-    verify_exact_setup_quad(digits + 16 * i, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16 + TABLE_ENTRY_WORDS, item, dig, q);
-    __syncthreads();                             // one wave: orders the quad's stores (LDS digits, HBM addends) before the other lanes' loads
-    uint32_t rw[8];
-    load32(rw, sigs, i, sig_stride);
-    const bool same = verify_exact_chain_quad(rw, item, dig, q);
-    if (live && q == 1) ok[i] = (uint8_t)same;
-    __syncthreads();                             // ... and this round's loads before the next round's stores
-  }
+  verify_exact_setup_quad(digits + 16 * i, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16 + TABLE_ENTRY_WORDS, item, dig, q);
+  __syncthreads();                               // one wave: orders the quad's stores (LDS digits, HBM addends) before the other lanes' loads
+  uint32_t rw[8];
+  load32(rw, sigs, i, sig_stride);
+  const bool same = verify_exact_chain_quad(rw, item, dig, q);
+  if (q == 1) ok[i] = (uint8_t)same;
 }
 
 __global__ void __launch_bounds__(BLOCK, 4)
@@ -1165,12 +1166,14 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   if (bulk_done && bulk_early) EDK_DO(hipEventRecord(bulk_done, stream));   // the next pass may start beside this one's main kernel
   // the exact path depends only on what came before: it runs beside the main kernel on the side stream
   if (ws->exact_offcurve) {
-    const size_t qi = n < (size_t)EDK_EXACT_SLOTS ? n : (size_t)EDK_EXACT_SLOTS;
     EDK_DO(hipEventRecord(ws->ev_prepared, stream));
     EDK_DO(hipStreamWaitEvent(ws->side, ws->ev_prepared, 0));
-    const size_t dense = (qi + QUAD_CHAIN_ITEMS - 1) / QUAD_CHAIN_ITEMS, spread = qi < (size_t)QUAD_SPREAD_WAVES ? qi : (size_t)QUAD_SPREAD_WAVES;
-    EDK_LAUNCH(k_verify_exact_quad, dim3((unsigned)(dense > spread ? dense : spread)), dim3(QUAD_CHAIN_BLOCK), 0, ws->side, ok,
-               src.sigs, src.sig_stride, ws->digits, ws->table, ws->offlist, ws->offcount, base16, ws->exact_pad);
+    for (size_t first = 0; first < n; first += (size_t)EDK_EXACT_SLOTS) {
+      const size_t qi = n - first < (size_t)EDK_EXACT_SLOTS ? n - first : (size_t)EDK_EXACT_SLOTS;
+      const size_t dense = (qi + QUAD_CHAIN_ITEMS - 1) / QUAD_CHAIN_ITEMS, spread = qi < (size_t)QUAD_SPREAD_WAVES ? qi : (size_t)QUAD_SPREAD_WAVES;
+      EDK_LAUNCH(k_verify_exact_quad, dim3((unsigned)(dense > spread ? dense : spread)), dim3(QUAD_CHAIN_BLOCK), 0, ws->side, ok,
+                 src.sigs, src.sig_stride, ws->digits, ws->table, ws->offlist, ws->offcount, base16, ws->exact_pad, first);
+    }
     EDK_DO(hipEventRecord(ws->ev_exact, ws->side));
   }
   if (half_quad && n <= EDK_SUMS_MAX_ITEMS) {
