@@ -540,6 +540,16 @@ constexpr int POINT_BLOCK = COMB_IMG_WORDS * 4 > 80 * 1024 ? 512 : 256;   // 8 w
 // then wave 2 to wave 0, which delivers.  The shares are secrets (partial sums of a secret multiple): the slots are
 // zeroed once read.
 constexpr int POINT_SPLIT = 4, POINT_SPLIT_ITEMS = 64;
+// The blocks of a pass that fills the chip are PERSISTENT: one block per CU stages the 99 KB image once and then takes
+// tile after tile (stride = the grid).  With a block per tile every block began by staging the image alone on its CU -
+// twelve dependent rounds of 8 KB loads, 20-30 us of a tile's 290 us in which the CU issued nothing: the "idle 10 %" of
+// k_sign_point's VALU-busy 0.90.  A tile = the lanes of one block (64 items of a four-wave PARTS = 4 block).
+#ifndef POINT_PERSISTENT
+#define POINT_PERSISTENT 1
+#endif
+constexpr unsigned POINT_MAX_BLOCKS = 256u * (512 / (COMB_IMG_WORDS * 4 > 80 * 1024 ? 512 : 256));   // as many as are resident at once
+#define POINT_TILES(tile) \
+  _Pragma("unroll 1") for (size_t tile = blockIdx.x; tile * (PARTS == 1 ? (size_t)blockDim.x : (size_t)POINT_SPLIT_ITEMS) < n; tile += gridDim.x)
 ED_DEV void share_store(uint32_t* slot, const ge& p) {
 #pragma unroll
   for (int j = 0; j < 10; j++) {
@@ -576,13 +586,15 @@ k_genpub_point(uint32_t* accout, const uint8_t* secs, size_t n, const uint32_t* 
   __shared__ uint32_t lds_shares[PARTS == 1 ? 1 : 2 * 40 * 64];
   // blocks of POINT_BLOCK lanes, or smaller ones for small passes (EDK_POINT_GRID); PARTS = 4: four waves, 64 items
   const int part = PARTS == 1 ? 0 : (int)(threadIdx.x >> 6);
-  const size_t i = PARTS == 1 ? (size_t)blockIdx.x * blockDim.x + threadIdx.x : (size_t)blockIdx.x * POINT_SPLIT_ITEMS + (threadIdx.x & 63u);
-  uint32_t sk[8];
-  load32(sk, secs, i < n ? i : n - 1, 32);
-  ge A;
-  genpub_point_lane<PARTS>(A, sk, lds_comb, part);
-  if (PARTS > 1) point_reduce4(A, lds_shares, part);
-  if (PARTS == 1 || (part == 0 && i < n)) acc_store(accout, i, A);
+  POINT_TILES(tile) {
+    const size_t i = PARTS == 1 ? tile * blockDim.x + threadIdx.x : tile * POINT_SPLIT_ITEMS + (threadIdx.x & 63u);
+    uint32_t sk[8];
+    load32(sk, secs, i < n ? i : n - 1, 32);
+    ge A;
+    genpub_point_lane<PARTS>(A, sk, lds_comb, part);
+    if (PARTS > 1) point_reduce4(A, lds_shares, part);
+    if (PARTS == 1 || (part == 0 && i < n)) acc_store(accout, i, A);
+  }
 }
 
 // Z of a comb result is never 0 (B and its multiples are curve points)
@@ -619,20 +631,27 @@ k_sign_point(uint32_t* accout, uint32_t* aux, const uint8_t* secs, const uint8_t
   __shared__ uint32_t lds_shares[PARTS == 1 ? 1 : 2 * 40 * 64];
   // blocks of POINT_BLOCK lanes, or smaller ones for small passes (EDK_POINT_GRID); PARTS = 4: four waves, 64 items
   const int part = PARTS == 1 ? 0 : (int)(threadIdx.x >> 6);
-  const size_t i = PARTS == 1 ? (size_t)blockIdx.x * blockDim.x + threadIdx.x : (size_t)blockIdx.x * POINT_SPLIT_ITEMS + (threadIdx.x & 63u);
-  const size_t item = i < n ? i : n - 1;
-  const uint8_t* m; size_t mlen;
-  msg_span(m, mlen, msgs, msg_off, msg_len, item);
-  uint32_t sk[8], aw[8], rw[8];
-  load32(sk, secs, item, 32);
-  ge R;
-  sign_point_lane<PARTS>(R, aw, rw, sk, m, mlen, lds_comb, part);
-  if (PARTS > 1) point_reduce4(R, lds_shares, part);
-  if (PARTS == 1 || (part == 0 && i < n)) acc_store(accout, i, R);
-  if (i >= n || part != 0) return;               // an idle lane must not leave a copy of the last item's secrets
-  uint4* d = reinterpret_cast<uint4*>(aux + 16 * i);     // the secret scalars a and r, for the finish step
-  d[0] = make_uint4(aw[0], aw[1], aw[2], aw[3]); d[1] = make_uint4(aw[4], aw[5], aw[6], aw[7]);
-  d[2] = make_uint4(rw[0], rw[1], rw[2], rw[3]); d[3] = make_uint4(rw[4], rw[5], rw[6], rw[7]);
+  POINT_TILES(tile) {
+    const size_t i = PARTS == 1 ? tile * blockDim.x + threadIdx.x : tile * POINT_SPLIT_ITEMS + (threadIdx.x & 63u);
+    const size_t item = i < n ? i : n - 1;
+    const uint8_t* m; size_t mlen;
+    msg_span(m, mlen, msgs, msg_off, msg_len, item);
+    uint32_t sk[8], aw[8], rw[8];
+    load32(sk, secs, item, 32);
+    sign_scalars_lane(aw, rw, sk, m, mlen);
+    // the secret scalars a and r, for the finish step: handed over BEFORE the comb (sixteen registers less to hold across
+    // its 44 additions, which is what lets a row's two lookups be issued ahead of its two additions without a spill).
+    // An idle lane must not leave a copy of the last item's secrets.
+    if (i < n && part == 0) {
+      uint4* d = reinterpret_cast<uint4*>(aux + 16 * i);
+      d[0] = make_uint4(aw[0], aw[1], aw[2], aw[3]); d[1] = make_uint4(aw[4], aw[5], aw[6], aw[7]);
+      d[2] = make_uint4(rw[0], rw[1], rw[2], rw[3]); d[3] = make_uint4(rw[4], rw[5], rw[6], rw[7]);
+    }
+    ge R;
+    scale_base_lane<PARTS>(R, rw, lds_comb, part);
+    if (PARTS > 1) point_reduce4(R, lds_shares, part);
+    if (PARTS == 1 || (part == 0 && i < n)) acc_store(accout, i, R);
+  }
 }
 
 struct sign_finish_policy {
@@ -683,15 +702,17 @@ k_x25519_base_point(uint32_t* accout, const uint8_t* scalars, size_t n, const ui
   __shared__ uint32_t lds_shares[PARTS == 1 ? 1 : 2 * 40 * 64];
   // blocks of POINT_BLOCK lanes, or smaller ones for small passes (EDK_POINT_GRID); PARTS = 4: four waves, 64 items
   const int part = PARTS == 1 ? 0 : (int)(threadIdx.x >> 6);
-  const size_t i = PARTS == 1 ? (size_t)blockIdx.x * blockDim.x + threadIdx.x : (size_t)blockIdx.x * POINT_SPLIT_ITEMS + (threadIdx.x & 63u);
-  uint32_t s[8];
-  load32(s, scalars, i < n ? i : n - 1, 32);
-  ge R;
-  x25519_base_point_lane<PARTS>(R, s, lds_comb, part);
-  if (PARTS > 1) point_reduce4(R, lds_shares, part);
-  fe_add(R.X, R.Z, R.Y);                         // the finish step needs z + y, not x
-  fe_carry(R.X);
-  if (PARTS == 1 || (part == 0 && i < n)) acc_store(accout, i, R);
+  POINT_TILES(tile) {
+    const size_t i = PARTS == 1 ? tile * blockDim.x + threadIdx.x : tile * POINT_SPLIT_ITEMS + (threadIdx.x & 63u);
+    uint32_t s[8];
+    load32(s, scalars, i < n ? i : n - 1, 32);
+    ge R;
+    x25519_base_point_lane<PARTS>(R, s, lds_comb, part);
+    if (PARTS > 1) point_reduce4(R, lds_shares, part);
+    fe_add(R.X, R.Z, R.Y);                       // the finish step needs z + y, not x
+    fe_carry(R.X);
+    if (PARTS == 1 || (part == 0 && i < n)) acc_store(accout, i, R);
+  }
 }
 
 // u = (z + y) / (z - y); z = y gives 0 in the reference (fld_inv(0) = 0, x25519.c:192): such an
@@ -1282,7 +1303,8 @@ hipError_t edk_debug_layer(int op, int form, uint8_t* out, size_t out_w, const u
 // the same item: 0.23 ms in the point kernel against 0.12 with a wave to itself), and 4096 items occupied 8 CUs of 256.
 // So: the smallest block that covers the pass with one block per CU - one, two or four waves, each with a SIMD to itself.
 #define POINT_LANES(n) ((n) <= (size_t)64 * 256 ? 64 : (n) <= (size_t)128 * 256 ? 128 : (n) <= (size_t)256 * 256 ? 256 : POINT_BLOCK)
-#define EDK_POINT_GRID(n) dim3((unsigned)(((n) + POINT_LANES(n) - 1) / POINT_LANES(n))), dim3(POINT_LANES(n)), 0, stream
+#define POINT_GRID_BLOCKS(n) ((unsigned)(((n) + POINT_LANES(n) - 1) / POINT_LANES(n)))
+#define EDK_POINT_GRID(n) dim3(POINT_PERSISTENT && POINT_GRID_BLOCKS(n) > POINT_MAX_BLOCKS ? POINT_MAX_BLOCKS : POINT_GRID_BLOCKS(n)), dim3(POINT_LANES(n)), 0, stream
 // Passes of up to POINT_SPLIT_MAX_N items spend four lanes on an item (lanes.h: scale_base_lane<4>, k_genpub_point above): the 44 additions of
 // the comb in a row were the latency of the pass (a single ed25519_sign: 0.17 ms in k_sign_point, now 0.09).
 constexpr size_t POINT_SPLIT_MAX_N = (size_t)1 << 14;

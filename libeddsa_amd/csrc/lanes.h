@@ -910,11 +910,23 @@ ED_DEV void scale_base_lane(ge& out, const uint32_t xw[8], const uint32_t* comb,
       for (int k = 0; k < 8; k++) y[k] = (y[k] >> (2 * COMB_W)) | (y[k + 1] << (32 - 2 * COMB_W));
       y[8] >>= 2 * COMB_W;
     }
+#ifndef COMB_LOOKUP_LATE
+    // both lookups of the row are issued ahead of its two additions: the second one's 30 shuffles and their latency run on
+    // the LDS pipe beside the first addition's multiplications instead of between the two additions (fe_mul ends in a
+    // scheduling barrier, so the compiler does not move them there by itself).  Measured, profiles/r04_sign_ab.txt:
+    // sign 434 -> 444 M/s; thirty more registers (253 of 256: the secret scalars leave for the workspace before the comb).
+    ge_niels e, e2;
+    comb_select(e, comb, valid ? row : 0, valid ? two & ((1u << COMB_W) - 1u) : (uint32_t)COMB_HALF);
+    comb_select(e2, comb, valid ? row : 0, valid ? two >> COMB_W : (uint32_t)COMB_HALF);
+    if (i == 0) ge_from_niels(r0, e); else ge_add_niels(r0, r0, e, true);      // (the first entry IS the sum so far: one multiplication instead of seven)
+    if (i == 0) ge_from_niels(r1, e2); else ge_add_niels(r1, r1, e2, true);
+#else                    /* the A/B build: each lookup right before its addition */
     ge_niels e;
     comb_select(e, comb, valid ? row : 0, valid ? two & ((1u << COMB_W) - 1u) : (uint32_t)COMB_HALF);
-    if (i == 0) ge_from_niels(r0, e); else ge_add_niels(r0, r0, e, true);      // (the first entry IS the sum so far: one multiplication instead of seven)
+    if (i == 0) ge_from_niels(r0, e); else ge_add_niels(r0, r0, e, true);
     comb_select(e, comb, valid ? row : 0, valid ? two >> COMB_W : (uint32_t)COMB_HALF);
     if (i == 0) ge_from_niels(r1, e); else ge_add_niels(r1, r1, e, true);
+#endif
   }
 #pragma unroll 1
   for (int k = 0; k < COMB_W; k++) ge_dbl(r1, r1, k == COMB_W - 1);
@@ -954,11 +966,9 @@ ED_DEV void genpub_point_lane(ge& A, const uint32_t sk[8], const uint32_t* comb,
   scale_base_lane<PARTS>(A, aw, comb, part);
 }
 
-// ed25519-sha512.c:84-110 sign, up to R = r*B; aw, rw = the reduced scalars a and r as words
-template <int PARTS = 1>
-ED_DEV void sign_point_lane(ge& R, uint32_t aw[8], uint32_t rw[8], const uint32_t sk[8],
-                            const uint8_t* m, size_t mlen, const uint32_t* comb, int part = 0) {
-  uint32_t h[16], dig[16], rdig[8];
+// ed25519-sha512.c:84-105 sign, the secret scalars: aw = a (from the key hash) and rw = r = H(h[32..64) || M) mod l, as words
+ED_DEV void sign_scalars_lane(uint32_t aw[8], uint32_t rw[8], const uint32_t sk[8], const uint8_t* m, size_t mlen) {
+  uint32_t h[16], dig[16];
   key_setup(h, sk);
   sc a, r;
   sc_from_words<8>(a, h);
@@ -966,9 +976,14 @@ ED_DEV void sign_point_lane(ge& R, uint32_t aw[8], uint32_t rw[8], const uint32_
   sha512_prefix_msg<8>(dig, h + 8, m, mlen);     // r = H(h[32..64) || M)
   sc_from_words<16>(r, dig);
   sc_to_words(rw, r);
-#pragma unroll
-  for (int k = 0; k < 8; k++) rdig[k] = rw[k];
-  scale_base_lane<PARTS>(R, rdig, comb, part);
+}
+
+// ed25519-sha512.c:84-110 sign, up to R = r*B; aw, rw = the reduced scalars a and r as words
+template <int PARTS = 1>
+ED_DEV void sign_point_lane(ge& R, uint32_t aw[8], uint32_t rw[8], const uint32_t sk[8],
+                            const uint8_t* m, size_t mlen, const uint32_t* comb, int part = 0) {
+  sign_scalars_lane(aw, rw, sk, m, mlen);
+  scale_base_lane<PARTS>(R, rw, comb, part);
 }
 
 // ed25519-sha512.c:112-122 sign, from the encoded R on: S = r + H(R || A || M) * a, in two steps so that
