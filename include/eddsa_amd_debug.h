@@ -70,7 +70,7 @@ EDDSA_AMD_DECL int eddsa_amd_debug_layer(int op, int form, uint8_t *out, size_t 
  * lane per item whatever the size; 3: the arrangement of 24 577 .. 2^18 items at any size below 2^18. */
 EDDSA_AMD_DECL void eddsa_amd_set_verify_algo(int algo);
 /* items of the first chunk of a host-pointer call and of its later stages; 0 = the defaults (2^16 for verify, 2^17
- * otherwise, then doubling up to 2^19 for verify and 2^18 for the other operations) */
+ * otherwise, then doubling - for verify up to 2^18 with the rest of the call as the last chunk, for the other operations up to 2^18) */
 EDDSA_AMD_DECL void eddsa_amd_set_pipeline(size_t first_chunk, size_t stage_chunk);
 /* how the kernels of consecutive chunks of a host-pointer call are ordered.  -1 (default): each operation's own
  * setting; 0: side by side; 1: in chunk order; 2: in chunk order, a verify chunk starting beside the previous chunk's

@@ -850,9 +850,10 @@ static int pipe_run(const struct hjob *j, size_t n)
  * jobs
  * ---------------------------------------------------------------------------------------- */
 
-/* verify: two residencies per stage, so that the exact path's chain for off-curve keys stays hidden behind
- * the main kernel as it is in one big pass */
-#define PIPE_CHUNK_VERIFY ((size_t)1 << 19)
+/* verify: chunks of 2^16, 2^17, 2^18 items, then the rest in one (measured, tools/pipe_verify_sweep.py, 2^20 items from
+ * malloc memory, round 4: stage 2^20 98.8 M/s on the config-2 mix and 102.2 on valid signatures, stage 2^19 98.2 / 101.4):
+ * the large last chunk hides its exact chain behind a main kernel of several rounds, as one big pass does */
+#define PIPE_CHUNK_VERIFY CHUNK_MAX
 #define PIPE_FIRST_CHUNK_VERIFY ((size_t)1 << 16)   /* the first chunk of a verify call (the other operations: PIPE_FIRST_CHUNK) */
 
 #define RUN_ARGS struct engine *e, const struct hjob *j, uint8_t *d_out, uint8_t *const d_in[PIPE_MAX_IN], \

@@ -205,6 +205,10 @@ constexpr int QUAD_BLOCK = 256;                  // k_verify_main_quad
 constexpr int QUAD_CHAIN_BLOCK = 64;             // k_verify_exact_quad: one wave, up to 16 items
 constexpr int QUAD_CHAIN_ITEMS = QUAD_CHAIN_BLOCK / 4;
 constexpr int QUAD_SPREAD_WAVES = 256;           // a short work list is spread over this many waves, a long one packed 16 items to the wave
+#ifndef EXACT_DENSE_LOG2
+#define EXACT_DENSE_LOG2 16
+#endif
+constexpr size_t EXACT_DENSE_MIN_N = (size_t)1 << EXACT_DENSE_LOG2;   // passes from this size on pack the chain's items 16 to the wave whatever their number
 static_assert((size_t)EDK_EXACT_SLOTS * QUAD_ITEM_WORDS * 4 <= EDK_EXACT_PAD_BYTES, "scratchpad too small");
 static_assert(EDK_EXACT_SLOTS % QUAD_CHAIN_ITEMS == 0, "whole waves");
 
@@ -217,7 +221,7 @@ static_assert(EDK_EXACT_SLOTS % QUAD_CHAIN_ITEMS == 0, "whole waves");
 // live in LDS (33 words per item), the addends in the HBM scratchpad, one slot per quad of the grid.
 __global__ void __launch_bounds__(QUAD_CHAIN_BLOCK, 2)
 k_verify_exact_quad(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const uint32_t* digits, const uint32_t* table,
-                    const uint32_t* offlist, const uint32_t* offcount, const uint32_t* base16, uint32_t* pad, size_t first) {
+                    const uint32_t* offlist, const uint32_t* offcount, const uint32_t* base16, uint32_t* pad, size_t first, int dense) {
   __shared__ uint32_t lds_dig[QUAD_CHAIN_ITEMS * QUAD_DIGIT_WORDS];
   __builtin_amdgcn_s_setprio(3);                 // small passes wait for the chain: 1-3 % there; no difference beside a full k_verify_main
   // this launch's stretch of the work list: entries first .. first + EDK_EXACT_SLOTS - 1 (edk_verify launches one kernel per
@@ -225,7 +229,12 @@ k_verify_exact_quad(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const u
   const size_t listed = *offcount;
   if (listed <= first) return;
   const size_t count = listed - first < (size_t)EDK_EXACT_SLOTS ? listed - first : (size_t)EDK_EXACT_SLOTS;
-  size_t per = (count + QUAD_SPREAD_WAVES - 1) / QUAD_SPREAD_WAVES;               // items per wave: 1 .. 16
+  // items per wave: 16 in a pass whose main kernel outlasts the chain anyway (dense: the chain's total work is what counts
+  // there - every wave issues the chain's 300 k instructions however few items it carries, and in the host pipeline, where
+  // the chunks' kernels fill one another's gaps, 557 items spread three to the wave cost a 2^16-item chunk a quarter of its
+  // main kernel's work on top); in a small pass, which WAITS for the chain, as few as one (its wave then skips the
+  // addition of every step without digits)
+  size_t per = dense ? (size_t)QUAD_CHAIN_ITEMS : (count + QUAD_SPREAD_WAVES - 1) / QUAD_SPREAD_WAVES;
   per = per > (size_t)QUAD_CHAIN_ITEMS ? (size_t)QUAD_CHAIN_ITEMS : per;
   const size_t quad = threadIdx.x >> 2;          // quads are all-or-nothing
   const size_t g = (size_t)blockIdx.x * per + quad;
@@ -1193,7 +1202,8 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
       const size_t qi = n - first < (size_t)EDK_EXACT_SLOTS ? n - first : (size_t)EDK_EXACT_SLOTS;
       const size_t dense = (qi + QUAD_CHAIN_ITEMS - 1) / QUAD_CHAIN_ITEMS, spread = qi < (size_t)QUAD_SPREAD_WAVES ? qi : (size_t)QUAD_SPREAD_WAVES;
       EDK_LAUNCH(k_verify_exact_quad, dim3((unsigned)(dense > spread ? dense : spread)), dim3(QUAD_CHAIN_BLOCK), 0, ws->side, ok,
-                 src.sigs, src.sig_stride, ws->digits, ws->table, ws->offlist, ws->offcount, base16, ws->exact_pad, first);
+                 src.sigs, src.sig_stride, ws->digits, ws->table, ws->offlist, ws->offcount, base16, ws->exact_pad, first,
+                 (int)(n >= EXACT_DENSE_MIN_N));
     }
     EDK_DO(hipEventRecord(ws->ev_exact, ws->side));
   }
