@@ -13,3 +13,6 @@ cp $SAN tests/host_check/libhostcheck.so
 trap '[ -s $KEEP ] && cp $KEEP tests/host_check/libhostcheck.so || rm -f tests/host_check/libhostcheck.so' EXIT
 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 \
     python -m pytest tests/test_device_source_on_host.py -x -q
+# ... and the product's HOST side (eddsa_amd.c + host_pipe.c, unchanged) against the fake HIP runtime / fake RCCL of
+# tests/fake_hip/, under -fsanitize=thread and -fsanitize=address,undefined, with 2, 3 and 8 devices
+python -m pytest tests/test_host_side_sanitized.py -x -q
