@@ -158,3 +158,29 @@ def test_host_pipeline_at_chunk_boundaries(engine, oracle, n):
     assert np.array_equal(xo[lo:hi], oracle.x25519_batch(sk[lo:hi], pt[lo:hi]))
     assert np.array_equal(ok[lo:hi], oracle.verify_batch(bad[lo:hi], pk[lo:hi], msg[lo:hi], 20))
     assert np.array_equal(sig[lo:hi], oracle.sign_batch(sk[lo:hi], pk[lo:hi], msg[lo:hi], 20))
+
+
+LARGE_ROUTE_EDGES = [65535, 65536, 65537, 262143, 262144, 262145, 524287, 524288, 524289]
+
+
+@pytest.mark.parametrize("n", LARGE_ROUTE_EDGES)
+def test_large_route_boundaries_against_the_oracle(engine, oracle, n):
+    """both sides of the thresholds above the small-pass routes (kernels.hip: edk_verify) - 2^16: the exact chain packs 16
+    items to the wave; 2^18: three-lane preparation with the long loop in place -> prepare + halve + one-lane evaluation;
+    2^19: pairs up to 2^138 / 35 windows -> 2^134 / 34 - on the config-2 mix with garbage keys on top (off-curve keys and
+    items without a short pair on the exact path), EVERY verdict against the oracle, device- and host-pointer entry points"""
+    import workload
+    sk, msg = workload.sign_inputs(n, seed=77, config=2)
+    pk = engine.ed25519_genpub_batch(dev(sk))
+    sig = engine.ed25519_sign_batch(dev(sk), pk, dev(msg)).cpu().numpy()
+    pk = pk.cpu().numpy()
+    workload.corrupt_for_verify(sig, pk, msg, seed=77)
+    rng = np.random.default_rng(n)
+    g = rng.integers(0, n, n // 97)
+    pk[g] = rng.integers(0, 256, (len(g), 32), dtype=np.uint8)            # garbage keys: about half are no curve point
+    want = oracle.verify_batch(sig, pk, msg, 32)
+    assert 0.8 < want.mean() < 0.95
+    got_d = engine.ed25519_verify_batch(dev(sig), dev(pk), dev(msg), msg_len=32).cpu().numpy()
+    assert np.array_equal(got_d, want)
+    if n in (65536, 262145, 524288):
+        assert np.array_equal(engine.ed25519_verify_batch(sig, pk, msg, msg_len=32), want)      # the host pipeline's chunks of the same batch
