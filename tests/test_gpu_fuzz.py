@@ -184,3 +184,35 @@ def test_large_route_boundaries_against_the_oracle(engine, oracle, n):
     assert np.array_equal(got_d, want)
     if n in (65536, 262145, 524288):
         assert np.array_equal(engine.ed25519_verify_batch(sig, pk, msg, msg_len=32), want)      # the host pipeline's chunks of the same batch
+
+
+@pytest.mark.parametrize("n,garbage_every", [(200000, 50), (400000, 2), (1 << 20, 3)])
+def test_host_calls_of_several_chunks_with_garbage_keys(engine, oracle, n, garbage_every):
+    """host_pipe.c: multi-chunk verify calls (packed arrays, records, ragged messages with rebased offset tables) whose chunks
+    each carry exact work - few garbage keys, and so many that a chunk's work list passes the 65 536 entries one launch of the
+    chain takes: every verdict against the oracle and against the device-pointer entry point"""
+    import workload
+    sk, msg = workload.sign_inputs(n, seed=78, config=2)
+    pk = engine.ed25519_genpub_batch(dev(sk))
+    sig = engine.ed25519_sign_batch(dev(sk), pk, dev(msg)).cpu().numpy()
+    pk = pk.cpu().numpy()
+    rng = np.random.default_rng(n + garbage_every)
+    g = np.arange(0, n, garbage_every)
+    pk[g] = rng.integers(0, 256, (len(g), 32), dtype=np.uint8)
+    sig[5::11, 3] ^= 2
+    want = oracle.verify_batch(sig, pk, msg, 32)
+    got_h = engine.ed25519_verify_batch(sig, pk, msg, msg_len=32)
+    assert np.array_equal(got_h, want)
+    assert np.array_equal(engine.ed25519_verify_batch(dev(sig), dev(pk), dev(msg), msg_len=32).cpu().numpy(), want)
+    rec = np.concatenate([sig, pk, msg], axis=1)                          # the record form shares the pipeline
+    assert np.array_equal(engine.ed25519_verify_records(rec, 0, 64, 96, 32), want)
+    # ragged messages (chunk offset tables rebased) with the same keys
+    lens = rng.integers(0, 40, n)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    blob = rng.integers(0, 256, int(off[-1]), dtype=np.uint8)
+    sig_r = engine.ed25519_sign_batch(dev(sk), dev(pk), dev(blob), msg_off=dev(off.astype(np.int64))).cpu().numpy()
+    got_r = engine.ed25519_verify_batch(sig_r, pk, blob, msg_off=off)
+    assert np.array_equal(got_r, engine.ed25519_verify_batch(dev(sig_r), dev(pk), dev(blob), msg_off=dev(off.astype(np.int64))).cpu().numpy())
+    lo = 65536 - 50
+    for i in range(lo, lo + 100):                                         # across the first chunk boundary, against the oracle
+        assert got_r[i] == oracle.verify(sig_r[i].tobytes(), pk[i].tobytes(), blob[int(off[i]):int(off[i + 1])].tobytes()), i
