@@ -101,6 +101,7 @@ static void fws_release(struct vslot *v)
 {
     wipe_free(v->fws.acc, v->fws.capacity * ACC_WORDS * sizeof(uint32_t));
     wipe_free(v->fws.aux, v->fws.capacity * 16 * sizeof(uint32_t));
+    if (v->fws.tiles) HIP_NOTE(hipFree(v->fws.tiles));
     memset(&v->fws, 0, sizeof(v->fws));
 }
 
@@ -131,6 +132,8 @@ static int fws_reserve(struct vslot *v, size_t items, hipStream_t st)
      * with the kernels of a non-blocking stream and could land after their first stores */
     TRY(hipMemsetAsync(v->fws.acc, 0, cap * ACC_WORDS * sizeof(uint32_t), st));
     TRY(hipMemsetAsync(v->fws.aux, 0, cap * 16 * sizeof(uint32_t), st));
+    TRY(hipMalloc((void **)&v->fws.tiles, 256));
+    TRY(hipMemsetAsync(v->fws.tiles, 0, 256, st));
     v->fws.capacity = cap;
 out:
     if (rc) fws_release(v);

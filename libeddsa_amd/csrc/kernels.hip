@@ -549,16 +549,42 @@ constexpr int POINT_BLOCK = COMB_IMG_WORDS * 4 > 80 * 1024 ? 512 : 256;   // 8 w
 // then wave 2 to wave 0, which delivers.  The shares are secrets (partial sums of a secret multiple): the slots are
 // zeroed once read.
 constexpr int POINT_SPLIT = 4, POINT_SPLIT_ITEMS = 64;
-// The blocks of a pass that fills the chip are PERSISTENT: one block per CU stages the 99 KB image once and then takes
-// tile after tile (stride = the grid).  With a block per tile every block began by staging the image alone on its CU -
-// twelve dependent rounds of 8 KB loads, 20-30 us of a tile's 290 us in which the CU issued nothing: the "idle 10 %" of
-// k_sign_point's VALU-busy 0.90.  A tile = the lanes of one block (64 items of a four-wave PARTS = 4 block).
-#ifndef POINT_PERSISTENT
-#define POINT_PERSISTENT 1
+// The blocks of a pass that fills the chip are PERSISTENT - one block per CU stages the 99 KB image once - and their WAVES take
+// 64-item tiles from a counter until none is left (point_tile below).  Why not a tile per block, or a fixed share per wave:
+// the image leaves room for ONE block of eight waves per CU, two waves per SIMD, and the SIMD issues its older wave first; with
+// equal shares the older wave of every pair finished at ~60 % of the kernel's time and the younger one ran the rest alone, at
+// the issue rate of a single wave (SQ_WAVE_CYCLES: 1.52 waves resident per SIMD on average, VALU-busy 0.92 - the "idle 10 %" of
+// VERDICT r03 #8; not the staging, not LDS latency, not the instruction cache: profiles/r04_sign_ab.txt).  Handed out one by
+// one, the tiles go to whichever wave is ahead and all waves finish together.  Small passes (no more blocks than CUs, or four
+// lanes per item) keep the fixed mapping: block b takes tile b.
+#ifndef POINT_DYNAMIC
+#define POINT_DYNAMIC 1
 #endif
-constexpr unsigned POINT_MAX_BLOCKS = 256u * (512 / (COMB_IMG_WORDS * 4 > 80 * 1024 ? 512 : 256));   // as many as are resident at once
-#define POINT_TILES(tile) \
-  _Pragma("unroll 1") for (size_t tile = blockIdx.x; tile * (PARTS == 1 ? (size_t)blockDim.x : (size_t)POINT_SPLIT_ITEMS) < n; tile += gridDim.x)
+constexpr unsigned POINT_MAX_BLOCKS = 256u * (512 / POINT_BLOCK);   // as many as are resident at once
+
+// the next item of this lane, or false when the pass is done.  `it` = the lane's iteration count so far (0 at the start).
+// Dynamic hand-out: lane 0 of the wave draws a tile number, the wave takes items 64 t .. 64 t + 63; the wave that finds the
+// counter past the end reports itself done, and the last wave to do so zeroes the counter block for the next launch
+// (launches that share a workspace are ordered by its stream).
+template <int PARTS>
+ED_DEV bool point_tile(size_t& i, unsigned it, size_t n, uint32_t* tiles) {
+  if (PARTS == 1 && POINT_DYNAMIC && tiles != nullptr) {
+    unsigned t = 0;
+    if ((threadIdx.x & 63u) == 0) t = atomicAdd(tiles, 1u);
+    t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+    if ((size_t)t * 64 < n) { i = (size_t)t * 64 + (threadIdx.x & 63u); return true; }
+    if ((threadIdx.x & 63u) == 0) {
+      const unsigned waves = gridDim.x * (blockDim.x >> 6);
+      if (atomicAdd(tiles + 1, 1u) == waves - 1) { tiles[0] = 0; tiles[1] = 0; }
+    }
+    return false;
+  }
+  const size_t span = PARTS == 1 ? (size_t)blockDim.x : (size_t)POINT_SPLIT_ITEMS;
+  const size_t base = ((size_t)blockIdx.x + (size_t)it * gridDim.x) * span;
+  i = base + (PARTS == 1 ? threadIdx.x : (threadIdx.x & 63u));
+  return base < n;
+}
+
 ED_DEV void share_store(uint32_t* slot, const ge& p) {
 #pragma unroll
   for (int j = 0; j < 10; j++) {
@@ -589,14 +615,15 @@ ED_DEV void point_reduce4(ge& a, uint32_t* lds_shares, int part) {
 
 template <int PARTS>
 __global__ void __launch_bounds__(POINT_BLOCK, 512 / POINT_BLOCK)
-k_genpub_point(uint32_t* accout, const uint8_t* secs, size_t n, const uint32_t* comb) {
+k_genpub_point(uint32_t* accout, const uint8_t* secs, size_t n, const uint32_t* comb, uint32_t* tiles) {
   __shared__ alignas(16) uint32_t lds_comb[COMB_IMG_WORDS];
   stage_table(lds_comb, comb, COMB_IMG_WORDS);
   __shared__ uint32_t lds_shares[PARTS == 1 ? 1 : 2 * 40 * 64];
   // blocks of POINT_BLOCK lanes, or smaller ones for small passes (EDK_POINT_GRID); PARTS = 4: four waves, 64 items
   const int part = PARTS == 1 ? 0 : (int)(threadIdx.x >> 6);
-  POINT_TILES(tile) {
-    const size_t i = PARTS == 1 ? tile * blockDim.x + threadIdx.x : tile * POINT_SPLIT_ITEMS + (threadIdx.x & 63u);
+  size_t i;
+#pragma unroll 1
+  for (unsigned it = 0; point_tile<PARTS>(i, it, n, tiles); it++) {
     uint32_t sk[8];
     load32(sk, secs, i < n ? i : n - 1, 32);
     ge A;
@@ -634,14 +661,15 @@ k_encode_finish(uint8_t* out, uint32_t* acc, size_t n, int K) {
 template <int PARTS>
 __global__ void __launch_bounds__(POINT_BLOCK, 512 / POINT_BLOCK)
 k_sign_point(uint32_t* accout, uint32_t* aux, const uint8_t* secs, const uint8_t* msgs,
-             const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* comb) {
+             const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* comb, uint32_t* tiles) {
   __shared__ alignas(16) uint32_t lds_comb[COMB_IMG_WORDS];
   stage_table(lds_comb, comb, COMB_IMG_WORDS);
   __shared__ uint32_t lds_shares[PARTS == 1 ? 1 : 2 * 40 * 64];
   // blocks of POINT_BLOCK lanes, or smaller ones for small passes (EDK_POINT_GRID); PARTS = 4: four waves, 64 items
   const int part = PARTS == 1 ? 0 : (int)(threadIdx.x >> 6);
-  POINT_TILES(tile) {
-    const size_t i = PARTS == 1 ? tile * blockDim.x + threadIdx.x : tile * POINT_SPLIT_ITEMS + (threadIdx.x & 63u);
+  size_t i;
+#pragma unroll 1
+  for (unsigned it = 0; point_tile<PARTS>(i, it, n, tiles); it++) {
     const size_t item = i < n ? i : n - 1;
     const uint8_t* m; size_t mlen;
     msg_span(m, mlen, msgs, msg_off, msg_len, item);
@@ -705,14 +733,15 @@ k_sign_finish(uint8_t* sigs, uint32_t* acc, uint32_t* aux, const uint8_t* pubs, 
 
 template <int PARTS>
 __global__ void __launch_bounds__(POINT_BLOCK, 512 / POINT_BLOCK)
-k_x25519_base_point(uint32_t* accout, const uint8_t* scalars, size_t n, const uint32_t* comb) {
+k_x25519_base_point(uint32_t* accout, const uint8_t* scalars, size_t n, const uint32_t* comb, uint32_t* tiles) {
   __shared__ alignas(16) uint32_t lds_comb[COMB_IMG_WORDS];
   stage_table(lds_comb, comb, COMB_IMG_WORDS);
   __shared__ uint32_t lds_shares[PARTS == 1 ? 1 : 2 * 40 * 64];
   // blocks of POINT_BLOCK lanes, or smaller ones for small passes (EDK_POINT_GRID); PARTS = 4: four waves, 64 items
   const int part = PARTS == 1 ? 0 : (int)(threadIdx.x >> 6);
-  POINT_TILES(tile) {
-    const size_t i = PARTS == 1 ? tile * blockDim.x + threadIdx.x : tile * POINT_SPLIT_ITEMS + (threadIdx.x & 63u);
+  size_t i;
+#pragma unroll 1
+  for (unsigned it = 0; point_tile<PARTS>(i, it, n, tiles); it++) {
     uint32_t s[8];
     load32(s, scalars, i < n ? i : n - 1, 32);
     ge R;
@@ -1314,14 +1343,16 @@ hipError_t edk_debug_layer(int op, int form, uint8_t* out, size_t out_w, const u
 // So: the smallest block that covers the pass with one block per CU - one, two or four waves, each with a SIMD to itself.
 #define POINT_LANES(n) ((n) <= (size_t)64 * 256 ? 64 : (n) <= (size_t)128 * 256 ? 128 : (n) <= (size_t)256 * 256 ? 256 : POINT_BLOCK)
 #define POINT_GRID_BLOCKS(n) ((unsigned)(((n) + POINT_LANES(n) - 1) / POINT_LANES(n)))
-#define EDK_POINT_GRID(n) dim3(POINT_PERSISTENT && POINT_GRID_BLOCKS(n) > POINT_MAX_BLOCKS ? POINT_MAX_BLOCKS : POINT_GRID_BLOCKS(n)), dim3(POINT_LANES(n)), 0, stream
 // Passes of up to POINT_SPLIT_MAX_N items spend four lanes on an item (lanes.h: scale_base_lane<4>, k_genpub_point above): the 44 additions of
-// the comb in a row were the latency of the pass (a single ed25519_sign: 0.17 ms in k_sign_point, now 0.09).
+// the comb in a row were the latency of the pass (a single ed25519_sign: 0.17 ms in k_sign_point, now 0.09).  A pass with more
+// tiles than CUs runs POINT_MAX_BLOCKS persistent blocks whose waves draw their tiles from ws->tiles (point_tile above); a smaller
+// one a block per tile, without the counter.
 constexpr size_t POINT_SPLIT_MAX_N = (size_t)1 << 14;
 #define EDK_POINT_LAUNCH(kernel, n, ...) do { \
     if ((n) <= POINT_SPLIT_MAX_N) hipLaunchKernelGGL((kernel<POINT_SPLIT>), dim3((unsigned)(((n) + POINT_SPLIT_ITEMS - 1) / POINT_SPLIT_ITEMS)), \
-                                                     dim3(POINT_SPLIT * 64), 0, stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL((kernel<1>), EDK_POINT_GRID(n), __VA_ARGS__); } while (0)
+                                                     dim3(POINT_SPLIT * 64), 0, stream, __VA_ARGS__, (uint32_t*)nullptr); \
+    else if (POINT_GRID_BLOCKS(n) > POINT_MAX_BLOCKS) hipLaunchKernelGGL((kernel<1>), dim3(POINT_MAX_BLOCKS), dim3(POINT_LANES(n)), 0, stream, __VA_ARGS__, ws->tiles); \
+    else hipLaunchKernelGGL((kernel<1>), dim3(POINT_GRID_BLOCKS(n)), dim3(POINT_LANES(n)), 0, stream, __VA_ARGS__, (uint32_t*)nullptr); } while (0)
 #define EDK_FINISH_GRID(n) dim3((unsigned)((((n) + BLOCK - 1) / BLOCK + finish_k(n) - 1) / finish_k(n))), dim3(BLOCK), 0, stream
 
 hipError_t edk_genpub(uint8_t* pubs, const uint8_t* secs, size_t n, const uint32_t* comb,
