@@ -77,8 +77,8 @@ typedef struct edk_fixed_ws {
   size_t capacity;
   uint32_t* acc;      /* capacity * ACC_WORDS words: projective result, lane-interleaved per tile */
   uint32_t* aux;      /* capacity * 16 words: sign's secret scalars a, r between its two kernels (zeroed after use) */
-  uint32_t* tiles;    /* 64 words, zero between launches: [0] the next tile a wave of a persistent point kernel takes, [1] waves that are
-                         done (the last one zeroes both): kernels.hip, point_tile */
+  uint32_t* tiles;    /* 64 words; [0] the next 64-item tile a wave of a persistent point kernel takes (zeroed by the launcher before
+                         every such launch): kernels.hip, point_tile */
 } edk_fixed_ws;
 
 /* workspace of the batch (random-linear-combination) verification for up to `capacity` items: one

@@ -563,9 +563,8 @@ constexpr int POINT_SPLIT = 4, POINT_SPLIT_ITEMS = 64;
 constexpr unsigned POINT_MAX_BLOCKS = 256u * (512 / POINT_BLOCK);   // as many as are resident at once
 
 // the next item of this lane, or false when the pass is done.  `it` = the lane's iteration count so far (0 at the start).
-// Dynamic hand-out: lane 0 of the wave draws a tile number, the wave takes items 64 t .. 64 t + 63; the wave that finds the
-// counter past the end reports itself done, and the last wave to do so zeroes the counter block for the next launch
-// (launches that share a workspace are ordered by its stream).
+// Dynamic hand-out: lane 0 of the wave draws a tile number, the wave takes items 64 t .. 64 t + 63, until the counter is past
+// the end (the launcher zeroes it on the pass's stream before every such launch).
 template <int PARTS>
 ED_DEV bool point_tile(size_t& i, unsigned it, size_t n, uint32_t* tiles) {
   if (PARTS == 1 && POINT_DYNAMIC && tiles != nullptr) {
@@ -573,10 +572,6 @@ ED_DEV bool point_tile(size_t& i, unsigned it, size_t n, uint32_t* tiles) {
     if ((threadIdx.x & 63u) == 0) t = atomicAdd(tiles, 1u);
     t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
     if ((size_t)t * 64 < n) { i = (size_t)t * 64 + (threadIdx.x & 63u); return true; }
-    if ((threadIdx.x & 63u) == 0) {
-      const unsigned waves = gridDim.x * (blockDim.x >> 6);
-      if (atomicAdd(tiles + 1, 1u) == waves - 1) { tiles[0] = 0; tiles[1] = 0; }
-    }
     return false;
   }
   const size_t span = PARTS == 1 ? (size_t)blockDim.x : (size_t)POINT_SPLIT_ITEMS;
@@ -1351,7 +1346,9 @@ constexpr size_t POINT_SPLIT_MAX_N = (size_t)1 << 14;
 #define EDK_POINT_LAUNCH(kernel, n, ...) do { \
     if ((n) <= POINT_SPLIT_MAX_N) hipLaunchKernelGGL((kernel<POINT_SPLIT>), dim3((unsigned)(((n) + POINT_SPLIT_ITEMS - 1) / POINT_SPLIT_ITEMS)), \
                                                      dim3(POINT_SPLIT * 64), 0, stream, __VA_ARGS__, (uint32_t*)nullptr); \
-    else if (POINT_GRID_BLOCKS(n) > POINT_MAX_BLOCKS) hipLaunchKernelGGL((kernel<1>), dim3(POINT_MAX_BLOCKS), dim3(POINT_LANES(n)), 0, stream, __VA_ARGS__, ws->tiles); \
+    else if (POINT_GRID_BLOCKS(n) > POINT_MAX_BLOCKS) { \
+      const hipError_t z_ = hipMemsetAsync(ws->tiles, 0, sizeof(uint32_t), stream); if (z_ != hipSuccess) return z_; \
+      hipLaunchKernelGGL((kernel<1>), dim3(POINT_MAX_BLOCKS), dim3(POINT_LANES(n)), 0, stream, __VA_ARGS__, ws->tiles); } \
     else hipLaunchKernelGGL((kernel<1>), dim3(POINT_GRID_BLOCKS(n)), dim3(POINT_LANES(n)), 0, stream, __VA_ARGS__, (uint32_t*)nullptr); } while (0)
 #define EDK_FINISH_GRID(n) dim3((unsigned)((((n) + BLOCK - 1) / BLOCK + finish_k(n) - 1) / finish_k(n))), dim3(BLOCK), 0, stream
 
