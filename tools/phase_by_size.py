@@ -5,7 +5,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.in
 import libeddsa_amd as ed, workload
 ed.init(0)
 d = lambda a: torch.from_numpy(a).cuda()
-for l in (20, 19, 18, 17, 16):
+for l in ([int(a) for a in sys.argv[1:]] or (20, 19, 18, 17, 16)):
     n = 1 << l
     sk, msg = workload.sign_inputs(n, seed=1, config=2)
     pk = ed.ed25519_genpub_batch(d(sk)); sig = ed.ed25519_sign_batch(d(sk), pk, d(msg)).cpu().numpy(); pk = pk.cpu().numpy()
