@@ -48,7 +48,7 @@ typedef struct edk_verify_ws {
   uint32_t* offlist;  /* capacity words: the exact path's work list (keys off the curve; large passes: items without a short pair) */
   uint32_t* offcount; /* 64 words, zeroed at allocation: [0] the length of offlist (zeroed by every pass), [EDK_REFUSED_WORD] half-length
                          pairs that the exact check of lanes.h: verify_half_scalars_lane refused since allocation (diagnostic) */
-  uint32_t* exact_pad;/* EDK_EXACT_PAD_BYTES: per-lane scratchpad of k_verify_exact */
+  uint32_t* exact_pad;/* EDK_EXACT_PAD_BYTES: scratchpad of k_verify_exact_quad: the addends of the items in flight, one slot per quad */
   uint32_t* sums;     /* EDK_SUMS_BYTES: the windows' sums of a small pass */
   hipStream_t side;   /* the exact path runs here, beside the main kernel */
   hipEvent_t ev_prepared, ev_exact;

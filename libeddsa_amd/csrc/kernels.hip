@@ -7,7 +7,7 @@
 //   k_x25519_*       x25519.c:129-150 do_x25519                      (config 3)
 //   k_verify_*       ed25519-sha512.c:148-181 ed25519_verify        (config 2, 4): prepare / halve / main_half by
 //                    default (half-length scalars, halve.h), prepare / main / finish for the full-length route,
-//                    *_pair / *_quad forms for small passes, k_verify_exact* for keys that are not curve points
+//                    *_pair / *_quad forms for small passes, k_verify_exact_quad for keys that are not curve points
 //   k_sign_*         ed25519-sha512.c:84-123 sign                    (config 5)
 //   k_genpub_point + k_encode_finish          ed25519-sha512.c:53-67 genpub
 //   k_x25519_base_*  x25519.c:158-197 do_x25519_base
@@ -429,7 +429,7 @@ ED_DEV void den_commit(fe& z, bool good, uint32_t* acc, int k, int K) {
 }
 
 // verify: encode and compare with R as bytes (ed25519-sha512.c:176-180): a non-canonical R can
-// never match.  Items whose A is off the curve are skipped here (k_verify_exact writes their
+// never match.  Items whose A is off the curve are skipped here (k_verify_exact_quad writes their
 // verdict; DESIGN.md "Off-curve public keys"); Z = 0 cannot occur for a curve point (the a = -1 law
 // is complete) and is rejected defensively.
 struct verify_finish_policy {
@@ -455,7 +455,7 @@ struct verify_finish_policy {
     load32(rw, sigs, p.i, sig_stride);
     const uint8_t fl = flags[p.i];
     if ((fl & 1) == 0) {                         // off-curve key
-      if (!exact_offcurve) ok[p.i] = 0;          // reject mode; otherwise k_verify_exact owns ok[i]
+      if (!exact_offcurve) ok[p.i] = 0;          // reject mode; otherwise k_verify_exact_quad owns ok[i]
       return;
     }
     ok[p.i] = (uint8_t)(verify_encode_lane(x, y, zinv, rw) && (fl & 2) != 0);
