@@ -10,7 +10,8 @@
 //   verify_encode_lane     ed.c:155-169 ed_export + ed25519-sha512.c:176-180 (given 1/Z)
 //   verify_half_scalars_lane, verify_half_point_lane, verify_half_main_lane   the same verdict from half-length
 //                          scalars (halve.h): u (S B - t A - R) = 0, 132 doublings
-//   verify_exact_lane      the reference's own JSF/Shamir chain, for keys that are not on the curve
+//   verify_exact_lane      the reference's own JSF/Shamir chain, for keys that are not on the curve (one lane per item: the host
+//                          build and the layer probe; the kernels run its four-lane form, quad_lanes.h)
 //   scale_base_lane        ed.c:397-430 ed_scale_base (comb, constant-time select)
 //   genpub_point_lane, sign_point_lane, sign_finish_lane, encode_lane   ed25519-sha512.c:53-123
 //   x25519_base_point_lane, x25519_base_finish_lane                      x25519.c:158-197
