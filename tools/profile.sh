@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
-CMD="python3 $REPO/bench.py --steps 5 --warmup 1 --cpu-sample 4096 --sustained 0"
+CMD="python3 $REPO/bench.py --steps 10 --warmup 2 --cpu-sample 4096 --sustained 0"   # bench.py's own default step counts
 # the default command (verify + x25519 + sign in one process), then each op alone
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_all -- $CMD > $OUT/bench_stats_all.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD --op verify > $OUT/bench_stats.log 2>&1
