@@ -99,8 +99,8 @@ EDDSA_AMD_DECL int ed25519_sign_batch_multi(uint8_t *sigs, const uint8_t *secs, 
                                             size_t msg_len, size_t n);
 EDDSA_AMD_DECL int x25519_batch_multi(uint8_t *out, const uint8_t *scalars, const uint8_t *points, size_t n);
 /* device pointers: sigs[d] / pubs[d] / msgs[d] (fixed msg_len) hold shard d in device d's HBM,
- * ok_full[d] is a buffer of n_total bytes there, streams[d] a stream of device d (NULL entries =
- * default stream).  Shard d is verified on device d into its slice of ok_full[d]; then ONE RCCL
+ * ok_full[d] is a buffer of n_total bytes there, streams[d] a stream of device d (NULL entries, or
+ * streams == NULL = default stream).  Shard d is verified on device d into its slice of ok_full[d]; then ONE RCCL
  * all-gather (grouped broadcasts when the shards differ in length) leaves the whole verdict vector
  * in every ok_full[d].  Enqueues and returns; the streams order the work. */
 EDDSA_AMD_DECL int ed25519_verify_batch_multi_dev(uint8_t *const ok_full[], const uint8_t *const sigs[],

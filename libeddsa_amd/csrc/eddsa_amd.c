@@ -926,6 +926,8 @@ int ed25519_verify_batch_multi_dev(uint8_t *const ok_full[], const uint8_t *cons
                                    const uint8_t *const msgs[], size_t msg_len, size_t n_total, void *const streams[])
 {
     int rc = 0, saved = -1, g, r, even = 1, locked = 0;
+    void *const no_streams[MAX_DEVICES] = { 0 };
+    if (!streams) streams = no_streams;          /* no array: every device's default stream */
     pthread_rwlock_rdlock(&g_table);
     g = g_multi.n;
     if (g == 0) { rc = -(int)hipErrorNotInitialized; goto unlock; }
@@ -946,6 +948,10 @@ int ed25519_verify_batch_multi_dev(uint8_t *const ok_full[], const uint8_t *cons
     /* the final result gather: the only exchange of the path */
     if ((r = g_multi.GroupStart())) { rc = ERR_RCCL_BASE - r; goto out; }
     for (int d = 0; d < g; d++) {
+        /* a NULL stream is the default stream of the CURRENT device: rank d's calls are made with its device current.
+         * (A failure here is reported, but the rank still makes its calls: a group that lacks a rank never completes.) */
+        hipError_t er = hipSetDevice(g_multi.dev[d]);
+        if (er != hipSuccess && !rc) rc = -(int)er;
         if (even) {
             size_t lo, hi;
             eddsa_amd_shard_bounds(n_total, d, g, &lo, &hi);

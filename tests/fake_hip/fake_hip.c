@@ -54,6 +54,24 @@ int fake_hip_device_count(void)
 
 static hipError_t fail(hipError_t e) { t_last = e; return e; }
 
+/* Fault injection for tests/c/host_fault_walk.c: the call with ordinal g_fail_at among the FALLIBLE runtime calls
+ * (allocations, copies, memsets, stream / event creation, records, waits, synchronisations, hipSetDevice - the ones a
+ * real runtime fails when the device is lost or memory runs out; releases are not failed) returns an error instead of
+ * doing its work.  One shot: the ordinal is consumed when it fires. */
+static long g_calls, g_fail_at, g_fired;         /* atomics */
+long fake_hip_calls(void) { return __atomic_load_n(&g_calls, __ATOMIC_SEQ_CST); }
+void fake_hip_fail_call(long ordinal) { __atomic_store_n(&g_fail_at, ordinal, __ATOMIC_SEQ_CST); }
+long fake_hip_faults_fired(void) { return __atomic_load_n(&g_fired, __ATOMIC_SEQ_CST); }
+static int tick(void)
+{
+    const long c = __atomic_add_fetch(&g_calls, 1, __ATOMIC_SEQ_CST);
+    long at = c;
+    if (!__atomic_compare_exchange_n(&g_fail_at, &at, 0, 0, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) return 0;
+    __atomic_add_fetch(&g_fired, 1, __ATOMIC_SEQ_CST);
+    return 1;
+}
+#define FALLIBLE(err) do { if (tick()) return fail(err); } while (0)
+
 /* the allocation that holds [p, p + bytes), or NULL */
 static struct alloc *find(const void *p, size_t bytes)
 {
@@ -96,7 +114,10 @@ static hipError_t add(void **out, size_t bytes, int device, int host)
 {
     uint8_t *p = NULL;
     if (posix_memalign((void **)&p, 256, bytes ? bytes : 1) != 0) return fail(hipErrorOutOfMemory);
-    memset(p, 0xa5, bytes);                       /* fresh device memory holds garbage */
+    /* fresh device memory holds garbage (of a large buffer only both ends are filled: the fault walk allocates the
+     * 63 MB scratchpads of the verify workspaces a few thousand times) */
+    if (bytes <= ((size_t)4 << 20)) memset(p, 0xa5, bytes);
+    else { memset(p, 0xa5, (size_t)1 << 20); memset(p + bytes - ((size_t)1 << 20), 0xa5, (size_t)1 << 20); }
     pthread_mutex_lock(&g_lk);
     int i = 0;
     while (i < MAX_ALLOCS && g_allocs[i].p) i++;
@@ -147,7 +168,7 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t *prop, int d)
     prop->multiProcessorCount = 256;
     return hipSuccess;
 }
-hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
+hipError_t hipDeviceSynchronize(void) { FALLIBLE(hipErrorUnknown); return hipSuccess; }
 hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = -1; return hipSuccess; }
 hipError_t hipGetLastError(void) { const hipError_t e = t_last; t_last = hipSuccess; return e; }
 const char *hipGetErrorString(hipError_t e)
@@ -165,9 +186,9 @@ const char *hipGetErrorString(hipError_t e)
 }
 
 /* ---- memory ---- */
-hipError_t hipMalloc(void **p, size_t bytes) { return add(p, bytes, t_device, 0); }
+hipError_t hipMalloc(void **p, size_t bytes) { FALLIBLE(hipErrorOutOfMemory); return add(p, bytes, t_device, 0); }
 hipError_t hipFree(void *p) { return drop(p, 0); }
-hipError_t hipHostMalloc(void **p, size_t bytes, unsigned flags) { (void)flags; return add(p, bytes, -1, 1); }
+hipError_t hipHostMalloc(void **p, size_t bytes, unsigned flags) { (void)flags; FALLIBLE(hipErrorOutOfMemory); return add(p, bytes, -1, 1); }
 hipError_t hipHostFree(void *p) { return drop(p, 1); }
 
 hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *p)
@@ -194,31 +215,47 @@ static void check_copy(void *dst, const void *src, size_t bytes, hipMemcpyKind k
     if (kind == hipMemcpyHostToDevice && fake_hip_owner(src, bytes) >= 0) die("host-to-device copy from device memory");
     if (kind == hipMemcpyDeviceToHost && fake_hip_owner(dst, bytes) >= 0) die("device-to-host copy into device memory");
 }
+static hipError_t copy_now(void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    check_copy(dst, src, bytes, kind);
+    if (bytes) memmove(dst, src, bytes);
+    return hipSuccess;
+}
 hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
 {
+    FALLIBLE(hipErrorUnknown);
     check_copy(dst, src, bytes, kind);
     if (bytes) memmove(dst, src, bytes);
     return hipSuccess;
 }
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t s)
 {
+    FALLIBLE(hipErrorUnknown);
     check_stream(s, "hipMemcpyAsync");
-    return hipMemcpy(dst, src, bytes, kind);
+    return copy_now(dst, src, bytes, kind);
+}
+static hipError_t set_now(void *dst, int v, size_t bytes)
+{
+    if (bytes) { fake_hip_require_device(dst, bytes, t_device, "hipMemset"); memset(dst, v, bytes); }
+    return hipSuccess;
 }
 hipError_t hipMemset(void *dst, int v, size_t bytes)
 {
+    FALLIBLE(hipErrorUnknown);
     if (bytes) { fake_hip_require_device(dst, bytes, t_device, "hipMemset"); memset(dst, v, bytes); }
     return hipSuccess;
 }
 hipError_t hipMemsetAsync(void *dst, int v, size_t bytes, hipStream_t s)
 {
+    FALLIBLE(hipErrorUnknown);
     check_stream(s, "hipMemsetAsync");
-    return hipMemset(dst, v, bytes);
+    return set_now(dst, v, bytes);
 }
 
 /* ---- streams and events: tagged objects; everything has completed by the time a call returns ---- */
 static hipError_t new_stream(hipStream_t *s)
 {
+    FALLIBLE(hipErrorOutOfMemory);
     *s = (hipStream_t)malloc(sizeof(**s));
     if (!*s) return fail(hipErrorOutOfMemory);
     (*s)->magic = STREAM_MAGIC; (*s)->device = t_device;
@@ -236,9 +273,10 @@ hipError_t hipStreamDestroy(hipStream_t s)
     pthread_mutex_lock(&g_lk); g_live_streams--; pthread_mutex_unlock(&g_lk);
     return hipSuccess;
 }
-hipError_t hipStreamSynchronize(hipStream_t s) { if (s && s->magic != STREAM_MAGIC) die("hipStreamSynchronize of a dead stream"); return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t s) { if (s && s->magic != STREAM_MAGIC) die("hipStreamSynchronize of a dead stream"); FALLIBLE(hipErrorUnknown); return hipSuccess; }
 static hipError_t new_event(hipEvent_t *e)
 {
+    FALLIBLE(hipErrorOutOfMemory);
     *e = (hipEvent_t)malloc(sizeof(**e));
     if (!*e) return fail(hipErrorOutOfMemory);
     (*e)->magic = EVENT_MAGIC; (*e)->device = t_device;
@@ -260,9 +298,10 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s)
     if (!e || e->magic != EVENT_MAGIC) die("hipEventRecord of a dead event");
     check_stream(s, "hipEventRecord");
     if (e->device != fake_hip_stream_device(s)) die("hipEventRecord: the event belongs to another device than the stream");
+    FALLIBLE(hipErrorUnknown);
     return hipSuccess;
 }
-hipError_t hipEventSynchronize(hipEvent_t e) { if (!e || e->magic != EVENT_MAGIC) die("hipEventSynchronize of a dead event"); return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t e) { if (!e || e->magic != EVENT_MAGIC) die("hipEventSynchronize of a dead event"); FALLIBLE(hipErrorUnknown); return hipSuccess; }
 hipError_t hipEventQuery(hipEvent_t e) { if (!e || e->magic != EVENT_MAGIC) die("hipEventQuery of a dead event"); return hipSuccess; }
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
 {
@@ -275,5 +314,6 @@ hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags)
     (void)flags;
     if (!e || e->magic != EVENT_MAGIC) die("hipStreamWaitEvent on a dead event");
     if (s && s->magic != STREAM_MAGIC) die("hipStreamWaitEvent of a dead stream");
+    FALLIBLE(hipErrorUnknown);
     return hipSuccess;
 }

@@ -11,6 +11,9 @@ int fake_hip_owner(const void *p, size_t bytes);          /* >= 0: device memory
 void fake_hip_require_device(const void *p, size_t bytes, int device, const char *what);   /* aborts with a message otherwise */
 int fake_hip_stream_device(struct ihipStream_t *s);       /* NULL: the current device */
 long fake_hip_live_allocations(void);                     /* allocations, streams and events not yet released */
+long fake_hip_calls(void);                                /* fallible runtime calls made so far (all threads) */
+void fake_hip_fail_call(long ordinal);                    /* the call with that ordinal fails instead of doing its work (one shot; 0: disarm) */
+long fake_hip_faults_fired(void);                         /* how many armed ordinals were reached */
 #ifdef __cplusplus
 }
 #endif

@@ -42,9 +42,26 @@ static int complain(int rc, const char *what)
     return rc;
 }
 
+/* fault injection for tests/c/host_fault_walk.c, as in fake_hip.c: the call with this ordinal (ncclCommInitAll, group
+ * start / end and the collectives are counted) fails instead of doing its work; one shot */
+static long g_calls, g_fail_at, g_fired;         /* atomics */
+long fake_rccl_calls(void) { return __atomic_load_n(&g_calls, __ATOMIC_SEQ_CST); }
+void fake_rccl_fail_call(long ordinal) { __atomic_store_n(&g_fail_at, ordinal, __ATOMIC_SEQ_CST); }
+long fake_rccl_faults_fired(void) { return __atomic_load_n(&g_fired, __ATOMIC_SEQ_CST); }
+static int tick(void)
+{
+    const long c = __atomic_add_fetch(&g_calls, 1, __ATOMIC_SEQ_CST);
+    long at = c;
+    if (!__atomic_compare_exchange_n(&g_fail_at, &at, 0, 0, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) return 0;
+    __atomic_add_fetch(&g_fired, 1, __ATOMIC_SEQ_CST);
+    return 1;
+}
+#define ncclSystemError_ 2
+
 int ncclCommInitAll(ncclComm_t *comms, int n, const int *devices)
 {
     if (n < 1 || n > 64) return complain(ncclInvalidArgument, "ncclCommInitAll: bad rank count");
+    if (tick()) return ncclSystemError_;
     struct clique *cl = (struct clique *)calloc(1, sizeof(*cl));
     cl->nranks = n;
     for (int r = 0; r < n; r++) {
@@ -103,6 +120,7 @@ int ncclAllGather(const void *send, void *recv, size_t count, int dtype, ncclCom
             return complain(ncclInvalidArgument, "in-place all-gather: sendbuff must be recvbuff + rank * count");
     }
     struct op o = { OP_ALLGATHER, 0, send, recv, count, comm };
+    if (tick()) return ncclSystemError_;
     return push(o, stream);
 }
 
@@ -111,11 +129,13 @@ int ncclBroadcast(const void *send, void *recv, size_t count, int dtype, int roo
     if (dtype != 1) return complain(ncclInvalidArgument, "only ncclUint8 is expected here");
     if (comm && (root < 0 || root >= comm->nranks)) return complain(ncclInvalidArgument, "broadcast root out of range");
     struct op o = { OP_BROADCAST, root, send, recv, count, comm };
+    if (tick()) return ncclSystemError_;
     return push(o, stream);
 }
 
 int ncclGroupStart(void)
 {
+    if (tick()) return ncclSystemError_;
     pthread_mutex_lock(&g_lk);
     g_depth++;
     pthread_mutex_unlock(&g_lk);
@@ -127,6 +147,7 @@ int ncclGroupEnd(void)
 {
     int rc = ncclSuccess;
     pthread_mutex_lock(&g_lk);
+    if (tick()) { g_depth = 0; g_nops = 0; pthread_mutex_unlock(&g_lk); return ncclSystemError_; }   /* (the group is abandoned) */
     if (g_depth == 0) { pthread_mutex_unlock(&g_lk); return complain(ncclInvalidUsage, "ncclGroupEnd without ncclGroupStart"); }
     if (--g_depth > 0) { pthread_mutex_unlock(&g_lk); return ncclSuccess; }
     int used[MAX_OPS] = { 0 };
@@ -139,9 +160,9 @@ int ncclGroupEnd(void)
             for (int k = i; k < g_nops; k++)
                 if (!used[k] && g_ops[k].comm->cl == cl && g_ops[k].comm->rank == r) { part[r] = &g_ops[k]; used[k] = 1; break; }
         for (int r = 0; r < cl->nranks && rc == ncclSuccess; r++) {
-            if (!part[r]) rc = complain(ncclInvalidUsage, "a rank did not take part in a collective of the group (the real library would hang)");
+            if (!part[r]) rc = g_fired ? ncclInvalidUsage : complain(ncclInvalidUsage, "a rank did not take part in a collective of the group (the real library would hang)");
             else if (part[r]->kind != part[0]->kind || part[r]->count != part[0]->count || part[r]->root != part[0]->root)
-                rc = complain(ncclInvalidUsage, "the ranks disagree on a collective's kind, count or root");
+                rc = g_fired ? ncclInvalidUsage : complain(ncclInvalidUsage, "the ranks disagree on a collective's kind, count or root");   /* (expected once a call of the group was failed on purpose) */
         }
         if (rc != ncclSuccess) break;
         const size_t count = part[0]->count;

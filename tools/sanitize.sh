@@ -14,5 +14,6 @@ trap '[ -s $KEEP ] && cp $KEEP tests/host_check/libhostcheck.so || rm -f tests/h
 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 \
     python -m pytest tests/test_device_source_on_host.py -x -q
 # ... and the product's HOST side (eddsa_amd.c + host_pipe.c, unchanged) against the fake HIP runtime / fake RCCL of
-# tests/fake_hip/, under -fsanitize=thread and -fsanitize=address,undefined, with 2, 3 and 8 devices
+# tests/fake_hip/, under -fsanitize=thread and -fsanitize=address,undefined, with 2, 3 and 8 devices (incl. the walk that
+# fails every runtime and RCCL call in turn: tests/c/host_fault_walk.c)
 python -m pytest tests/test_host_side_sanitized.py -x -q
