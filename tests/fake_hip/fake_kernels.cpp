@@ -1,8 +1,11 @@
 // fake_kernels.cpp - TEST INFRASTRUCTURE: the launchers of libeddsa_amd/csrc/eddsa_kernels.h on the CPU, for the sanitizer
 // build of the product's host side (see fake_hip.c).  Every launcher computes what its kernels compute by calling the
 // -DED_HOST_CHECK build of the device source item by item (lanes.h: the same functions tests/host_check/ drives against the
-// oracle, every limb bound asserted), synchronously, and first checks that every pointer it was given is memory of the
-// calling thread's current device and that the stream belongs to it - the rank <-> device mix-ups a one-GPU box cannot show.
+// oracle, every limb bound asserted), and first checks that every pointer it was given is memory of the calling thread's
+// current device and that the stream belongs to it - the rank <-> device mix-ups a one-GPU box cannot show.  The work
+// itself is handed to the fake runtime as a task of the launch's stream (fake_hip_enqueue): at once in the eager model, as
+// late as the API allows with FAKE_HIP_DEFER=1 - arguments that a kernel receives by value are captured at the launch,
+// device memory is read when the task runs.
 // Never part of the product.
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
@@ -11,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <vector>
 
@@ -33,6 +37,8 @@ static void wr(uint8_t* p, const uint32_t w[8]) { memcpy(p, w, 32); }
 
 static int cur() { return fake_hip_current_device(); }
 static void own(const void* p, size_t bytes, const char* what) { if (bytes) fake_hip_require_device(p, bytes, cur(), what); }
+static void run_closure(void* a) { auto* f = static_cast<std::function<void()>*>(a); (*f)(); delete f; }
+static void enq(hipStream_t s, std::function<void()> f) { fake_hip_enqueue(s, run_closure, new std::function<void()>(std::move(f))); }
 static void own_stream(hipStream_t s) {
   if (fake_hip_stream_device(s) != cur()) { fprintf(stderr, "fake_kernels: launch on a stream of device %d while device %d is current\n", fake_hip_stream_device(s), cur()); abort(); }
 }
@@ -137,12 +143,14 @@ hipError_t edk_init_tables(uint32_t* base16, uint32_t* comb, uint32_t* comb_img,
   const Tables& t = tables();
   const size_t b16_bytes = (size_t)2 * TABLE_BASE16_ENTRIES * TABLE_ENTRY_WORDS * 4;
   own(base16, b16_bytes, "base16"); own(comb, t.comb.size() * 4, "comb"); own(comb_img, (size_t)COMB_IMG_WORDS * 4, "comb image");
-  memcpy(base16, t.b16(), b16_bytes);
-  memcpy(comb, t.comb.data(), t.comb.size() * 4);
   // (the host build of comb_select reads the comb in its global layout: that is what this "image" holds here)
   static_assert((size_t)COMB_IMG_WORDS >= (size_t)TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS, "the image buffer holds the plain comb");
-  memset(comb_img, 0, (size_t)COMB_IMG_WORDS * 4);
-  memcpy(comb_img, t.comb.data(), t.comb.size() * 4);
+  enq(stream, [=, &t] {
+    memcpy(base16, t.b16(), b16_bytes);
+    memcpy(comb, t.comb.data(), t.comb.size() * 4);
+    memset(comb_img, 0, (size_t)COMB_IMG_WORDS * 4);
+    memcpy(comb_img, t.comb.data(), t.comb.size() * 4);
+  });
   return hipSuccess;
 }
 
@@ -154,24 +162,35 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* src, size_t n, const ui
   own_stream(stream);
   own(ok, n, "verdicts");
   own(src->sigs, (n - 1) * src->sig_stride + 64, "signatures"); own(src->pubs, (n - 1) * src->pub_stride + 32, "keys");
-  if (src->msg_off) { own(src->msg_off, (n + 1) * 8, "message offsets"); own(src->msgs + src->msg_off[0], (size_t)(src->msg_off[n] - src->msg_off[0]), "messages"); }
+  if (src->msg_off) own(src->msg_off, (n + 1) * 8, "message offsets");
   else own(src->msgs, src->msg_len ? (n - 1) * src->msg_stride + src->msg_len : 0, "messages");
   own(base16, (size_t)2 * TABLE_BASE16_ENTRIES * TABLE_ENTRY_WORDS * 4, "base16");
   if (n > ws->capacity) { fprintf(stderr, "fake_kernels: pass of %zu items through a workspace of %zu\n", n, ws->capacity); abort(); }
   own(ws->digits, ws->capacity * 64, "workspace digits"); own(ws->table, ws->capacity * VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS * 4, "workspace table");
   own(ws->flags, ws->capacity, "workspace flags"); own(ws->offcount, 256, "work-list counter");
   if (fake_hip_stream_device(ws->side) != cur()) { fprintf(stderr, "fake_kernels: the workspace's side stream belongs to another device\n"); abort(); }
-  if (marks) for (int k = 0; k < 4; k++) if (hipEventRecord(marks[k], stream) != hipSuccess) return hipErrorUnknown;
-  if (hipEventRecord(ws->ev_prepared, stream) != hipSuccess || hipEventRecord(ws->ev_exact, ws->side) != hipSuccess) return hipErrorUnknown;
-  for (size_t i = 0; i < n; i++) ok[i] = (uint8_t)verify_item(*src, i, base16, ws->exact_offcurve);
-  if (bulk_done && hipEventRecord(bulk_done, stream) != hipSuccess) return hipErrorUnknown;
+  // the events of kernels.hip: edk_verify, in its order
+  if (marks) for (int k = 0; k < 2; k++) if (hipEventRecord(marks[k], stream) != hipSuccess) return hipErrorUnknown;
+  if (bulk_done && bulk_early && hipEventRecord(bulk_done, stream) != hipSuccess) return hipErrorUnknown;
+  const edk_verify_src s = *src;                 // a kernel argument: by value, at the launch
+  const int exact = ws->exact_offcurve, dev = cur();
+  enq(stream, [=] {
+    // (the offset table is device memory: its contents exist when the task runs, not before)
+    if (s.msg_off) fake_hip_require_device(s.msgs + s.msg_off[0], (size_t)(s.msg_off[n] - s.msg_off[0]) ? (size_t)(s.msg_off[n] - s.msg_off[0]) : 1, dev, "messages");
+    for (size_t i = 0; i < n; i++) ok[i] = (uint8_t)verify_item(s, i, base16, exact);
+  });
+  if (hipEventRecord(ws->ev_prepared, stream) != hipSuccess || hipStreamWaitEvent(ws->side, ws->ev_prepared, 0) != hipSuccess ||
+      hipEventRecord(ws->ev_exact, ws->side) != hipSuccess) return hipErrorUnknown;
+  if (marks) for (int k = 2; k < 4; k++) if (hipEventRecord(marks[k], stream) != hipSuccess) return hipErrorUnknown;
+  if (bulk_done && !bulk_early && hipEventRecord(bulk_done, stream) != hipSuccess) return hipErrorUnknown;
+  if (exact && hipStreamWaitEvent(stream, ws->ev_exact, 0) != hipSuccess) return hipErrorUnknown;
   return hipSuccess;
 }
 
 size_t edk_rlc_ws_bytes(size_t capacity) { return capacity ? capacity : 0; }
 hipError_t edk_rlc_note_per_item(uint32_t* stats, size_t n, hipStream_t stream) {
   own_stream(stream);
-  if (stats && n) { own(stats, 16, "statistics"); stats[1] += (uint32_t)n; stats[2] += (uint32_t)((n + 8191) / 8192); }
+  if (stats && n) { own(stats, 16, "statistics"); enq(stream, [=] { stats[1] += (uint32_t)n; stats[2] += (uint32_t)((n + 8191) / 8192); }); }
   return hipSuccess;
 }
 // the combination is device code (rlc.hip) that this build does not contain: the items are decided one by one, every
@@ -180,7 +199,8 @@ hipError_t edk_verify_rlc(uint8_t* ok, uint32_t* stats, const edk_verify_src* sr
                           const edk_verify_ws* ws, const edk_rlc_ws* rws, hipStream_t stream) {
   const hipError_t e = edk_verify(ok, src, n, base16, ws, nullptr, nullptr, 0, stream);
   if (e != hipSuccess) return e;
-  memset(rws->host_gok, 1, (n + 8191) / 8192);
+  void* gok = rws->host_gok;
+  enq(stream, [=] { memset(gok, 1, (n + 8191) / 8192); });
   return edk_rlc_note_per_item(stats, n, stream);
 }
 hipError_t edk_verify_rlc_fallback(uint8_t*, const edk_verify_src*, size_t, const uint32_t*, const edk_verify_ws*, const edk_rlc_ws*, hipStream_t) {
@@ -196,27 +216,31 @@ static void own_fixed(const edk_fixed_ws* ws, size_t n, hipStream_t stream) {
 hipError_t edk_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* points, size_t n, const edk_fixed_ws* ws, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   own_fixed(ws, n, stream); own(out, 32 * n, "x25519 out"); own(scalars, 32 * n, "scalars"); own(points, 32 * n, "points");
-  for (size_t i = 0; i < n; i++) {
-    uint32_t s[8], p[8], o[8];
-    rd(s, scalars + 32 * i); rd(p, points + 32 * i);
-    x25519_lane(o, s, p);
-    wr(out + 32 * i, o);
-  }
+  enq(stream, [=] {
+    for (size_t i = 0; i < n; i++) {
+      uint32_t s[8], p[8], o[8];
+      rd(s, scalars + 32 * i); rd(p, points + 32 * i);
+      x25519_lane(o, s, p);
+      wr(out + 32 * i, o);
+    }
+  });
   return hipSuccess;
 }
 
 hipError_t edk_genpub(uint8_t* pubs, const uint8_t* secs, size_t n, const uint32_t* comb, const edk_fixed_ws* ws, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   own_fixed(ws, n, stream); own(pubs, 32 * n, "public keys"); own(secs, 32 * n, "secret keys"); own(comb, (size_t)COMB_IMG_WORDS * 4, "comb");
-  for (size_t i = 0; i < n; i++) {
-    uint32_t sk[8], o[8];
-    rd(sk, secs + 32 * i);
-    ge A; fe zinv;
-    genpub_point_lane(A, sk, comb);
-    fe_inv(zinv, A.Z);
-    encode_lane(o, A.X, A.Y, zinv);
-    wr(pubs + 32 * i, o);
-  }
+  enq(stream, [=] {
+    for (size_t i = 0; i < n; i++) {
+      uint32_t sk[8], o[8];
+      rd(sk, secs + 32 * i);
+      ge A; fe zinv;
+      genpub_point_lane(A, sk, comb);
+      fe_inv(zinv, A.Z);
+      encode_lane(o, A.X, A.Y, zinv);
+      wr(pubs + 32 * i, o);
+    }
+  });
   return hipSuccess;
 }
 
@@ -224,61 +248,69 @@ hipError_t edk_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, con
                     size_t n, const uint32_t* comb, const edk_fixed_ws* ws, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   own_fixed(ws, n, stream); own(sigs, 64 * n, "signatures"); own(secs, 32 * n, "secret keys"); own(pubs, 32 * n, "public keys");
-  if (msg_off) { own(msg_off, (n + 1) * 8, "message offsets"); own(msgs + msg_off[0], (size_t)(msg_off[n] - msg_off[0]), "messages"); } else own(msgs, n * msg_len, "messages");
-  for (size_t i = 0; i < n; i++) {
-    const uint8_t* m = msg_off ? msgs + msg_off[i] : msgs + i * msg_len;
-    const size_t mlen = msg_off ? (size_t)(msg_off[i + 1] - msg_off[i]) : msg_len;
-    uint32_t sk[8], pk[8], R[8], S[8], aw[8], rw[8];
-    rd(sk, secs + 32 * i); rd(pk, pubs + 32 * i);
-    ge Rp; fe zinv;
-    sign_point_lane(Rp, aw, rw, sk, m, mlen, comb);
-    fe_inv(zinv, Rp.Z);
-    encode_lane(R, Rp.X, Rp.Y, zinv);
-    sign_finish_lane(S, R, aw, rw, pk, m, mlen);
-    wr(sigs + 64 * i, R); wr(sigs + 64 * i + 32, S);
-  }
+  if (msg_off) own(msg_off, (n + 1) * 8, "message offsets"); else own(msgs, n * msg_len, "messages");
+  const int dev = cur();
+  enq(stream, [=] {
+    if (msg_off) fake_hip_require_device(msgs + msg_off[0], (size_t)(msg_off[n] - msg_off[0]) ? (size_t)(msg_off[n] - msg_off[0]) : 1, dev, "messages");
+    for (size_t i = 0; i < n; i++) {
+      const uint8_t* m = msg_off ? msgs + msg_off[i] : msgs + i * msg_len;
+      const size_t mlen = msg_off ? (size_t)(msg_off[i + 1] - msg_off[i]) : msg_len;
+      uint32_t sk[8], pk[8], R[8], S[8], aw[8], rw[8];
+      rd(sk, secs + 32 * i); rd(pk, pubs + 32 * i);
+      ge Rp; fe zinv;
+      sign_point_lane(Rp, aw, rw, sk, m, mlen, comb);
+      fe_inv(zinv, Rp.Z);
+      encode_lane(R, Rp.X, Rp.Y, zinv);
+      sign_finish_lane(S, R, aw, rw, pk, m, mlen);
+      wr(sigs + 64 * i, R); wr(sigs + 64 * i + 32, S);
+    }
+  });
   return hipSuccess;
 }
 
 hipError_t edk_x25519_base(uint8_t* out, const uint8_t* scalars, size_t n, const uint32_t* comb, const edk_fixed_ws* ws, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   own_fixed(ws, n, stream); own(out, 32 * n, "x25519_base out"); own(scalars, 32 * n, "scalars");
-  for (size_t i = 0; i < n; i++) {
-    uint32_t s[8], o[8];
-    rd(s, scalars + 32 * i);
-    ge R; fe d;
-    x25519_base_point_lane(R, s, comb);
-    fe_sub(d, R.Z, R.Y);
-    fe_inv(d, d);
-    x25519_base_finish_lane(o, R.Y, R.Z, d);
-    wr(out + 32 * i, o);
-  }
+  enq(stream, [=] {
+    for (size_t i = 0; i < n; i++) {
+      uint32_t s[8], o[8];
+      rd(s, scalars + 32 * i);
+      ge R; fe d;
+      x25519_base_point_lane(R, s, comb);
+      fe_sub(d, R.Z, R.Y);
+      fe_inv(d, d);
+      x25519_base_finish_lane(o, R.Y, R.Z, d);
+      wr(out + 32 * i, o);
+    }
+  });
   return hipSuccess;
 }
 
 hipError_t edk_pk_to_x(uint8_t* out, const uint8_t* in, size_t n, hipStream_t stream) {
   own_stream(stream); own(out, 32 * n, "pk->x out"); own(in, 32 * n, "pk->x in");
-  for (size_t i = 0; i < n; i++) { uint32_t w[8], o[8]; rd(w, in + 32 * i); pk_to_x_lane(o, w); wr(out + 32 * i, o); }
+  enq(stream, [=] { for (size_t i = 0; i < n; i++) { uint32_t w[8], o[8]; rd(w, in + 32 * i); pk_to_x_lane(o, w); wr(out + 32 * i, o); } });
   return hipSuccess;
 }
 hipError_t edk_sk_to_x(uint8_t* out, const uint8_t* in, size_t n, hipStream_t stream) {
   own_stream(stream); own(out, 32 * n, "sk->x out"); own(in, 32 * n, "sk->x in");
-  for (size_t i = 0; i < n; i++) { uint32_t w[8], o[8]; rd(w, in + 32 * i); sk_to_x_lane(o, w); wr(out + 32 * i, o); }
+  enq(stream, [=] { for (size_t i = 0; i < n; i++) { uint32_t w[8], o[8]; rd(w, in + 32 * i); sk_to_x_lane(o, w); wr(out + 32 * i, o); } });
   return hipSuccess;
 }
 
 hipError_t edk_debug_halve(uint8_t* out, const uint8_t* t, size_t n, int wide, hipStream_t stream) {
   own_stream(stream); own(out, 48 * n, "halve out"); own(t, 32 * n, "halve in");
-  for (size_t i = 0; i < n; i++) {
-    uint32_t tw[8], vw[5], uw[5];
-    rd(tw, t + 32 * i);
-    bool ng;
-    const bool found = wide ? halve_scalar_lane<HALF_BITS_SMALL>(vw, uw, ng, tw) : halve_scalar_lane<HALF_BITS>(vw, uw, ng, tw);
-    uint32_t o[12];
-    for (int k = 0; k < 5; k++) { o[k] = vw[k]; o[5 + k] = uw[k]; }
-    o[10] = (ng ? 1u : 0u) | (found ? 0x100u : 0u); o[11] = 0;
-    memcpy(out + 48 * i, o, 48);
-  }
+  enq(stream, [=] {
+    for (size_t i = 0; i < n; i++) {
+      uint32_t tw[8], vw[5], uw[5];
+      rd(tw, t + 32 * i);
+      bool ng;
+      const bool found = wide ? halve_scalar_lane<HALF_BITS_SMALL>(vw, uw, ng, tw) : halve_scalar_lane<HALF_BITS>(vw, uw, ng, tw);
+      uint32_t o[12];
+      for (int k = 0; k < 5; k++) { o[k] = vw[k]; o[5 + k] = uw[k]; }
+      o[10] = (ng ? 1u : 0u) | (found ? 0x100u : 0u); o[11] = 0;
+      memcpy(out + 48 * i, o, 48);
+    }
+  });
   return hipSuccess;
 }
 

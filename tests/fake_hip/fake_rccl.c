@@ -29,7 +29,7 @@ struct clique { int nranks; struct ncclComm *comm[64]; };
 typedef struct ncclComm *ncclComm_t;
 
 enum { OP_ALLGATHER, OP_BROADCAST };
-struct op { int kind, root; const void *send; void *recv; size_t count; struct ncclComm *comm; };
+struct op { int kind, root; const void *send; void *recv; size_t count; struct ncclComm *comm; hipStream_t stream; };
 #define MAX_OPS 4096
 static struct op g_ops[MAX_OPS];
 static int g_nops, g_depth;
@@ -101,6 +101,7 @@ static int push(struct op o, hipStream_t stream)
             return complain(ncclInvalidArgument, "receive buffer is not (entirely) memory of the rank's device");
         if (fake_hip_owner(o.send, o.count) != o.comm->device) return complain(ncclInvalidArgument, "send buffer is not memory of the rank's device");
     }
+    o.stream = fake_hip_resolve_stream(stream);     /* (a NULL handle: the default stream of the device current NOW) */
     pthread_mutex_lock(&g_lk);
     if (g_nops == MAX_OPS) { pthread_mutex_unlock(&g_lk); return complain(ncclInvalidUsage, "too many grouped operations"); }
     g_ops[g_nops++] = o;
@@ -119,7 +120,7 @@ int ncclAllGather(const void *send, void *recv, size_t count, int dtype, ncclCom
         if (s + count > r && s < r + total && s != r + (size_t)comm->rank * count)
             return complain(ncclInvalidArgument, "in-place all-gather: sendbuff must be recvbuff + rank * count");
     }
-    struct op o = { OP_ALLGATHER, 0, send, recv, count, comm };
+    struct op o = { OP_ALLGATHER, 0, send, recv, count, comm, NULL };
     if (tick()) return ncclSystemError_;
     return push(o, stream);
 }
@@ -128,7 +129,7 @@ int ncclBroadcast(const void *send, void *recv, size_t count, int dtype, int roo
 {
     if (dtype != 1) return complain(ncclInvalidArgument, "only ncclUint8 is expected here");
     if (comm && (root < 0 || root >= comm->nranks)) return complain(ncclInvalidArgument, "broadcast root out of range");
-    struct op o = { OP_BROADCAST, root, send, recv, count, comm };
+    struct op o = { OP_BROADCAST, root, send, recv, count, comm, NULL };
     if (tick()) return ncclSystemError_;
     return push(o, stream);
 }
@@ -140,6 +141,44 @@ int ncclGroupStart(void)
     g_depth++;
     pthread_mutex_unlock(&g_lk);
     return ncclSuccess;
+}
+
+struct coll {
+    int kind, root, nranks, left, leader;
+    volatile int arrived[64];
+    size_t count;
+    const void *send[64]; void *recv[64]; hipStream_t stream[64];
+};
+struct coll_part { struct coll *c; int rank; };
+static void coll_move(struct coll *c)
+{
+    const size_t count = c->count;
+    if (c->kind == OP_ALLGATHER) {
+        uint8_t *all = (uint8_t *)malloc(count * (size_t)c->nranks);    /* every contribution first: in-place receivers overwrite their senders */
+        for (int r = 0; r < c->nranks; r++) memcpy(all + (size_t)r * count, c->send[r], count);
+        for (int r = 0; r < c->nranks; r++) memcpy(c->recv[r], all, count * (size_t)c->nranks);
+        free(all);
+    } else {
+        uint8_t *val = (uint8_t *)malloc(count);
+        memcpy(val, c->send[c->root], count);
+        for (int r = 0; r < c->nranks; r++) memcpy(c->recv[r], val, count);
+        free(val);
+    }
+}
+/* rank r's stream has reached the collective (a task of that stream; the fake runtime runs one task at a time) */
+static void coll_arrive(void *a)
+{
+    struct coll_part *cp = (struct coll_part *)a;
+    struct coll *c = cp->c;
+    const int r = cp->rank;
+    free(cp);
+    c->arrived[r] = 1;
+    if (c->leader < 0) {                         /* the first to arrive brings the others here, then moves the data */
+        c->leader = r;
+        for (int k = 0; k < c->nranks; k++) if (!c->arrived[k]) fake_hip_run_until(c->stream[k], &c->arrived[k]);
+        coll_move(c);
+    }
+    if (--c->left == 0) free(c);
 }
 
 /* the k-th operation issued on every communicator of a clique forms one collective */
@@ -167,19 +206,21 @@ int ncclGroupEnd(void)
         if (rc != ncclSuccess) break;
         const size_t count = part[0]->count;
         if (!count) continue;
-        if (part[0]->kind == OP_ALLGATHER) {
-            uint8_t *all = (uint8_t *)malloc(count * (size_t)cl->nranks);   /* every contribution first: in-place receivers overwrite their senders */
-            for (int r = 0; r < cl->nranks; r++) memcpy(all + (size_t)r * count, part[r]->send, count);
-            for (int r = 0; r < cl->nranks; r++) memcpy(part[r]->recv, all, count * (size_t)cl->nranks);
-            free(all);
-            g_gathers++;
-        } else {
-            uint8_t *val = (uint8_t *)malloc(count);
-            memcpy(val, part[part[0]->root]->send, count);
-            for (int r = 0; r < cl->nranks; r++) memcpy(part[r]->recv, val, count);
-            free(val);
-            g_broadcasts++;
+        /* the collective is work of every rank's stream: it moves the data when each of them has reached it (eager
+         * model: now; FAKE_HIP_DEFER=1: when the first of the streams is made to run that far - which then makes the
+         * others run up to their part) */
+        struct coll *c = (struct coll *)calloc(1, sizeof(*c));
+        c->kind = part[0]->kind; c->root = part[0]->root; c->count = count; c->nranks = cl->nranks; c->left = cl->nranks; c->leader = -1;
+        for (int r = 0; r < cl->nranks; r++) { c->send[r] = part[r]->send; c->recv[r] = part[r]->recv; c->stream[r] = part[r]->stream; }
+        if (c->kind == OP_ALLGATHER) g_gathers++; else g_broadcasts++;
+        if (!fake_hip_deferred()) { coll_move(c); free(c); continue; }
+        void *parts[64];
+        for (int r = 0; r < cl->nranks; r++) {
+            struct coll_part *cp = (struct coll_part *)malloc(sizeof(*cp));
+            cp->c = c; cp->rank = r;
+            parts[r] = cp;
         }
+        fake_hip_enqueue_group(cl->nranks, c->stream, coll_arrive, parts);
     }
     g_nops = 0;
     pthread_mutex_unlock(&g_lk);

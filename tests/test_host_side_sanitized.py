@@ -17,8 +17,12 @@ Run under -fsanitize=thread and -fsanitize=address,undefined:
                               device-pointer calls (warm and cold), of the device set and of the gather - and every call
                               into the fake RCCL - failed once, one at a time: an error return or a right result, the next
                               call works, no secret stays in a staging buffer, nothing is leaked
-This is the only multi-device evidence obtainable without a multi-GPU node; it says nothing about stream ordering on real
-hardware (the fake completes every operation at once)."""
+Each also runs with FAKE_HIP_DEFER=1: the fake runtime then QUEUES asynchronous work per stream and runs it as late as the API
+allows (only what a synchronisation or an event wait forces), so a consumer that lacks its wait reads stale bytes and the
+program's own comparison with the reference fails - ordering between streams, which the eager model cannot see
+(test_the_deferred_model_catches_a_missing_wait shows the checker at work).
+This is the only multi-device evidence obtainable without a multi-GPU node; the launchers' own stream protocol (kernels.hip:
+edk_verify's side stream) is replaced by the fake's and is tested on hardware only."""
 import hashlib
 import os
 import subprocess
@@ -60,8 +64,8 @@ def build(request):
     return san, out
 
 
-def run(out, exe, args, devices, timeout=900):
-    env = dict(os.environ, FAKE_HIP_DEVICES=str(devices), LD_LIBRARY_PATH=out,
+def run(out, exe, args, devices, timeout=900, defer=0):
+    env = dict(os.environ, FAKE_HIP_DEVICES=str(devices), FAKE_HIP_DEFER=str(defer), LD_LIBRARY_PATH=out,
                TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=1:abort_on_error=0",
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     r = subprocess.run([os.path.join(out, exe)] + [str(a) for a in args], env=env, capture_output=True, text=True, timeout=timeout)
@@ -71,30 +75,31 @@ def run(out, exe, args, devices, timeout=900):
     return text
 
 
-@pytest.mark.parametrize("devices", [2, 3, 8])
-def test_multi_device_entry_points_over_several_devices(build, msgs, devices):
+@pytest.mark.parametrize("devices,defer", [(2, 1), (3, 0), (8, 1)])
+def test_multi_device_entry_points_over_several_devices(build, msgs, devices, defer):
     san, out = build
     # 96 table entries (messages of 0 .. 95 bytes), unequal shards from 2^8 - 3 items
-    text = run(out, "multi_device", [os.path.join(GOLD, "ed25519_table.bin"), msgs, 96, 253], devices)
+    text = run(out, "multi_device", [os.path.join(GOLD, "ed25519_table.bin"), msgs, 96, 253], devices, defer=defer)
     assert f"multi_device: ok ({devices} devices" in text
     assert f"fake RCCL ran 1 all-gather and {devices} broadcasts over {devices} ranks" in text   # both forms of the gather ran
 
 
-def test_threaded_callers_through_the_combiner(build, msgs):
+@pytest.mark.parametrize("defer", [0, 1])
+def test_threaded_callers_through_the_combiner(build, msgs, defer):
     san, out = build
     text = run(out, "threaded_callers", [os.path.join(GOLD, "ed25519_table.bin"), msgs, os.path.join(GOLD, "x25519_table.bin"),
-                                         64, 6, 48, "trace"], 2)
+                                         64, 6, 48, "trace"], 2, defer=defer)
     assert "threaded_callers: ok" in text and " 0 wrong" in text
     import re
     launches, calls = map(int, re.findall(r"(\d+) launches carried (\d+) calls so far", text)[-1])
     assert calls > 2 * launches                                   # the calls did meet: the merging code ran
 
 
-@pytest.mark.parametrize("threads", [16])
-def test_host_pipeline_faults_trace_and_concurrent_shutdown(build, msgs, threads):
+@pytest.mark.parametrize("threads,defer", [(16, 1)])
+def test_host_pipeline_faults_trace_and_concurrent_shutdown(build, msgs, threads, defer):
     san, out = build
     text = run(out, "host_side_stress", [os.path.join(GOLD, "ed25519_table.bin"), msgs, os.path.join(GOLD, "x25519_table.bin"),
-                                         threads, 4], 2)
+                                         threads, 4], 2, defer=defer)
     assert "host_side_stress: ok" in text and "nothing left allocated in the fake runtime" in text
 
 
@@ -104,12 +109,62 @@ def test_every_runtime_call_failed_in_turn(build, msgs):
     san, out = build
     if san != "address":
         pytest.skip("one thread: the leak and bounds checks of the address build are the point")
-    text = run(out, "host_fault_walk", [os.path.join(GOLD, "ed25519_table.bin"), msgs, os.path.join(GOLD, "x25519_table.bin")], 2)
+    # (in the deferred model: the failed call's earlier work is still queued when the error path runs)
+    text = run(out, "host_fault_walk", [os.path.join(GOLD, "ed25519_table.bin"), msgs, os.path.join(GOLD, "x25519_table.bin")], 2, defer=1)
     assert "host_fault_walk: ok (2 devices)" in text
     import re
     rows = re.findall(r"host_fault_walk: (.+?)\s+(\d+) runtime calls,\s+(\d+) of them failed in turn: (\d+) came back as errors, (\d+) were absorbed", text)
     assert len(rows) == 18 and sum(int(r[2]) for r in rows) > 800, text
     assert all(int(r[2]) == int(r[3]) + int(r[4]) and int(r[3]) > 0 for r in rows)
+
+
+def test_the_deferred_model_catches_a_missing_wait(build, tmp_path):
+    """the checker checks: a download on the default stream does not wait for a NON-BLOCKING stream's kernels - the deferred
+    model hands back stale bytes (the eager one cannot), and the same code on a blocking stream, or with the wait, is right"""
+    san, out = build
+    if san != "address":
+        pytest.skip("once is enough")
+    src = tmp_path / "missing_wait.c"
+    src.write_text(r'''
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "eddsa_amd.h"
+int main(int argc, char **argv) {
+    const int blocking = atoi(argv[2]), wait = atoi(argv[3]);
+    uint8_t tab[96 * 4], got[32 * 4], *out = 0, *sc = 0, *pt = 0;
+    FILE *f = fopen(argv[1], "rb");
+    if (!f || fread(tab, 1, sizeof(tab), f) != sizeof(tab)) return 2;
+    hipStream_t st;
+    hipSetDevice(0); hipMalloc((void **)&out, 128); hipMalloc((void **)&sc, 128); hipMalloc((void **)&pt, 128);
+    for (int i = 0; i < 4; i++) { hipMemcpy(pt + 32 * i, tab + 96 * i, 32, hipMemcpyHostToDevice); hipMemcpy(sc + 32 * i, tab + 96 * i + 32, 32, hipMemcpyHostToDevice); }
+    if (blocking) hipStreamCreate(&st); else hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (x25519_batch_dev(out, sc, pt, 4, st) != 0) return 3;
+    if (wait) hipStreamSynchronize(st);
+    hipMemcpy(got, out, 128, hipMemcpyDeviceToHost);
+    int right = 1;
+    for (int i = 0; i < 4; i++) right &= memcmp(got + 32 * i, tab + 96 * i + 64, 32) == 0;
+    hipStreamSynchronize(st); hipStreamDestroy(st); hipFree(out); hipFree(sc); hipFree(pt);
+    eddsa_amd_shutdown();
+    return right ? 0 : 5;
+}
+''')
+    exe = tmp_path / "missing_wait"
+    objs = [os.path.join(out, o) for o in ("eddsa_amd.o", "host_pipe.o", "fake_kernels.o")]
+    subprocess.check_call(["g++", "-fsanitize=address,undefined", "-x", "c", "-std=c11", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", str(src),
+                           "-x", "none"] + objs + ["-o", str(exe), "-L" + out, "-lfakehip", "-Wl,-rpath," + out, "-lpthread", "-ldl"])
+    table = os.path.join(GOLD, "x25519_table.bin")
+
+    def rc(defer, blocking, wait):
+        return subprocess.run([str(exe), table, str(blocking), str(wait)], env=dict(os.environ, FAKE_HIP_DEVICES="2", FAKE_HIP_DEFER=str(defer), LD_LIBRARY_PATH=out),
+                              capture_output=True, text=True, timeout=300).returncode
+    assert rc(0, 0, 0) == 0            # eager model: the bug is invisible
+    assert rc(1, 0, 0) == 5            # deferred: stale bytes
+    assert rc(1, 0, 1) == 0            # ... the wait fixes it
+    assert rc(1, 1, 0) == 0            # ... and a blocking stream is ordered with the default stream by definition
 
 
 def test_the_fake_runtime_catches_a_buffer_on_the_wrong_device(build, tmp_path):
