@@ -14,7 +14,7 @@
  * runtime; AddressSanitizer's leak check covers the host heap).
  *
  * Walks: eddsa_amd_init on a fresh process state (engine construction, table generation); host-pointer verify (ragged
- * messages, three chunks through the lanes), sign, x25519, genpub on a warm engine and on a cold one (first use builds
+ * messages, three chunks through the lanes), the opt-in batch verification, sign, x25519, genpub on a warm engine and on a cold one (first use builds
  * the engine, the lanes and the workspaces inside the call); a one-item host call (the combiner's path); device-pointer
  * verify; eddsa_amd_init_devices + ed25519_verify_batch_multi + ed25519_verify_batch_multi_dev over every fake device,
  * the last two also with the fake RCCL's calls failed in turn (communicator set-up, group start / end, each collective).
@@ -69,6 +69,16 @@ static int op_verify(int *right)
     memset(ok, 7, sizeof(ok));
     const int rc = ed25519_verify_batch(ok, g_bad, g_pub, g_mm, g_off, 0, NE);
     *right = 1;
+    for (int i = 0; i < NE; i++) *right &= ok[i] == (i % 3 != 0);
+    return rc;
+}
+static int op_verify_rlc(int *right)             /* the opt-in batch verification's host path (its statistics travel too) */
+{
+    uint8_t ok[NE];
+    uint32_t stats[4] = { 9, 9, 9, 9 };
+    memset(ok, 7, sizeof(ok));
+    const int rc = ed25519_verify_batch_rlc(ok, stats, g_bad, g_pub, g_mm, g_off, 0, NE);
+    *right = stats[0] + stats[1] == NE;
     for (int i = 0; i < NE; i++) *right &= ok[i] == (i % 3 != 0);
     return rc;
 }
@@ -273,6 +283,9 @@ int main(int argc, char **argv)
     CHECK(op_verify(&right) == 0 && right && op_sign(&right) == 0 && right && op_x25519(&right) == 0 && right && op_genpub(&right) == 0 && right &&
           op_verify_one(&right) == 0 && right && op_verify_dev(&right) == 0 && right, "unarmed calls");
     if (walk("verify, warm", op_verify, 0, 0, NULL, 0)) return 1;
+    eddsa_amd_set_rlc_min_items(1);              /* the combination's route, whatever the size */
+    CHECK(op_verify_rlc(&right) == 0 && right, "unarmed batch verification");
+    if (walk("batch verification, warm", op_verify_rlc, 0, 0, NULL, 0)) return 1;
     if (walk("sign, warm", op_sign, 0, 1, NULL, 0)) return 1;
     if (walk("x25519, warm", op_x25519, 0, 2, NULL, 0)) return 1;
     if (walk("genpub, warm", op_genpub, 0, 1, NULL, 0)) return 1;

@@ -3,7 +3,8 @@
  * under the sanitizers against tests/fake_hip/ in the build container (it also runs against the real library):
  *
  *   1. multi-chunk pipelines on small batches (eddsa_amd_set_pipeline(48, 96): three lanes, drains, secrets wiped) for
- *      verify with RAGGED messages (the chunks' offset tables are rebased), sign and x25519 - same bytes as one chunk;
+ *      verify with RAGGED messages (the chunks' offset tables are rebased), the opt-in batch verification, sign and
+ *      x25519 - same bytes as one chunk;
  *   2. the fault hooks: inert until armed; a failed host-pointer call and a failed HIP call inside a verify pass come
  *      back as negative values, the next call works, no secret is left in a staging buffer;
  *   3. threads that issue chunked batches and single-item calls (merged by the combiner) while another thread switches the
@@ -154,6 +155,15 @@ int main(int argc, char **argv)
     CHECK(res[0] == 0 && res[2] == 0, "sign left secrets behind: %llu %llu", (unsigned long long)res[0], (unsigned long long)res[2]);
     RC(ed25519_verify_batch(ok, bad, g_pub, shifted, off5, 0, NE));
     for (int i = 0; i < NE; i++) CHECK(ok[i] == (i % 3 != 0), "chunked ragged verify: item %d", i);
+    {   /* the opt-in batch verification through the same lanes: its statistics are summed across the chunks */
+        uint32_t stats[4] = { 9, 9, 9, 9 };
+        eddsa_amd_set_rlc_min_items(1);
+        memset(ok, 7, sizeof(ok));
+        RC(ed25519_verify_batch_rlc(ok, stats, bad, g_pub, shifted, off5, 0, NE));
+        for (int i = 0; i < NE; i++) CHECK(ok[i] == (i % 3 != 0), "chunked ragged batch verification: item %d", i);
+        CHECK(stats[0] + stats[1] == NE, "batch verification statistics: %u + %u items", stats[0], stats[1]);
+        eddsa_amd_set_rlc_min_items((size_t)3 << 17);
+    }
     free(shifted);
 
     /* ---- 2b. armed: a failed call is an error return, the next one works, nothing secret stays ---- */

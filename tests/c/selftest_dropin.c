@@ -118,6 +118,7 @@ int main(int argc, char **argv)
         free(off); free(sk); free(pk); free(sig); free(chk); free(ok);
     }
     eddsa_amd_shutdown();
+    free(xt); free(et); free(msgs);
     printf("selftest_dropin: ok (%zu x25519 vectors, %zu ed25519 vectors)\n", nx, ne);
     return 0;
 }

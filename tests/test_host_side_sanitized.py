@@ -13,6 +13,7 @@ Run under -fsanitize=thread and -fsanitize=address,undefined:
   tests/c/threaded_callers.c  64 threads looping over the eddsa.h single-item functions: the flat combiner
   tests/c/host_side_stress.c  multi-chunk pipelines with ragged messages, the fault hooks, the trace switched on and off
                               under load, two concurrent shutdowns beside callers, nothing leaked
+  tests/c/selftest_dropin.c   (address build) the reference's selftests over eddsa.h and every batched entry point
   tests/c/host_fault_walk.c   (address build) every fallible runtime call of engine construction, of the host-pointer and
                               device-pointer calls (warm and cold), of the device set and of the gather - and every call
                               into the fake RCCL - failed once, one at a time: an error return or a right result, the next
@@ -57,7 +58,7 @@ def build(request):
     r = subprocess.run(["make", "-C", FAKE, "-j4", "SAN=" + san], capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     out = os.path.join(FAKE, "_build", san)
-    for exe in ("multi_device", "threaded_callers", "host_side_stress", "host_fault_walk"):
+    for exe in ("multi_device", "threaded_callers", "host_side_stress", "host_fault_walk", "selftest_dropin"):
         # test binaries against the fake runtime: they must not pull in the real one
         ldd = subprocess.check_output(["ldd", os.path.join(out, exe)], text=True)
         assert "libamdhip64" not in ldd and "libfakehip.so" in ldd, ldd
@@ -103,6 +104,16 @@ def test_host_pipeline_faults_trace_and_concurrent_shutdown(build, msgs, threads
     assert "host_side_stress: ok" in text and "nothing left allocated in the fake runtime" in text
 
 
+def test_the_reference_selftests_and_every_batched_entry_point(build, msgs):
+    """tests/c/selftest_dropin.c (the reference's four selftests over eddsa.h, records, conversions, x25519_base: the program
+    the GPU suite runs against the real library) through the unchanged host side, deferred model"""
+    san, out = build
+    if san != "address":
+        pytest.skip("one thread")
+    text = run(out, "selftest_dropin", [os.path.join(GOLD, "x25519_table.bin"), os.path.join(GOLD, "ed25519_table.bin"), msgs], 2, defer=1)
+    assert "selftest_dropin: ok (1024 x25519 vectors, 1024 ed25519 vectors)" in text
+
+
 def test_every_runtime_call_failed_in_turn(build, msgs):
     """error paths of the host side: ~850 injected failures of HIP runtime and RCCL calls, none of which may crash, hang,
     leak, leave a secret behind, report success with wrong bytes, or break the call that follows"""
@@ -114,7 +125,7 @@ def test_every_runtime_call_failed_in_turn(build, msgs):
     assert "host_fault_walk: ok (2 devices)" in text
     import re
     rows = re.findall(r"host_fault_walk: (.+?)\s+(\d+) runtime calls,\s+(\d+) of them failed in turn: (\d+) came back as errors, (\d+) were absorbed", text)
-    assert len(rows) == 18 and sum(int(r[2]) for r in rows) > 800, text
+    assert len(rows) == 19 and sum(int(r[2]) for r in rows) > 800, text
     assert all(int(r[2]) == int(r[3]) + int(r[4]) and int(r[3]) > 0 for r in rows)
 
 
