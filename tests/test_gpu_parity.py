@@ -382,6 +382,28 @@ def test_c_program_against_eddsa_h(engine, golden, tmp_path):
     assert "selftest_dropin: ok" in r.stdout
 
 
+def test_host_side_stress_program_on_the_real_runtime(engine, golden, tmp_path):
+    """tests/c/host_side_stress.c - multi-chunk pipelines on small batches (ragged verify, the opt-in batch verification,
+    sign, x25519), the fault hooks, 16 threads of chunked batches and single-item calls while the pipeline trace is switched on
+    and off, two concurrent shutdowns beside callers, no HIP call failed on a clean-up path - against the real library and
+    the real runtime, where the ordering between streams is the hardware's (the CPU suite runs the same program against the
+    fake runtime under the sanitizers)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "host_side_stress"
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-pthread", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c", "host_side_stress.c"), "-L" + os.path.join(root, "libeddsa_amd"),
+                           "-leddsa_amd", "-Wl,-rpath," + os.path.join(root, "libeddsa_amd"), "-ldl", "-o", str(exe)])
+    msgs = tmp_path / "msgs.bin"
+    msgs.write_bytes(b"".join(golden_msg(i) for i in range(1024)))
+    r = subprocess.run([str(exe), os.path.join(root, "tests", "golden", "ed25519_table.bin"), str(msgs),
+                        os.path.join(root, "tests", "golden", "x25519_table.bin"), "16", "12"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "host_side_stress: ok (16 threads" in r.stdout
+
+
 def test_threaded_c_application_on_the_single_item_functions(engine, golden, tmp_path):
     """VERDICT r02 missing #4: tests/c/threaded_callers.c, 64 pthreads looping over ed25519_verify (then a mix of
     verify / sign / x25519 / genpub) through eddsa.h only.  Every result must be the golden table's, and the calls must
