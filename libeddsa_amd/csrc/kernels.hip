@@ -307,6 +307,8 @@ k_verify_halve(const uint8_t* sigs, size_t sig_stride, size_t n, const uint32_t*
   if ((fl & 1) != 0 && !mine && i < n) offlist[atomicAdd(offcount, 1u)] = (uint32_t)i;
 }
 
+// dynamic LDS the main kernels are launched with: what keeps a third block off the CU, and where k_verify_main_half keeps its digit words
+constexpr unsigned MAIN_LDS_RESERVE = 74 * 1024;   // (2 x 74 of the CU's 160 KB: a third block does not fit, four waves of k_verify_exact_quad do)
 // (A/B builds only: -DMAIN_HALF_BLOCK=128 -DMAIN_HALF_LDS_KB=50 gives three blocks of 128 lanes per CU, 1.5 waves per
 // SIMD, a resident set of 226 MB that fits the 256 MB Infinity Cache: profiles/r03_verify_ab.txt)
 #ifndef MAIN_HALF_BLOCK
@@ -323,9 +325,26 @@ k_verify_main_half(uint8_t* ok, const uint32_t* hdigits, const uint32_t* table, 
                    const uint32_t* base16, const uint8_t* flags, size_t n, int exact_offcurve) {
   const size_t i = (size_t)blockIdx.x * MAIN_HALF_BLOCK + threadIdx.x;   // < workspace capacity
   const uint32_t* hd = hdigits + HALF_DIGIT_WORDS * (WITH_LONG && i >= n ? n - 1 : i);   // (an idle lane's own words are whatever the last pass left)
-  const bool long_loop = WITH_LONG && __any((hd[24] & 2u) != 0);
-  const bool neutral = verify_half_main_lane<WITH_LONG, WINDOWS>(hd, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
-                                             rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16, long_loop);
+  // The lane's digit words go to LDS once (word w of lane t at [w][t]: no bank conflicts).  Read from memory window by
+  // window they were the hottest lines of L2 - one per resident item, 16 MB of its 32 - and L2 is what the table lines
+  // need: its hits are worth 12 % to this kernel (profiles/r04_main_half_loads_ab.txt), and with the digits out of it the
+  // pass gained 1.5 %.  (The launch reserves MAIN_LDS_RESERVE bytes per block anyway; this uses 28 KB of them.)
+  extern __shared__ uint32_t digit_words[];
+  static_assert(HALF_DIGIT_WORDS * MAIN_HALF_BLOCK * 4 <= MAIN_LDS_RESERVE, "the digit words fit the block's LDS");
+  {
+    const uint4* g = reinterpret_cast<const uint4*>(hd);
+#pragma unroll
+    for (int q = 0; q < HALF_DIGIT_WORDS / 4; q++) {
+      const uint4 v = g[q];
+      digit_words[(4 * q) * MAIN_HALF_BLOCK + threadIdx.x] = v.x; digit_words[(4 * q + 1) * MAIN_HALF_BLOCK + threadIdx.x] = v.y;
+      digit_words[(4 * q + 2) * MAIN_HALF_BLOCK + threadIdx.x] = v.z; digit_words[(4 * q + 3) * MAIN_HALF_BLOCK + threadIdx.x] = v.w;
+    }
+  }
+  const uint32_t* hl = digit_words + threadIdx.x;
+  const bool long_loop = WITH_LONG && __any((hl[24 * MAIN_HALF_BLOCK] & 2u) != 0);
+  // a zero digit reads item 0's entry 0 - the neutral element, like every item's own: one line for the chip, not one per item
+  const bool neutral = verify_half_main_lane<WITH_LONG, WINDOWS>(hl, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
+                                             rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16, long_loop, MAIN_HALF_BLOCK, table);
   if (i >= n) return;
   const uint8_t fl = flags[i];
   if ((fl & 1) == 0) {                           // the exact path owns this verdict (or, in reject mode, nobody does)
@@ -349,7 +368,6 @@ constexpr int FINISH_K = 8;
 // waves) per CU.  Measured (profiles/r02_verify_ab.txt): the kernel itself is about 1 % FASTER that way (two
 // waves per SIMD already saturate VALU issue; fewer resident tables), and the exact path's waves fit beside
 // it on every CU without taking the place of any of its blocks.
-constexpr unsigned MAIN_LDS_RESERVE = 74 * 1024;   // (2 x 74 of the CU's 160 KB: a third block does not fit, four waves of k_verify_exact_quad do)
 
 struct finish_pos {
   size_t tile, i;            // tile index and global item index of slot k for this lane

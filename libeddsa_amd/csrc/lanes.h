@@ -452,18 +452,18 @@ ED_DEV bool verify_half_point_lane(uint32_t* tab, const uint32_t rw[8]) {
 // miss to HBM per addition otherwise).
 template <bool WITH_LONG, int WINDOWS = HALF_WINDOWS>
 ED_DEV bool verify_half_main_lane(const uint32_t* hd, const uint32_t* tab_a, const uint32_t* tab_r, const uint32_t* base16,
-                                  bool long_loop) {
+                                  bool long_loop, int hs = 1, const uint32_t* neutral = nullptr) {   // hs: distance in words between consecutive digit words (1: as k_verify_halve wrote them); neutral: a table whose entry 0 every lane may read for a zero digit (one line for the whole chip instead of one per item), or none
   ge acc;
   ge_neutral(acc);
-  const bool uneg = (hd[24] & 1u) != 0, is_long = WITH_LONG && (hd[24] & 2u) != 0;
+  const bool uneg = (hd[24 * hs] & 1u) != 0, is_long = WITH_LONG && (hd[24 * hs] & 2u) != 0;
   const int top = (WITH_LONG && long_loop ? HALF_LONG_WINDOWS : WINDOWS) - 1;
 #pragma unroll 1
   for (int w = top; w >= 0; w--) {
-    const int dv = (int)((hd[w >> 3] >> (4 * (w & 7))) & 15u) - 8;
-    const int du = (int)((hd[8 + (w >> 3)] >> (4 * (w & 7))) & 15u) - 8;
+    const int dv = (int)((hd[(w >> 3) * hs] >> (4 * (w & 7))) & 15u) - 8;
+    const int du = (int)((hd[(8 + (w >> 3)) * hs] >> (4 * (w & 7))) & 15u) - 8;
     cached_raw ra, rr;
-    cached_load_raw(ra, tab_a, (uint32_t)(dv < 0 ? -dv : dv));
-    cached_load_raw(rr, tab_r, (uint32_t)(du < 0 ? -du : du));
+    cached_load_raw(ra, neutral && dv == 0 ? neutral : tab_a, (uint32_t)(dv < 0 ? -dv : dv));
+    cached_load_raw(rr, neutral && du == 0 ? neutral : tab_r, (uint32_t)(du < 0 ? -du : du));
     const bool base_here = (w & 3) == 0 && (WITH_LONG || w < 32);
     if (w != top) {
 #pragma unroll 1
@@ -484,7 +484,7 @@ ED_DEV bool verify_half_main_lane(const uint32_t* hd, const uint32_t* tab_a, con
       for (int h = 0; h < (j < 8 ? 2 : 1); h++) {
         // short items: digit j from k*B and digit 8 + j from k*2^128*B, j < 8; long items: digit j from k*B, j < 16
         const int jj = j + 8 * h;
-        int dig = (int)((hd[16 + (jj >> 1)] >> (16 * (jj & 1))) & 0xffffu) - 32768;
+        int dig = (int)((hd[(16 + (jj >> 1)) * hs] >> (16 * (jj & 1))) & 0xffffu) - 32768;
         if (WITH_LONG) dig = (is_long ? h == 0 : j < 8) ? dig : 0;
         const uint32_t mag = (uint32_t)(dig < 0 ? -dig : dig);
         ge_niels nb;
