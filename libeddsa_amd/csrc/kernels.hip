@@ -330,7 +330,6 @@ k_verify_main_half(uint8_t* ok, const uint32_t* hdigits, const uint32_t* table, 
   // need: its hits are worth 12 % to this kernel (profiles/r04_main_half_loads_ab.txt), and with the digits out of it the
   // pass gained 1.5 %.  (The launch reserves MAIN_LDS_RESERVE bytes per block anyway; this uses 28 KB of them.)
   extern __shared__ uint32_t digit_words[];
-  static_assert(HALF_DIGIT_WORDS * MAIN_HALF_BLOCK * 4 <= MAIN_LDS_RESERVE, "the digit words fit the block's LDS");
   {
     const uint4* g = reinterpret_cast<const uint4*>(hd);
 #pragma unroll
@@ -1275,6 +1274,7 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
 #else
     constexpr unsigned half_lds = MAIN_LDS_RESERVE;
 #endif
+    static_assert(HALF_DIGIT_WORDS * MAIN_HALF_BLOCK * 4 <= half_lds, "k_verify_main_half keeps its digit words in the block's LDS");
     const unsigned hblocks = (blocks * BLOCK + MAIN_HALF_BLOCK - 1) / MAIN_HALF_BLOCK;
     if (pair_one)
       EDK_LAUNCH((k_verify_main_half<HALF_WINDOWS_SMALL, true>), dim3(hblocks), dim3(MAIN_HALF_BLOCK), half_lds, stream, ok, ws->hdigits,
