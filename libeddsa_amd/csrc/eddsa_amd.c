@@ -88,12 +88,13 @@ static void ws_release(struct vslot *v)
     if (v->ws.hdigits) HIP_NOTE(hipFree(v->ws.hdigits));
     if (v->ws.rtable) HIP_NOTE(hipFree(v->ws.rtable));
     if (v->ws.offlist) HIP_NOTE(hipFree(v->ws.offlist));
+    if (v->ws.onlist) HIP_NOTE(hipFree(v->ws.onlist));
     if (v->ws.offcount) HIP_NOTE(hipFree(v->ws.offcount));
     if (v->ws.exact_pad) HIP_NOTE(hipFree(v->ws.exact_pad));
     if (v->ws.sums) HIP_NOTE(hipFree(v->ws.sums));
     v->ws.capacity = 0;
     v->ws.digits = v->ws.table = v->ws.acc = v->ws.offlist = v->ws.offcount = v->ws.exact_pad = NULL;
-    v->ws.hdigits = v->ws.rtable = v->ws.sums = NULL;
+    v->ws.hdigits = v->ws.rtable = v->ws.sums = v->ws.onlist = NULL;
     v->ws.flags = NULL;
 }
 
@@ -156,6 +157,7 @@ static int ws_reserve(struct vslot *v, size_t items)
     TRY(hipMalloc((void **)&v->ws.rtable, cap / VERIFY_TILE * (size_t)VERIFY_TABLE_WORDS_PER_TILE * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&v->ws.flags, cap));
     TRY(hipMalloc((void **)&v->ws.offlist, cap * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&v->ws.onlist, cap * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&v->ws.offcount, 256));
     TRY(hipMemset(v->ws.offcount, 0, 256));
     TRY(hipStreamSynchronize(NULL));      /* the pass's stream does not wait for the null stream */

@@ -80,6 +80,20 @@ ED_DEV void stage_table(uint32_t* lds, const uint32_t* src, int words) {
   __syncthreads();
 }
 
+// Append to a work list: the lanes of the wave that `want` a slot get consecutive ones from ONE atomic (a pass of 2^20
+// items would otherwise send as many atomics to one address).  Callable under divergence: the ballot counts the active
+// lanes only, and the leader is one of them.
+ED_DEV uint32_t wave_append(uint32_t* counter, bool want) {
+  const uint64_t m = __ballot(want);
+  if (m == 0) return 0;
+  const unsigned lane = __lane_id();
+  const int leader = __ffsll((unsigned long long)m) - 1;
+  uint32_t base = 0;
+  if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+  base = (uint32_t)__shfl((int)base, leader);
+  return base + (uint32_t)__popcll(m & (((uint64_t)1 << lane) - 1));
+}
+
 // ---------------------------------------------------------------------------------------------
 
 // X25519 in two kernels, like the fixed-base operations: the ladder leaves (x2 : z2) in the point
@@ -159,7 +173,7 @@ __global__ void __launch_bounds__(64) k_init_comb_image(uint32_t* img, const uin
 
 __global__ void __launch_bounds__(BLOCK, 2)
 k_verify_prepare(edk_verify_src src, size_t n, uint32_t* digits,
-                 uint32_t* table, uint8_t* flags, uint32_t* offlist, uint32_t* offcount, int all_exact) {
+                 uint32_t* table, uint8_t* flags, uint32_t* onlist, uint32_t* offlist, uint32_t* offcount, int all_exact) {
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const size_t item = i < n ? i : n - 1;         // idle lanes redo the last item into their own slot
   uint32_t rw[8], aw[8], sw[8], tw[8];
@@ -179,7 +193,14 @@ k_verify_prepare(edk_verify_src src, size_t n, uint32_t* digits,
   // list (all_exact, a self-check mode: every item does, and the windowed result is not used)
   const bool windowed = oncurve && !all_exact;
   flags[i] = (uint8_t)windowed;
-  if (!windowed && i < n) offlist[atomicAdd(offcount, 1u)] = (uint32_t)i;
+  // Two work lists: the items the windowed evaluation decides (the half-length route's k_verify_halve and
+  // k_verify_main_half run over THIS list, not over the pass: a caller who sends nothing but garbage keys then pays for
+  // the exact path only, not for a windowed evaluation whose result is discarded on top), and the exact path's.
+  const bool live = i < n;
+  const uint32_t on_slot = wave_append(offcount + EDK_ONLIST_WORD, live && windowed);
+  if (live && windowed) onlist[on_slot] = (uint32_t)i;
+  const uint32_t off_slot = wave_append(offcount, live && !windowed);
+  if (live && !windowed) offlist[off_slot] = (uint32_t)i;
 }
 
 // The exact path: ed25519-sha512.c:148-181 replayed in the reference's own order for the items k_verify_prepare (and, on
@@ -209,6 +230,11 @@ constexpr int QUAD_SPREAD_WAVES = 256;           // a short work list is spread 
 #define EXACT_DENSE_LOG2 16
 #endif
 constexpr size_t EXACT_DENSE_MIN_N = (size_t)1 << EXACT_DENSE_LOG2;   // passes from this size on pack the chain's items 16 to the wave whatever their number
+#ifndef EXACT_LANE_MIN_LOG2
+#define EXACT_LANE_MIN_LOG2 15
+#endif
+constexpr size_t EXACT_LANE_MIN_LISTED = (size_t)1 << EXACT_LANE_MIN_LOG2;   // work lists from this length on go to k_verify_exact_lane_* ...
+constexpr size_t EXACT_LANE_MIN_N = (size_t)1 << 16;                          // ... in passes of at least this many items
 static_assert((size_t)EDK_EXACT_SLOTS * QUAD_ITEM_WORDS * 4 <= EDK_EXACT_PAD_BYTES, "scratchpad too small");
 static_assert(EDK_EXACT_SLOTS % QUAD_CHAIN_ITEMS == 0, "whole waves");
 
@@ -221,13 +247,15 @@ static_assert(EDK_EXACT_SLOTS % QUAD_CHAIN_ITEMS == 0, "whole waves");
 // live in LDS (33 words per item), the addends in the HBM scratchpad, one slot per quad of the grid.
 __global__ void __launch_bounds__(QUAD_CHAIN_BLOCK, 2)
 k_verify_exact_quad(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const uint32_t* digits, const uint32_t* table,
-                    const uint32_t* offlist, const uint32_t* offcount, const uint32_t* base16, uint32_t* pad, size_t first, int dense) {
+                    const uint32_t* offlist, const uint32_t* offcount, const uint32_t* base16, uint32_t* pad, size_t first, int dense,
+                    uint32_t lane_min) {
   __shared__ uint32_t lds_dig[QUAD_CHAIN_ITEMS * QUAD_DIGIT_WORDS];
   __builtin_amdgcn_s_setprio(3);                 // small passes wait for the chain: 1-3 % there; no difference beside a full k_verify_main
   // this launch's stretch of the work list: entries first .. first + EDK_EXACT_SLOTS - 1 (edk_verify launches one kernel per
   // stretch the pass could fill; all but the first find nothing to do unless the caller sent thousands of garbage keys)
   const size_t listed = *offcount;
   if (listed <= first) return;
+  if (lane_min != 0 && listed >= lane_min) return;   // a list this long belongs to the one-lane kernels (k_verify_exact_lane_*)
   const size_t count = listed - first < (size_t)EDK_EXACT_SLOTS ? listed - first : (size_t)EDK_EXACT_SLOTS;
   // items per wave: 16 in a pass whose main kernel outlasts the chain anyway (dense: the chain's total work is what counts
   // there - every wave issues the chain's 300 k instructions however few items it carries, and in the host pipeline, where
@@ -249,6 +277,46 @@ k_verify_exact_quad(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const u
   load32(rw, sigs, i, sig_stride);
   const bool same = verify_exact_chain_quad(rw, item, dig, q);
   if (q == 1) ok[i] = (uint8_t)same;
+}
+
+// The exact path for LONG work lists: one lane per item (lanes.h: verify_exact_setup_table_lane,
+// verify_exact_chain_table_lane), two kernels of persistent blocks behind the four-lane launches on the side stream.  Which
+// form serves a pass is decided on the device, by the length of the list: below `min_listed` entries these kernels end at
+// once and k_verify_exact_quad does the work (its single-wave blocks answer soonest and disturb a full main kernel least);
+// from there on it is the other way round - a wave of the four-lane chain carries 16 items through 300 k instructions, a
+// wave of this one 64 through 620 k, and a caller who sends nothing but garbage keys (47 % of random strings are no curve
+// point) is served at the rate of a kernel that fills the chip: profiles/r05_exact_lane.txt.
+// The set-up writes into the item's OWN workspace - Q + B and Q - B over entries 2 and 3 of its table, the digit string
+// over the first words of its rtable slot - which nobody reads for such an item: the windowed kernels skip it (on the
+// half-length route they do not even visit it, see k_verify_prepare) or discard what they compute from it.
+constexpr unsigned EXACT_LANE_BLOCKS = 512;      // two resident blocks per CU, each lane walks the list in strides of the grid
+__global__ void __launch_bounds__(BLOCK, 2)
+k_verify_exact_lane_setup(const uint32_t* digits, uint32_t* table, uint32_t* rtable, const uint32_t* offlist, uint32_t* offcount,
+                          const uint32_t* base16, uint32_t min_listed) {
+  const size_t listed = *offcount;
+  if (listed < min_listed) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) exact_bentry_store(offcount + EDK_BENTRY_WORD);   // (the same bytes in every pass)
+  for (size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x; g < listed; g += (size_t)gridDim.x * BLOCK) {
+    const size_t i = offlist[g];
+    verify_exact_setup_table_lane(table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), 1,
+                                  digits + 16 * i, base16 + TABLE_ENTRY_WORDS);
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK, 2)
+k_verify_exact_lane_chain(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const uint32_t* table, const uint32_t* rtable,
+                          const uint32_t* offlist, const uint32_t* offcount, uint32_t min_listed) {
+  const size_t listed = *offcount;
+  if (listed < min_listed) return;
+  for (size_t base = (size_t)blockIdx.x * BLOCK; base < listed; base += (size_t)gridDim.x * BLOCK) {
+    const size_t g = base + threadIdx.x;
+    const size_t i = offlist[g < listed ? g : listed - 1];       // an idle lane redoes the last entry
+    uint32_t rw[8];
+    load32(rw, sigs, i, sig_stride);
+    const bool same = verify_exact_chain_table_lane(rw, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), offcount + EDK_BENTRY_WORD,
+                                                    rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), 1);
+    if (g < listed) ok[i] = (uint8_t)same;
+  }
 }
 
 __global__ void __launch_bounds__(BLOCK, 4)
@@ -277,10 +345,13 @@ k_verify_main(const uint32_t* digits, const uint32_t* table, const uint32_t* bas
 // ---------------------------------------------------------------------------------------------
 template <int BITS>
 __global__ void __launch_bounds__(BLOCK, 2)
-k_verify_halve(const uint8_t* sigs, size_t sig_stride, size_t n, const uint32_t* digits, uint32_t* hdigits,
-               uint32_t* rtable, uint8_t* flags, uint32_t* offlist, uint32_t* offcount) {
-  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  const size_t item = i < n ? i : n - 1;
+k_verify_halve(const uint8_t* sigs, size_t sig_stride, const uint32_t* digits, uint32_t* hdigits,
+               uint32_t* rtable, uint8_t* flags, const uint32_t* onlist, uint32_t* offlist, uint32_t* offcount) {
+  // over the list of items the windowed evaluation decides (k_verify_prepare), not over the pass: the grid is sized for
+  // the pass, the blocks beyond the list end at once
+  const size_t slot = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (slot >= (size_t)offcount[EDK_ONLIST_WORD]) return;
+  const size_t i = onlist[slot], item = i;
   const uint8_t fl = flags[i];
   uint32_t tdig[8], sdig[8], hd[HALF_DIGIT_WORDS];
   {
@@ -290,7 +361,7 @@ k_verify_halve(const uint8_t* sigs, size_t sig_stride, size_t n, const uint32_t*
     sdig[0] = c.x; sdig[1] = c.y; sdig[2] = c.z; sdig[3] = c.w; sdig[4] = e.x; sdig[5] = e.y; sdig[6] = e.z; sdig[7] = e.w;
   }
   verify_half_scalars_lane<BITS>(hd, tdig, sdig);
-  if ((hd[24] & 4u) != 0 && i < n) atomicAdd(offcount + EDK_REFUSED_WORD, 1u);   // a pair the exact check refused: never seen (diagnostic)
+  if ((hd[24] & 4u) != 0) atomicAdd(offcount + EDK_REFUSED_WORD, 1u);   // a pair the exact check refused: never seen (diagnostic)
   uint4* o = reinterpret_cast<uint4*>(hdigits + HALF_DIGIT_WORDS * i);
 #pragma unroll
   for (int q = 0; q < HALF_DIGIT_WORDS / 4; q++) o[q] = make_uint4(hd[4 * q], hd[4 * q + 1], hd[4 * q + 2], hd[4 * q + 3]);
@@ -304,7 +375,7 @@ k_verify_halve(const uint8_t* sigs, size_t sig_stride, size_t n, const uint32_t*
   // (k_verify_main_half_quad).
   const bool mine = (fl & 1) != 0 && (hd[24] & 2u) == 0;
   flags[i] = (uint8_t)((mine ? 1 : 0) | (rvalid ? 4 : 0));
-  if ((fl & 1) != 0 && !mine && i < n) offlist[atomicAdd(offcount, 1u)] = (uint32_t)i;
+  if ((fl & 1) != 0 && !mine) offlist[atomicAdd(offcount, 1u)] = (uint32_t)i;
 }
 
 // dynamic LDS the main kernels are launched with: what keeps a third block off the CU, and where k_verify_main_half keeps its digit words
@@ -322,9 +393,12 @@ constexpr unsigned MAIN_LDS_RESERVE = 74 * 1024;   // (2 x 74 of the CU's 160 KB
 template <int WINDOWS, bool WITH_LONG = false>
 __global__ void __launch_bounds__(MAIN_HALF_BLOCK, MAIN_HALF_BLOCKS_PER_CU)
 k_verify_main_half(uint8_t* ok, const uint32_t* hdigits, const uint32_t* table, const uint32_t* rtable,
-                   const uint32_t* base16, const uint8_t* flags, size_t n, int exact_offcurve) {
-  const size_t i = (size_t)blockIdx.x * MAIN_HALF_BLOCK + threadIdx.x;   // < workspace capacity
-  const uint32_t* hd = hdigits + HALF_DIGIT_WORDS * (WITH_LONG && i >= n ? n - 1 : i);   // (an idle lane's own words are whatever the last pass left)
+                   const uint32_t* base16, const uint8_t* flags, const uint32_t* onlist, const uint32_t* offcount) {
+  // over the list of items the windowed evaluation decides (k_verify_prepare / k_verify_prepare_pair), like k_verify_halve
+  const size_t slot = (size_t)blockIdx.x * MAIN_HALF_BLOCK + threadIdx.x;
+  if (slot >= (size_t)offcount[EDK_ONLIST_WORD]) return;
+  const size_t i = onlist[slot];
+  const uint32_t* hd = hdigits + HALF_DIGIT_WORDS * i;
   // The lane's digit words go to LDS once (word w of lane t at [w][t]: no bank conflicts).  Read from memory window by
   // window they were the hottest lines of L2 - one per resident item, 16 MB of its 32 - and L2 is what the table lines
   // need: its hits are worth 12 % to this kernel (profiles/r04_main_half_loads_ab.txt), and with the digits out of it the
@@ -344,12 +418,8 @@ k_verify_main_half(uint8_t* ok, const uint32_t* hdigits, const uint32_t* table, 
   // a zero digit reads item 0's entry 0 - the neutral element, like every item's own: one line for the chip, not one per item
   const bool neutral = verify_half_main_lane<WITH_LONG, WINDOWS>(hl, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
                                              rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16, long_loop, MAIN_HALF_BLOCK, table);
-  if (i >= n) return;
   const uint8_t fl = flags[i];
-  if ((fl & 1) == 0) {                           // the exact path owns this verdict (or, in reject mode, nobody does)
-    if (!exact_offcurve) ok[i] = 0;
-    return;
-  }
+  if ((fl & 1) == 0) return;                     // k_verify_halve handed the item to the exact path, which owns its verdict
   ok[i] = (uint8_t)(neutral && (fl & 4) != 0);
 }
 
@@ -837,7 +907,7 @@ k_sk_to_x(uint8_t* out, const uint8_t* in, size_t n) {
 template <int BITS>
 __global__ void __launch_bounds__(BLOCK, 2)
 k_verify_prepare_pair(edk_verify_src src, size_t n, uint32_t* digits, uint32_t* hdigits, uint32_t* table, uint32_t* rtable,
-                      uint8_t* flags, uint32_t* offlist, uint32_t* offcount, int all_exact, unsigned point_blocks) {
+                      uint8_t* flags, uint32_t* onlist, uint32_t* offlist, uint32_t* offcount, int all_exact, unsigned point_blocks) {
   if (blockIdx.x >= point_blocks) {
     // the scalars' blocks, one lane per item: hash, reduce, search the pair.  They need nothing from the points' blocks
     // and those nothing from here: the two square-root chains of an item run BESIDE its hash and its search
@@ -879,7 +949,11 @@ k_verify_prepare_pair(edk_verify_src src, size_t n, uint32_t* digits, uint32_t* 
   if (!second) {
     const bool keep = oncurve && !all_exact;
     flags[i] = (uint8_t)((keep ? 1 : 0) | (other ? 4 : 0));
-    if (!keep) offlist[atomicAdd(offcount, 1u)] = (uint32_t)i;
+    // the two work lists of k_verify_prepare (the four-lane evaluations of small passes do not use the first)
+    const uint32_t on_slot = wave_append(offcount + EDK_ONLIST_WORD, keep);
+    if (keep) onlist[on_slot] = (uint32_t)i;
+    const uint32_t off_slot = wave_append(offcount, !keep);
+    if (!keep) offlist[off_slot] = (uint32_t)i;
   }
 }
 
@@ -1193,7 +1267,7 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   const edk_verify_src src = *srcp;
   if (n == 0) return hipSuccess;
   const unsigned blocks = (unsigned)((n + BLOCK - 1) / BLOCK);
-  EDK_DO(hipMemsetAsync(ws->offcount, 0, sizeof(uint32_t), stream));
+  EDK_DO(hipMemsetAsync(ws->offcount, 0, 2 * sizeof(uint32_t), stream));   // both work lists' lengths
   if (marks) EDK_DO(hipEventRecord(marks[0], stream));
   // algo 0: half-length scalars - the three-lane preparation and four lanes per item up to 24 576 items, the same preparation and one lane per item up to 2^18, one lane per item above;
   // 3: the mid-size arrangement at any size below 2^18;
@@ -1214,29 +1288,32 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   const bool quad_wide = half_quad && n > QUAD_WIDE_MIN_N;
   if (pair_one || quad_wide)
     EDK_LAUNCH(k_verify_prepare_pair<HALF_BITS_SMALL>, dim3(pair_point_blocks + blocks), dim3(BLOCK), 0, stream, src, n,
-               ws->digits, ws->hdigits, ws->table, ws->rtable, ws->flags, ws->offlist, ws->offcount, ws->exact_offcurve == 2,
+               ws->digits, ws->hdigits, ws->table, ws->rtable, ws->flags, ws->onlist, ws->offlist, ws->offcount, ws->exact_offcurve == 2,
                pair_point_blocks);
   else if (half_quad)
     EDK_LAUNCH(k_verify_prepare_pair<HALF_BITS>, dim3(pair_point_blocks + blocks), dim3(BLOCK), 0, stream, src, n,
-               ws->digits, ws->hdigits, ws->table, ws->rtable, ws->flags, ws->offlist, ws->offcount, ws->exact_offcurve == 2,
+               ws->digits, ws->hdigits, ws->table, ws->rtable, ws->flags, ws->onlist, ws->offlist, ws->offcount, ws->exact_offcurve == 2,
                pair_point_blocks);
   else
-    EDK_LAUNCH(k_verify_prepare, dim3(blocks), dim3(BLOCK), 0, stream, src, n, ws->digits, ws->table, ws->flags, ws->offlist, ws->offcount,
-               ws->exact_offcurve == 2);
+    EDK_LAUNCH(k_verify_prepare, dim3(blocks), dim3(BLOCK), 0, stream, src, n, ws->digits, ws->table, ws->flags, ws->onlist, ws->offlist,
+               ws->offcount, ws->exact_offcurve == 2);
   // Below HALF_WIDE_MIN_N items the pass searches pairs up to 2^138 and runs 35 windows (2 t in 10^7 without a pair instead
   // of 8.5 in 10^5; 3 % more instructions in the main kernel): an item without a short pair goes through the exact path's
   // chain, and beside a main kernel of one or two rounds of resident blocks that chain costs the pass 0.3-0.4 ms (the
   // SIMDs its waves sit on finish their tiles that much later and the grid has no slack: profiles/r04_small_grid.txt)
   if (half && wide)
-    EDK_LAUNCH(k_verify_halve<HALF_BITS_SMALL>, dim3(blocks), dim3(BLOCK), 0, stream, src.sigs, src.sig_stride, n, ws->digits,
-               ws->hdigits, ws->rtable, ws->flags, ws->offlist, ws->offcount);
+    EDK_LAUNCH(k_verify_halve<HALF_BITS_SMALL>, dim3(blocks), dim3(BLOCK), 0, stream, src.sigs, src.sig_stride, ws->digits,
+               ws->hdigits, ws->rtable, ws->flags, ws->onlist, ws->offlist, ws->offcount);
   else if (half)
-    EDK_LAUNCH(k_verify_halve<HALF_BITS>, dim3(blocks), dim3(BLOCK), 0, stream, src.sigs, src.sig_stride, n, ws->digits,
-               ws->hdigits, ws->rtable, ws->flags, ws->offlist, ws->offcount);
+    EDK_LAUNCH(k_verify_halve<HALF_BITS>, dim3(blocks), dim3(BLOCK), 0, stream, src.sigs, src.sig_stride, ws->digits,
+               ws->hdigits, ws->rtable, ws->flags, ws->onlist, ws->offlist, ws->offcount);
   if (marks) EDK_DO(hipEventRecord(marks[1], stream));
   if (bulk_done && bulk_early) EDK_DO(hipEventRecord(bulk_done, stream));   // the next pass may start beside this one's main kernel
   // the exact path depends only on what came before: it runs beside the main kernel on the side stream
   if (ws->exact_offcurve) {
+    // Passes of EXACT_LANE_MIN_N items or more hand a work list of EXACT_LANE_MIN_LISTED entries or more to the one-lane
+    // kernels; which form runs is decided on the device (the host does not know the list's length): the other ends at once.
+    const uint32_t lane_min = n >= EXACT_LANE_MIN_N ? (uint32_t)EXACT_LANE_MIN_LISTED : 0u;
     EDK_DO(hipEventRecord(ws->ev_prepared, stream));
     EDK_DO(hipStreamWaitEvent(ws->side, ws->ev_prepared, 0));
     for (size_t first = 0; first < n; first += (size_t)EDK_EXACT_SLOTS) {
@@ -1244,7 +1321,15 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
       const size_t dense = (qi + QUAD_CHAIN_ITEMS - 1) / QUAD_CHAIN_ITEMS, spread = qi < (size_t)QUAD_SPREAD_WAVES ? qi : (size_t)QUAD_SPREAD_WAVES;
       EDK_LAUNCH(k_verify_exact_quad, dim3((unsigned)(dense > spread ? dense : spread)), dim3(QUAD_CHAIN_BLOCK), 0, ws->side, ok,
                  src.sigs, src.sig_stride, ws->digits, ws->table, ws->offlist, ws->offcount, base16, ws->exact_pad, first,
-                 (int)(n >= EXACT_DENSE_MIN_N));
+                 (int)(n >= EXACT_DENSE_MIN_N), lane_min);
+      if (lane_min != 0 && first + (size_t)EDK_EXACT_SLOTS >= (size_t)lane_min) break;   // a list that reaches the next stretch is the one-lane kernels'
+    }
+    if (lane_min != 0) {
+      const unsigned lane_blocks = blocks < EXACT_LANE_BLOCKS ? blocks : EXACT_LANE_BLOCKS;
+      EDK_LAUNCH(k_verify_exact_lane_setup, dim3(lane_blocks), dim3(BLOCK), 0, ws->side, ws->digits, ws->table, ws->rtable, ws->offlist,
+                 ws->offcount, base16, lane_min);
+      EDK_LAUNCH(k_verify_exact_lane_chain, dim3(lane_blocks), dim3(BLOCK), 0, ws->side, ok, src.sigs, src.sig_stride, ws->table, ws->rtable,
+                 ws->offlist, ws->offcount, lane_min);
     }
     EDK_DO(hipEventRecord(ws->ev_exact, ws->side));
   }
@@ -1278,13 +1363,13 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
     const unsigned hblocks = (blocks * BLOCK + MAIN_HALF_BLOCK - 1) / MAIN_HALF_BLOCK;
     if (pair_one)
       EDK_LAUNCH((k_verify_main_half<HALF_WINDOWS_SMALL, true>), dim3(hblocks), dim3(MAIN_HALF_BLOCK), half_lds, stream, ok, ws->hdigits,
-                 ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
+                 ws->table, ws->rtable, base16, ws->flags, ws->onlist, ws->offcount);
     else if (wide)
       EDK_LAUNCH(k_verify_main_half<HALF_WINDOWS_SMALL>, dim3(hblocks), dim3(MAIN_HALF_BLOCK), half_lds, stream, ok, ws->hdigits,
-                 ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
+                 ws->table, ws->rtable, base16, ws->flags, ws->onlist, ws->offcount);
     else
       EDK_LAUNCH(k_verify_main_half<HALF_WINDOWS>, dim3(hblocks), dim3(MAIN_HALF_BLOCK), half_lds, stream, ok, ws->hdigits,
-                 ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
+                 ws->table, ws->rtable, base16, ws->flags, ws->onlist, ws->offcount);
     if (marks) { EDK_DO(hipEventRecord(marks[2], stream)); EDK_DO(hipEventRecord(marks[3], stream)); }
   } else {
     if (small)

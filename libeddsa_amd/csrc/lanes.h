@@ -793,6 +793,141 @@ ED_DEV bool verify_exact_lane(const uint32_t rw[8], const uint32_t sraw[8], cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// The exact path as a THROUGHPUT kernel: one lane per item, for long work lists (a caller can send nothing but keys
+// that are no curve points: ed_import never fails, ed.c:100-149).  Four lanes per item (quad_lanes.h) answer a short
+// list soonest, but a wave of 16 items issues 300 k instructions - 1.2 M lane slots per item; one lane per item
+// needs about 600 k.  Everything the chain reads is laid out by a set-up step in the item's OWN workspace, in the form
+// the windowed kernels use for their tables (one packed 128-byte entry per lookup, cached_store):
+//   tab entry 1      -Q = what k_verify_prepare left: (y-x, y+x, 2d t, 2) of the imported key, negated - the
+//                    reference's ed_add_pc operand pc(Q) (ed.c:436-442) with 2 z = 2
+//   tab entry 2, 3   Q + B, Q - B (ed.c:473-476) in cached form (scaled by a common factor, see
+//                    verify_exact_setup_reuse_lane: every formula of the chain is homogeneous in the addend)
+//   bentry           B in cached form, one entry shared by all items (EXACT_BENTRY_WORD of the work-list counters)
+//   dig              the joint sparse form of (S, t), EXACT_DIGIT_WORDS words, one nibble per step
+// and a step of the chain is ge_add_cached (the values of ed.c:175-203 ed_add / :282-305 ed_add_pc with the factors
+// 2d t2 and 2 z2 multiplied in earlier; negating the addend swaps y-x with y+x and negates 2d t2: ed_sub / ed_sub_pc,
+// ed.c:245-273, :310-335) followed by ref_double (ed.c:211-237), with the uniform control flow of ref_dual_scale_chain.
+// ---------------------------------------------------------------------------------------------
+#define EXACT_DIGIT_WORDS 33                           /* REF_JSF_LEN nibbles, eight per word */
+
+// sc.c:297-324 sc_jsf of (a, b), limb boundaries included: step k as nibble (u0 + 1) | (u1 + 1) << 2 of word k / 8 at
+// dig[(k / 8) * stride]; the nibbles past step 260 read "no digit"
+ED_DEV void exact_jsf_words(uint32_t* dig, int stride, const uint32_t aw[8], const uint32_t bw[8]) {
+  int64_t n0 = 0, n1 = 0;
+  uint32_t word = 0;
+  int k = 0;
+#pragma unroll 1
+  for (int i = 0; i < 5; i++) {
+    n0 += (int64_t)ref_limb52(aw, i);
+    n1 += (int64_t)ref_limb52(bw, i);
+#pragma unroll 1
+    for (int j = 0; j < 52; j++, k++) {
+      const int d0 = ref_jsf_digit((uint64_t)n0, (uint64_t)n1), d1 = ref_jsf_digit((uint64_t)n1, (uint64_t)n0);
+      n0 = (n0 - d0) >> 1;
+      n1 = (n1 - d1) >> 1;
+      word |= (uint32_t)((d0 + 1) | ((d1 + 1) << 2)) << (4 * (k & 7));
+      if ((k & 7) == 7) { dig[(k >> 3) * stride] = word; word = 0; }
+    }
+  }
+  {                                              // step 260 (sc.c:319-320), then "no digit" up to the end of the word
+    const int d0 = ref_jsf_digit((uint64_t)n0, (uint64_t)n1), d1 = ref_jsf_digit((uint64_t)n1, (uint64_t)n0);
+    word |= (uint32_t)((d0 + 1) | ((d1 + 1) << 2)) << (4 * (k & 7));
+    for (int z = (k & 7) + 1; z < 8; z++) word |= 5u << (4 * z);
+    dig[(k >> 3) * stride] = word;
+  }
+}
+
+// B in cached form (ed.c:46-52 pced_B with 2 z = 2), packed: the shared entry
+ED_DEV void exact_bentry_store(uint32_t* bentry) {
+  ge b;
+  ge_cached c;
+  ge_base(b);
+  ge_to_cached(c, b);
+  cached_store(bentry, 0, c);
+}
+
+// set-up of one item from what k_verify_prepare left (digit words, entry 1 of the item's table): the digit string to
+// dig, Q + B and Q - B to entries 2 and 3 of the item's table (its multiples of -A beyond the first are not needed:
+// the windowed evaluation's result for this item is discarded)
+ED_DEV void verify_exact_setup_table_lane(uint32_t* tab, uint32_t* dig, int dstride, const uint32_t* digits, const uint32_t* base1) {
+  uint32_t tw[8], sw[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { tw[k] = digits[k]; sw[k] = digits[8 + k]; }
+  words_sub_pattern(tw, 0x88888888u);
+  words_sub_pattern(sw, 0x80008000u);
+  exact_jsf_words(dig, dstride, sw, tw);
+  ge_cached c1, c;
+  cached_load(c1, tab, 1);
+  ge qp, p;                                      // Q = -A with every coordinate doubled (verify_exact_setup_reuse_lane)
+  fe_sub(qp.X, c1.ypx, c1.ymx); fe_carry(qp.X);
+  fe_add(qp.Y, c1.ypx, c1.ymx); fe_carry(qp.Y);
+  qp.Z = c1.z2;
+  fe_mul(qp.T, c1.t2d, fe_const_inv_d());
+  ge_niels pcB;
+  niels_load(pcB, base1);
+  ref_add_pc(p, qp, pcB, false);                 // Q + B
+  ge_to_cached(c, p);
+  cached_store(tab, 2, c);
+  ref_add_pc(p, qp, pcB, true);                  // Q - B
+  ge_to_cached(c, p);
+  cached_store(tab, 3, c);
+}
+
+// which entry step `nib` adds, and with which sign (ed.c:480-501): 0 = Q, 1 = B, 2 = Q+B, 3 = Q-B
+struct exact_step { int which; bool neg, skip; };
+ED_DEV exact_step exact_step_of(uint32_t nib) {
+  const int da = (int)(nib & 3u) - 1, db = (int)(nib >> 2) - 1;
+  const bool both = (da != 0) && (db != 0);
+  exact_step s;
+  s.skip = (da == 0) && (db == 0);
+  s.which = both ? (da == db ? 2 : 3) : (da != 0 ? 1 : 0);
+  s.neg = s.which == 2 ? (da < 0) : s.which == 3 ? (da > 0) : s.which == 1 ? (da < 0) : (db < 0);
+  return s;
+}
+ED_DEV const uint32_t* exact_entry_of(const exact_step& s, const uint32_t* tab, const uint32_t* bentry) {
+  // a step without digits reads the shared entry (its sum is discarded): one line for the chip, not one per item
+  return (s.skip || s.which == 1) ? bentry : tab + (s.which == 0 ? 1 : s.which) * VERIFY_ENTRY_WORDS;
+}
+
+// ed.c:479-506 + ed_export + the byte comparison (ed25519-sha512.c:176-180) for one item.  The entry of a step is
+// requested one step ahead (its latency hides behind the current step's eighteen multiplications).
+ED_DEV bool verify_exact_chain_table_lane(const uint32_t rw[8], const uint32_t* tab, const uint32_t* bentry,
+                                          const uint32_t* dig, int dstride) {
+  ge r;
+  ge_neutral(r);
+  int i = REF_JSF_LEN - 1;
+  uint32_t w = dig[(i >> 3) * dstride];
+  exact_step st = exact_step_of((w >> (4 * (i & 7))) & 15u);
+  cached_raw raw;
+  cached_load_raw(raw, exact_entry_of(st, tab, bentry), 0);
+#pragma unroll 1
+  for (;;) {
+    const exact_step cur = st;
+    ge_cached c;
+    cached_from_raw(c, raw);
+    if (i > 0) {
+      const int j = i - 1;
+      if ((j & 7) == 7) w = dig[(j >> 3) * dstride];
+      st = exact_step_of((w >> (4 * (j & 7))) & 15u);
+      cached_load_raw(raw, exact_entry_of(st, tab, bentry), 0);
+    }
+    ge sum;
+    ge_cached_cneg(c, cur.neg);
+    ge_add_cached(sum, r, c, true);
+    fe_cmov(r.X, sum.X, !cur.skip); fe_cmov(r.Y, sum.Y, !cur.skip); fe_cmov(r.Z, sum.Z, !cur.skip); fe_cmov(r.T, sum.T, !cur.skip);
+    if (i == 0) break;
+    ref_double(r, r);
+    i--;
+  }
+  uint32_t cw[8];
+  ge_tobytes(cw, r);                             // fld_inv(0) = 0 as in the reference
+  uint32_t diff = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) diff |= cw[k] ^ rw[k];
+  return diff == 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // fixed-base path: ed.c:346-430 (scale16, ed_scale_base) and its callers
 // ---------------------------------------------------------------------------------------------
 // The reference's comb (ed.c:397-430) with a wider window: x + offset is cut into COMB_DIGITS

@@ -36,7 +36,7 @@ namespace ed {
 #define QUAD_VALUE_WORDS 12                            /* 10 limbs + 2 padding words: three 16-byte loads */
 #define QUAD_ADDEND_WORDS (5 * QUAD_VALUE_WORDS)       /* y-x | y+x | 2d*t | -2d*t | 2z */
 #define QUAD_ITEM_WORDS (4 * QUAD_ADDEND_WORDS)        /* the scratchpad of an item (HBM): Q, B, Q+B, Q-B */
-#define QUAD_DIGIT_WORDS 33                            /* the digit pairs of an item (LDS): REF_JSF_LEN nibbles, eight per word */
+#define QUAD_DIGIT_WORDS EXACT_DIGIT_WORDS              /* the digit pairs of an item (LDS): REF_JSF_LEN nibbles, eight per word */
 
 // ---- set-up: one lane per item -------------------------------------------------------------------
 
@@ -83,28 +83,7 @@ ED_DEV void verify_exact_setup_quad(const uint32_t* digits, const uint32_t* tab,
     for (int k = 0; k < 8; k++) { tw[k] = digits[k]; sw[k] = digits[8 + k]; }
     words_sub_pattern(tw, 0x88888888u);
     words_sub_pattern(sw, 0x80008000u);
-    int64_t n0 = 0, n1 = 0;
-    uint32_t word = 0;
-    int k = 0;
-#pragma unroll 1
-    for (int i = 0; i < 5; i++) {
-      n0 += (int64_t)ref_limb52(sw, i);
-      n1 += (int64_t)ref_limb52(tw, i);
-#pragma unroll 1
-      for (int j = 0; j < 52; j++, k++) {
-        const int d0 = ref_jsf_digit((uint64_t)n0, (uint64_t)n1), d1 = ref_jsf_digit((uint64_t)n1, (uint64_t)n0);
-        n0 = (n0 - d0) >> 1;
-        n1 = (n1 - d1) >> 1;
-        word |= (uint32_t)((d0 + 1) | ((d1 + 1) << 2)) << (4 * (k & 7));
-        if ((k & 7) == 7) { dig[k >> 3] = word; word = 0; }
-      }
-    }
-    {                                            // step 260 (sc.c:319-320), then "no digit" up to the end of the word
-      const int d0 = ref_jsf_digit((uint64_t)n0, (uint64_t)n1), d1 = ref_jsf_digit((uint64_t)n1, (uint64_t)n0);
-      word |= (uint32_t)((d0 + 1) | ((d1 + 1) << 2)) << (4 * (k & 7));
-      for (int z = (k & 7) + 1; z < 8; z++) word |= 5u << (4 * z);
-      dig[k >> 3] = word;
-    }
+    exact_jsf_words(dig, 1, sw, tw);             // lanes.h: one nibble per step, QUAD_DIGIT_WORDS words
   } else {
     ge_cached c1;
     cached_load(c1, tab, 1);

@@ -151,6 +151,20 @@ int hc_verify_exact(const uint8_t sig[64], const uint8_t pub[32], const uint8_t*
   return verify_exact_lane(rw, sw, aw, msg, len, tables().b16() + TABLE_ENTRY_WORDS, ux, uy, pts, 1) ? 1 : 0;
 }
 
+// the exact path as the one-lane throughput kernels run it (k_verify_exact_lane_setup + _chain): set-up from what the prepare
+// step left in the item's workspace (digit words, entry 1 of its table), Q + B and Q - B into entries 2 and 3, the chain
+// over packed cached entries
+int hc_verify_exact_table(const uint8_t sig[64], const uint8_t pub[32], const uint8_t* msg, size_t len) {
+  alignas(16) uint32_t tab[VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS], bentry[VERIFY_ENTRY_WORDS];
+  uint32_t rw[8], sw[8], aw[8], tw[8], digits[16], dig[EXACT_DIGIT_WORDS];
+  rd(rw, sig); rd(sw, sig + 32); rd(aw, pub);
+  verify_prepare_lane(tw, sw, tab, rw, aw, msg, len);
+  memcpy(digits, tw, 32); memcpy(digits + 8, sw, 32);
+  exact_bentry_store(bentry);
+  verify_exact_setup_table_lane(tab, dig, 1, digits, tables().b16() + TABLE_ENTRY_WORDS);
+  return verify_exact_chain_table_lane(rw, tab, bentry, dig, 1) ? 1 : 0;
+}
+
 // ed_dual_scale in the reference's order on an arbitrary 32-byte "point" (cf. orc_ed_dual_scale)
 void hc_dual_scale_exact(uint8_t out[32], const uint8_t s[32], const uint8_t t[32], const uint8_t q[32], int uniform) {
   uint32_t w[8], sw[8], tw[8], o[8];

@@ -153,6 +153,20 @@ def test_exact_chain_for_off_curve_points(hostcheck, oracle, golden):
     for c in golden("verify_edges.json"):
         msg = H(c["msg"])
         assert hostcheck.hc_verify_exact(H(c["sig"]), H(c["pub"]), msg, SZ(len(msg))) == int(c["accept"]), c["name"]
+        # the one-lane throughput form of the same chain (k_verify_exact_lane_*: packed cached entries in the item's table)
+        assert hostcheck.hc_verify_exact_table(H(c["sig"]), H(c["pub"]), msg, SZ(len(msg))) == int(c["accept"]), c["name"]
+    # genuine signatures under garbage keys (half are no curve points), R = 0 under garbage keys (the Z = 0 corner), and
+    # genuine items: the table form decides every one as the oracle does
+    accepted = 0
+    for i in range(60):
+        sk, msg = rb(32), rb(int(rng.integers(0, 90)))
+        pk = oracle.genpub(sk)
+        sig = oracle.sign(sk, pk, msg)
+        for s_, p_ in ((sig, pk), (sig, rb(32)), (bytes(32) + rb(32), rb(32)), (rb(64), rb(32))):
+            want = int(oracle.verify(s_, p_, msg))
+            accepted += want
+            assert hostcheck.hc_verify_exact_table(s_, p_, msg, SZ(len(msg))) == want
+    assert accepted >= 60
     no_violations(hostcheck)
 
 

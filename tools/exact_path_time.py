@@ -12,7 +12,7 @@ d = lambda a: torch.from_numpy(a).cuda()
 pk = ed.ed25519_genpub_batch(d(sk)); sig = ed.ed25519_sign_batch(d(sk), pk, d(msg)); dm = d(msg)
 rng = np.random.default_rng(1)
 garbage = d(rng.integers(0, 256, (n, 32), dtype=np.uint8))
-for share in (0, 1 / 1024, 1 / 128, 1 / 16, 1 / 2):
+for share in (0, 1 / 1024, 1 / 128, 1 / 16, 1 / 4, 1 / 2, 1):
     keys = pk.clone()
     if share:
         step = int(1 / share)
