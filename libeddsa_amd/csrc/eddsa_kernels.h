@@ -24,6 +24,7 @@
 #define EDK_HALF_DIGIT_WORDS 28     /* = HALF_DIGIT_WORDS of lanes.h */
 #define EDK_REFUSED_WORD 8
 #define EDK_ONLIST_WORD 1           /* word of edk_verify_ws.offcount: the length of onlist */
+#define EDK_EXACT_UNIT_WORD 2        /* word of edk_verify_ws.offcount: the next unit of work of k_verify_exact_lane_chain */
 #define EDK_BENTRY_WORD 32          /* words 32..63 of edk_verify_ws.offcount: the base point as a packed cached entry (lanes.h: exact_bentry_store) */
 #define ACC_WORDS 40               /* point workspace per item: X, Y, Z and one slot for the finish kernels' prefix products */
 
@@ -50,8 +51,8 @@ typedef struct edk_verify_ws {
   uint32_t* offlist;  /* capacity words: the exact path's work list (keys off the curve; large passes: items without a short pair) */
   uint32_t* onlist;   /* capacity words: the items the windowed evaluation decides (every other item); the half-length route's
                          k_verify_halve / k_verify_main_half run over this list */
-  uint32_t* offcount; /* 64 words, zeroed at allocation: [0] the length of offlist, [EDK_ONLIST_WORD] the length of onlist (both zeroed
-                         by every pass), [EDK_REFUSED_WORD] half-length pairs that the exact check of lanes.h: verify_half_scalars_lane
+  uint32_t* offcount; /* 64 words, zeroed at allocation: [0] the length of offlist, [EDK_ONLIST_WORD] the length of onlist, [EDK_EXACT_UNIT_WORD]
+                         (all three zeroed by every pass), [EDK_REFUSED_WORD] half-length pairs that the exact check of lanes.h: verify_half_scalars_lane
                          refused since allocation (diagnostic), [EDK_BENTRY_WORD..] the shared entry of the one-lane exact path */
   uint32_t* exact_pad;/* EDK_EXACT_PAD_BYTES: scratchpad of k_verify_exact_quad: the addends of the items in flight, one slot per quad */
   uint32_t* sums;     /* EDK_SUMS_BYTES: the windows' sums of a small pass */

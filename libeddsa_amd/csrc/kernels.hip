@@ -289,33 +289,65 @@ k_verify_exact_quad(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const u
 // The set-up writes into the item's OWN workspace - Q + B and Q - B over entries 2 and 3 of its table, the digit string
 // over the first words of its rtable slot - which nobody reads for such an item: the windowed kernels skip it (on the
 // half-length route they do not even visit it, see k_verify_prepare) or discard what they compute from it.
-constexpr unsigned EXACT_LANE_BLOCKS = 512;      // two resident blocks per CU, each lane walks the list in strides of the grid
+// Work is handed out to WAVES, one (stretch, tile) unit at a time from a counter: a tile is 64 entries of the list, a stretch a
+// quarter of the chain (lanes.h: EXACT_SEGS), the accumulators cross from stretch to stretch through the items' workspace and
+// a wave that draws stretch s of a tile waits for the tile's stretch s - 1 (tile_done; units are drawn in the order stretch 0 of
+// every tile, stretch 1 of every tile, ..., so the wait is over before it starts unless the list is shorter than the chip).
+// Why not one chain per lane per launch slot: beside k_verify_main_half half of these blocks become resident late, and with a
+// fixed share of 4 chains of 2.5 ms each per lane the kernel's tail was 3 ms of a 17 ms pass (profiles/r05_exact_lane.txt).
+constexpr unsigned EXACT_LANE_BLOCKS = 512;      // two resident blocks per CU
+constexpr int EXACT_DIGITS_AT = 0, EXACT_STATE_AT = 64;   // words of the item's rtable slot: the digit string; the accumulator between stretches (lines of its own)
 __global__ void __launch_bounds__(BLOCK, 2)
 k_verify_exact_lane_setup(const uint32_t* digits, uint32_t* table, uint32_t* rtable, const uint32_t* offlist, uint32_t* offcount,
-                          const uint32_t* base16, uint32_t min_listed) {
+                          const uint32_t* base16, uint32_t* tile_done, uint32_t min_listed) {
   const size_t listed = *offcount;
   if (listed < min_listed) return;
   if (blockIdx.x == 0 && threadIdx.x == 0) exact_bentry_store(offcount + EDK_BENTRY_WORD);   // (the same bytes in every pass)
   for (size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x; g < listed; g += (size_t)gridDim.x * BLOCK) {
+    if ((g & 63) == 0) tile_done[g >> 6] = 0;
     const size_t i = offlist[g];
-    verify_exact_setup_table_lane(table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), 1,
-                                  digits + 16 * i, base16 + TABLE_ENTRY_WORDS);
+    verify_exact_setup_table_lane(table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS),
+                                  rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS) + EXACT_DIGITS_AT, 1, digits + 16 * i, base16 + TABLE_ENTRY_WORDS);
   }
 }
 
 __global__ void __launch_bounds__(BLOCK, 2)
-k_verify_exact_lane_chain(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const uint32_t* table, const uint32_t* rtable,
-                          const uint32_t* offlist, const uint32_t* offcount, uint32_t min_listed) {
+k_verify_exact_lane_chain(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const uint32_t* table, uint32_t* rtable,
+                          const uint32_t* offlist, uint32_t* offcount, uint32_t* tile_done, uint32_t min_listed) {
   const size_t listed = *offcount;
   if (listed < min_listed) return;
-  for (size_t base = (size_t)blockIdx.x * BLOCK; base < listed; base += (size_t)gridDim.x * BLOCK) {
-    const size_t g = base + threadIdx.x;
-    const size_t i = offlist[g < listed ? g : listed - 1];       // an idle lane redoes the last entry
+  const unsigned tiles = (unsigned)((listed + 63) / 64), units = tiles * (unsigned)EXACT_SEGS;
+  const unsigned lane = threadIdx.x & 63u;
+  // no more waves than tiles: one that drew a later stretch of a tile still in its first would only hold, waiting, a slot
+  // that a wave of k_verify_main_half could use
+  if ((blockIdx.x * (unsigned)BLOCK + threadIdx.x) / 64u >= tiles) return;
+  for (;;) {
+    unsigned u = 0;
+    if (lane == 0) u = atomicAdd(offcount + EDK_EXACT_UNIT_WORD, 1u);
+    u = (unsigned)__builtin_amdgcn_readfirstlane((int)u);
+    if (u >= units) break;
+    const unsigned seg = u / tiles, tile = u - seg * tiles;
+    if (seg > 0) {
+      // the tile's previous stretch, possibly on another CU: its stores are in L2 once its count is; the acquire drops this
+      // CU's stale lines
+      if (lane == 0)
+        while (__hip_atomic_load(tile_done + tile, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seg) __builtin_amdgcn_s_sleep(16);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    const size_t g = (size_t)tile * 64 + lane;
+    const bool live = g < listed;
+    const size_t i = offlist[live ? g : listed - 1];             // an idle lane redoes the last entry (and stores nothing)
     uint32_t rw[8];
     load32(rw, sigs, i, sig_stride);
-    const bool same = verify_exact_chain_table_lane(rw, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), offcount + EDK_BENTRY_WORD,
-                                                    rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), 1);
-    if (g < listed) ok[i] = (uint8_t)same;
+    uint32_t* slot = rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS);
+    const bool same = verify_exact_chain_segment_lane((int)seg, rw, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), offcount + EDK_BENTRY_WORD,
+                                                      slot + EXACT_DIGITS_AT, 1, slot + EXACT_STATE_AT, live);
+    if (seg == (unsigned)EXACT_SEGS - 1) {
+      if (live) ok[i] = (uint8_t)same;
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");         // every lane's accumulator is out before the count says so
+      if (lane == 0) __hip_atomic_fetch_add(tile_done + tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -1267,7 +1299,7 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   const edk_verify_src src = *srcp;
   if (n == 0) return hipSuccess;
   const unsigned blocks = (unsigned)((n + BLOCK - 1) / BLOCK);
-  EDK_DO(hipMemsetAsync(ws->offcount, 0, 2 * sizeof(uint32_t), stream));   // both work lists' lengths
+  EDK_DO(hipMemsetAsync(ws->offcount, 0, 3 * sizeof(uint32_t), stream));   // both work lists' lengths and the one-lane exact path's unit counter
   if (marks) EDK_DO(hipEventRecord(marks[0], stream));
   // algo 0: half-length scalars - the three-lane preparation and four lanes per item up to 24 576 items, the same preparation and one lane per item up to 2^18, one lane per item above;
   // 3: the mid-size arrangement at any size below 2^18;
@@ -1326,10 +1358,11 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
     }
     if (lane_min != 0) {
       const unsigned lane_blocks = blocks < EXACT_LANE_BLOCKS ? blocks : EXACT_LANE_BLOCKS;
+      // (the scratchpad of the four-lane chain is free when these run: it holds their per-tile counts)
       EDK_LAUNCH(k_verify_exact_lane_setup, dim3(lane_blocks), dim3(BLOCK), 0, ws->side, ws->digits, ws->table, ws->rtable, ws->offlist,
-                 ws->offcount, base16, lane_min);
+                 ws->offcount, base16, ws->exact_pad, lane_min);
       EDK_LAUNCH(k_verify_exact_lane_chain, dim3(lane_blocks), dim3(BLOCK), 0, ws->side, ok, src.sigs, src.sig_stride, ws->table, ws->rtable,
-                 ws->offlist, ws->offcount, lane_min);
+                 ws->offlist, ws->offcount, ws->exact_pad, lane_min);
     }
     EDK_DO(hipEventRecord(ws->ev_exact, ws->side));
   }

@@ -810,27 +810,52 @@ ED_DEV bool verify_exact_lane(const uint32_t rw[8], const uint32_t sraw[8], cons
 // ---------------------------------------------------------------------------------------------
 #define EXACT_DIGIT_WORDS 33                           /* REF_JSF_LEN nibbles, eight per word */
 
-// sc.c:297-324 sc_jsf of (a, b), limb boundaries included: step k as nibble (u0 + 1) | (u1 + 1) << 2 of word k / 8 at
+// sc.c:272-281 jsfdigit without branches, from the low three bits of a and the low two of b: 0 for even a, else
+// 2 - (a mod 4), negated when a mod 8 is 3 or 5 and b mod 4 is 2
+ED_DEV int exact_jsf_digit(uint32_t a, uint32_t b) {
+  const int u = (int)(a & 1u) - 2 * (int)(a & (a >> 1) & 1u);
+  const uint32_t flip = a & ((a >> 1) ^ (a >> 2)) & (b >> 1) & ~b & 1u;
+  return flip ? -u : u;
+}
+
+// limb I (52 bits) of a reduced scalar held as eight 32-bit words (sc.h:26 in the 64-bit build); I is a constant, so
+// this is a shift or two (ref_limb52 walks the bits: it serves the host build and the layer probe)
+template <int I>
+ED_DEV uint64_t exact_limb52(const uint32_t w[8]) {
+  constexpr int lo = 52 * I, k = lo >> 5, sh = lo & 31;
+  uint64_t v = ((uint64_t)w[k] | ((uint64_t)(k + 1 < 8 ? w[k + 1 < 8 ? k + 1 : 7] : 0u) << 32)) >> sh;
+  if (sh + 52 > 64 && k + 2 < 8) v |= (uint64_t)w[k + 2 < 8 ? k + 2 : 7] << (64 - sh);
+  return v & (((uint64_t)1 << 52) - 1);
+}
+
+// sc.c:297-324 sc_jsf of (a, b), limb boundaries included (a limb joins the running value only when its turn comes, so the
+// look-ahead of jsfdigit does not see across the boundary): step k as nibble (u0 + 1) | (u1 + 1) << 2 of word k / 8 at
 // dig[(k / 8) * stride]; the nibbles past step 260 read "no digit"
-ED_DEV void exact_jsf_words(uint32_t* dig, int stride, const uint32_t aw[8], const uint32_t bw[8]) {
-  int64_t n0 = 0, n1 = 0;
-  uint32_t word = 0;
-  int k = 0;
+template <int I>
+ED_DEV void exact_jsf_limb(uint32_t* dig, int stride, uint64_t& n0, uint64_t& n1, uint32_t& word, const uint32_t aw[8], const uint32_t bw[8]) {
+  n0 += exact_limb52<I>(aw);                     // (the running values stay non-negative: a digit of 1 is taken from an odd value)
+  n1 += exact_limb52<I>(bw);
 #pragma unroll 1
-  for (int i = 0; i < 5; i++) {
-    n0 += (int64_t)ref_limb52(aw, i);
-    n1 += (int64_t)ref_limb52(bw, i);
-#pragma unroll 1
-    for (int j = 0; j < 52; j++, k++) {
-      const int d0 = ref_jsf_digit((uint64_t)n0, (uint64_t)n1), d1 = ref_jsf_digit((uint64_t)n1, (uint64_t)n0);
-      n0 = (n0 - d0) >> 1;
-      n1 = (n1 - d1) >> 1;
-      word |= (uint32_t)((d0 + 1) | ((d1 + 1) << 2)) << (4 * (k & 7));
-      if ((k & 7) == 7) { dig[(k >> 3) * stride] = word; word = 0; }
-    }
+  for (int j = 0; j < 52; j++) {
+    const int k = 52 * I + j;
+    const int d0 = exact_jsf_digit((uint32_t)n0, (uint32_t)n1), d1 = exact_jsf_digit((uint32_t)n1, (uint32_t)n0);
+    n0 = (uint64_t)((int64_t)(n0 - (uint64_t)(int64_t)d0) >> 1);
+    n1 = (uint64_t)((int64_t)(n1 - (uint64_t)(int64_t)d1) >> 1);
+    word |= (uint32_t)((d0 + 1) | ((d1 + 1) << 2)) << (4 * (k & 7));
+    if ((k & 7) == 7) { dig[(k >> 3) * stride] = word; word = 0; }
   }
+}
+ED_DEV void exact_jsf_words(uint32_t* dig, int stride, const uint32_t aw[8], const uint32_t bw[8]) {
+  uint64_t n0 = 0, n1 = 0;
+  uint32_t word = 0;
+  exact_jsf_limb<0>(dig, stride, n0, n1, word, aw, bw);
+  exact_jsf_limb<1>(dig, stride, n0, n1, word, aw, bw);
+  exact_jsf_limb<2>(dig, stride, n0, n1, word, aw, bw);
+  exact_jsf_limb<3>(dig, stride, n0, n1, word, aw, bw);
+  exact_jsf_limb<4>(dig, stride, n0, n1, word, aw, bw);
   {                                              // step 260 (sc.c:319-320), then "no digit" up to the end of the word
-    const int d0 = ref_jsf_digit((uint64_t)n0, (uint64_t)n1), d1 = ref_jsf_digit((uint64_t)n1, (uint64_t)n0);
+    constexpr int k = 260;
+    const int d0 = exact_jsf_digit((uint32_t)n0, (uint32_t)n1), d1 = exact_jsf_digit((uint32_t)n1, (uint32_t)n0);
     word |= (uint32_t)((d0 + 1) | ((d1 + 1) << 2)) << (4 * (k & 7));
     for (int z = (k & 7) + 1; z < 8; z++) word |= 5u << (4 * z);
     dig[(k >> 3) * stride] = word;
@@ -889,13 +914,10 @@ ED_DEV const uint32_t* exact_entry_of(const exact_step& s, const uint32_t* tab, 
   return (s.skip || s.which == 1) ? bentry : tab + (s.which == 0 ? 1 : s.which) * VERIFY_ENTRY_WORDS;
 }
 
-// ed.c:479-506 + ed_export + the byte comparison (ed25519-sha512.c:176-180) for one item.  The entry of a step is
-// requested one step ahead (its latency hides behind the current step's eighteen multiplications).
-ED_DEV bool verify_exact_chain_table_lane(const uint32_t rw[8], const uint32_t* tab, const uint32_t* bentry,
-                                          const uint32_t* dig, int dstride) {
-  ge r;
-  ge_neutral(r);
-  int i = REF_JSF_LEN - 1;
+// ed.c:479-506, steps hi .. lo of the chain (260 .. 0 is all of it): r = the accumulator on entry and on exit.  The entry of a
+// step is requested one step ahead (its latency hides behind the current step's eighteen multiplications).
+ED_DEV void exact_chain_steps(ge& r, const uint32_t* tab, const uint32_t* bentry, const uint32_t* dig, int dstride, int hi, int lo) {
+  int i = hi;
   uint32_t w = dig[(i >> 3) * dstride];
   exact_step st = exact_step_of((w >> (4 * (i & 7))) & 15u);
   cached_raw raw;
@@ -905,7 +927,7 @@ ED_DEV bool verify_exact_chain_table_lane(const uint32_t rw[8], const uint32_t* 
     const exact_step cur = st;
     ge_cached c;
     cached_from_raw(c, raw);
-    if (i > 0) {
+    if (i > lo) {
       const int j = i - 1;
       if ((j & 7) == 7) w = dig[(j >> 3) * dstride];
       st = exact_step_of((w >> (4 * (j & 7))) & 15u);
@@ -915,16 +937,75 @@ ED_DEV bool verify_exact_chain_table_lane(const uint32_t rw[8], const uint32_t* 
     ge_cached_cneg(c, cur.neg);
     ge_add_cached(sum, r, c, true);
     fe_cmov(r.X, sum.X, !cur.skip); fe_cmov(r.Y, sum.Y, !cur.skip); fe_cmov(r.Z, sum.Z, !cur.skip); fe_cmov(r.T, sum.T, !cur.skip);
-    if (i == 0) break;
-    ref_double(r, r);
+    if (i != 0) ref_double(r, r);                // ed.c:503-505: no doubling after the last digit
+    if (i == lo) break;
     i--;
   }
+}
+
+// The chain in EXACT_SEGS stretches of steps, so that a wave's unit of work is a quarter of a chain: the kernel hands the
+// (stretch, tile) units out one by one and the pass ends within a stretch's time of its last unit instead of a chain's
+// (kernels.hip: k_verify_exact_lane_chain).  The accumulator crosses from one stretch to the next through the item's
+// own workspace.
+constexpr int EXACT_SEGS = 4;
+ED_DEV constexpr int exact_seg_hi(int seg) { return REF_JSF_LEN - 1 - seg * ((REF_JSF_LEN + EXACT_SEGS - 1) / EXACT_SEGS); }
+ED_DEV constexpr int exact_seg_lo(int seg) { return seg == EXACT_SEGS - 1 ? 0 : exact_seg_hi(seg + 1) + 1; }
+#define EXACT_STATE_WORDS 40                           /* X | Y | Z | T, ten limbs each */
+ED_DEV void exact_state_store(uint32_t* st, const ge& r) {
+  word4* p = reinterpret_cast<word4*>(st);
+  const fe* f[4] = {&r.X, &r.Y, &r.Z, &r.T};
+  uint32_t w[EXACT_STATE_WORDS];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int j = 0; j < 10; j++) w[10 * k + j] = f[k]->v[j];
+#pragma unroll
+  for (int q = 0; q < EXACT_STATE_WORDS / 4; q++) p[q] = word4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+}
+ED_DEV void exact_state_load(ge& r, const uint32_t* st) {
+  const word4* p = reinterpret_cast<const word4*>(st);
+  fe* f[4] = {&r.X, &r.Y, &r.Z, &r.T};
+  uint32_t w[EXACT_STATE_WORDS];
+#pragma unroll
+  for (int q = 0; q < EXACT_STATE_WORDS / 4; q++) { const word4 v = p[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int j = 0; j < 10; j++) f[k]->v[j] = w[10 * k + j];
+}
+
+// ed_export + the byte comparison (ed25519-sha512.c:176-180)
+ED_DEV bool exact_chain_verdict(const ge& r, const uint32_t rw[8]) {
   uint32_t cw[8];
   ge_tobytes(cw, r);                             // fld_inv(0) = 0 as in the reference
   uint32_t diff = 0;
 #pragma unroll
   for (int k = 0; k < 8; k++) diff |= cw[k] ^ rw[k];
   return diff == 0;
+}
+
+// one stretch of one item: state = the accumulator between stretches (EXACT_STATE_WORDS words of the item's workspace);
+// returns the verdict after the last stretch (false before)
+ED_DEV bool verify_exact_chain_segment_lane(int seg, const uint32_t rw[8], const uint32_t* tab, const uint32_t* bentry,
+                                            const uint32_t* dig, int dstride, uint32_t* state, bool live) {
+  ge r;
+  if (seg == 0) ge_neutral(r); else exact_state_load(r, state);
+  // (the bounds are runtime values on purpose: one copy of the loop, whatever the stretch)
+  const int hi = seg == 0 ? exact_seg_hi(0) : seg == 1 ? exact_seg_hi(1) : seg == 2 ? exact_seg_hi(2) : exact_seg_hi(3);
+  const int lo = seg == 0 ? exact_seg_lo(0) : seg == 1 ? exact_seg_lo(1) : seg == 2 ? exact_seg_lo(2) : exact_seg_lo(3);
+  static_assert(EXACT_SEGS == 4, "the selects above list the stretches");
+  exact_chain_steps(r, tab, bentry, dig, dstride, hi, lo);
+  if (seg != EXACT_SEGS - 1) { if (live) exact_state_store(state, r); return false; }
+  return exact_chain_verdict(r, rw);
+}
+
+// the whole chain of one item in one go (host build; the kernels run it stretch by stretch)
+ED_DEV bool verify_exact_chain_table_lane(const uint32_t rw[8], const uint32_t* tab, const uint32_t* bentry,
+                                          const uint32_t* dig, int dstride) {
+  ge r;
+  ge_neutral(r);
+  exact_chain_steps(r, tab, bentry, dig, dstride, REF_JSF_LEN - 1, 0);
+  return exact_chain_verdict(r, rw);
 }
 
 // ---------------------------------------------------------------------------------------------

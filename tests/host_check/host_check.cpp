@@ -162,7 +162,45 @@ int hc_verify_exact_table(const uint8_t sig[64], const uint8_t pub[32], const ui
   memcpy(digits, tw, 32); memcpy(digits + 8, sw, 32);
   exact_bentry_store(bentry);
   verify_exact_setup_table_lane(tab, dig, 1, digits, tables().b16() + TABLE_ENTRY_WORDS);
-  return verify_exact_chain_table_lane(rw, tab, bentry, dig, 1) ? 1 : 0;
+  const bool whole = verify_exact_chain_table_lane(rw, tab, bentry, dig, 1);
+  // ... and stretch by stretch with the accumulator handed on through memory, as k_verify_exact_lane_chain runs it
+  alignas(16) uint32_t state[EXACT_STATE_WORDS];
+  bool staged = false;
+  for (int seg = 0; seg < EXACT_SEGS; seg++) staged = verify_exact_chain_segment_lane(seg, rw, tab, bentry, dig, 1, state, true);
+  if (staged != whole) return 2;
+  return whole ? 1 : 0;
+}
+
+// ed_dual_scale (s B + t Q, ed.c:455-507) on an arbitrary 32-byte "point" through the table form of the chain: what the
+// one-lane kernels compute, as bytes - for a Q that is no curve point the bytes depend on the digit string and on the order
+// of the formulas, which a verdict hardly ever shows
+void hc_dual_scale_exact_table(uint8_t out[32], const uint8_t s[32], const uint8_t t[32], const uint8_t q[32], int staged) {
+  alignas(16) uint32_t tab[VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS], bentry[VERIFY_ENTRY_WORDS], state[EXACT_STATE_WORDS];
+  uint32_t w[8], digits[16], dig[EXACT_DIGIT_WORDS], o[8];
+  sc x, y;
+  rd(w, s); sc_from_words<8>(x, w); sc_to_words(digits + 8, x);
+  rd(w, t); sc_from_words<8>(y, w); sc_to_words(digits, y);
+  words_add_pattern(digits, 0x88888888u);        // as k_verify_prepare leaves them
+  words_add_pattern(digits + 8, 0x80008000u);
+  rd(w, q);
+  ge Q, R; bool oc;
+  ge_frombytes(Q, oc, w, false);
+  ge_cached c;
+  ge_to_cached(c, Q);
+  cached_store(tab, 1, c);
+  exact_bentry_store(bentry);
+  verify_exact_setup_table_lane(tab, dig, 1, digits, tables().b16() + TABLE_ENTRY_WORDS);
+  if (staged) {
+    for (int seg = 0; seg < EXACT_SEGS; seg++) {
+      if (seg == 0) ge_neutral(R); else exact_state_load(R, state);
+      exact_chain_steps(R, tab, bentry, dig, 1, exact_seg_hi(seg), exact_seg_lo(seg));
+      exact_state_store(state, R);
+    }
+  } else {
+    ge_neutral(R);
+    exact_chain_steps(R, tab, bentry, dig, 1, REF_JSF_LEN - 1, 0);
+  }
+  ge_tobytes(o, R); wr(out, o);
 }
 
 // ed_dual_scale in the reference's order on an arbitrary 32-byte "point" (cf. orc_ed_dual_scale)

@@ -141,6 +141,7 @@ def test_exact_chain_for_off_curve_points(hostcheck, oracle, golden):
     for uniform in (0, 1):
         for s, t, q, r in k["ed_dual_scale"]:
             assert call(hostcheck, "hc_dual_scale_exact", 32, H(s), H(t), H(q), uniform).hex() == r
+            assert call(hostcheck, "hc_dual_scale_exact_table", 32, H(s), H(t), H(q), uniform).hex() == r
         for i in range(120):
             s, t, q = rb(32), rb(32), rb(32)
             if i % 9 == 0: s = bytes(32)
@@ -148,6 +149,8 @@ def test_exact_chain_for_off_curve_points(hostcheck, oracle, golden):
             want = ctypes.create_string_buffer(32)
             oracle.lib.orc_ed_dual_scale(want, s, t, q)
             assert call(hostcheck, "hc_dual_scale_exact", 32, s, t, q, uniform) == want.raw
+            # the table form of the one-lane kernels, in one go and stretch by stretch
+            assert call(hostcheck, "hc_dual_scale_exact_table", 32, s, t, q, uniform) == want.raw
             off += call(hostcheck, "hc_ed_import_export", 32, q) is not None and hostcheck.hc_ed_import_export(ctypes.create_string_buffer(32), q) == 0
     assert off > 60                                   # plenty of genuinely off-curve inputs were exercised
     for c in golden("verify_edges.json"):
