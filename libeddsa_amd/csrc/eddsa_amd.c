@@ -578,9 +578,11 @@ int verify_on(struct engine *e, uint8_t *ok, const edk_verify_src *all, size_t n
     v->ws.algo = g_offcurve_mode ? g_verify_algo : 1;   /* the reject mode has no exact path for the items the pair search gives up on */
     /* the slot may have served another stream: order this pass behind its previous one */
     TRY(hipStreamWaitEvent(st, v->free, 0));
+    edk_verify_src whole = *all;
+    if (whole.msg_off && !whole.msg_end) whole.msg_end = whole.msg_off + n;   /* the kernels clamp every span into [0, msg_off[n]) */
     for (size_t done = 0; done < n; done += CHUNK_MAX) {
         size_t m = n - done < CHUNK_MAX ? n - done : CHUNK_MAX;
-        edk_verify_src src = *all;
+        edk_verify_src src = whole;
         src.sigs += done * all->sig_stride;
         src.pubs += done * all->pub_stride;
         if (all->msg_off) src.msg_off += done; else src.msgs += done * all->msg_stride;
@@ -618,14 +620,14 @@ unlock:
     return rc;
 }
 
-struct sign_ctx { uint8_t *sigs; const uint8_t *secs, *pubs, *msgs; const uint64_t *msg_off; size_t msg_len; };
+struct sign_ctx { uint8_t *sigs; const uint8_t *secs, *pubs, *msgs; const uint64_t *msg_off, *msg_end; size_t msg_len; };
 
 static hipError_t sign_step(struct engine *e, size_t done, size_t m, const void *vctx, const edk_fixed_ws *fws, hipStream_t st)
 {
     const struct sign_ctx *c = (const struct sign_ctx *)vctx;
     const uint8_t *mp = c->msg_off ? c->msgs : c->msgs + done * c->msg_len;
     const uint64_t *op = c->msg_off ? c->msg_off + done : NULL;
-    return edk_sign(c->sigs + 64 * done, c->secs + 32 * done, c->pubs + 32 * done, mp, op, c->msg_len, m,
+    return edk_sign(c->sigs + 64 * done, c->secs + 32 * done, c->pubs + 32 * done, mp, op, c->msg_end, c->msg_len, m,
                     e->comb_img, fws, st);
 }
 
@@ -654,7 +656,7 @@ static hipError_t xbase_step(struct engine *e, size_t done, size_t m, const void
 int sign_on(struct engine *e, uint8_t *sigs, const uint8_t *secs, const uint8_t *pubs, const uint8_t *msgs,
                    const uint64_t *msg_off, size_t msg_len, size_t n, hipStream_t st)
 {
-    struct sign_ctx c = { sigs, secs, pubs, msgs, msg_off, msg_len };
+    struct sign_ctx c = { sigs, secs, pubs, msgs, msg_off, msg_off ? msg_off + n : NULL, msg_len };   /* spans are clamped into [0, msg_off[n]) */
     return fixed_on(e, n, sign_step, &c, st);
 }
 
@@ -716,9 +718,11 @@ int rlc_on(struct engine *e, uint8_t *ok, uint32_t *stats, const edk_verify_src 
     v->ws.exact_offcurve = g_offcurve_mode ? g_offcurve_mode : 1;
     v->ws.algo = g_verify_algo;
     TRY(hipStreamWaitEvent(st, v->free, 0));
+    edk_verify_src whole = *all;
+    if (whole.msg_off && !whole.msg_end) whole.msg_end = whole.msg_off + n;
     for (size_t done = 0; done < n; done += CHUNK_MAX) {
         size_t m = n - done < CHUNK_MAX ? n - done : CHUNK_MAX;
-        edk_verify_src src = *all;
+        edk_verify_src src = whole;
         src.sigs += done * all->sig_stride;
         src.pubs += done * all->pub_stride;
         if (all->msg_off) src.msg_off += done; else src.msgs += done * all->msg_stride;
@@ -752,7 +756,7 @@ release:
 int ed25519_verify_batch_dev(uint8_t *ok, const uint8_t *sigs, const uint8_t *pubs, const uint8_t *msgs,
                              const uint64_t *msg_off, size_t msg_len, size_t n, void *stream)
 {
-    const edk_verify_src src = { sigs, pubs, msgs, msg_off, msg_len, 64, 32, msg_len };
+    const edk_verify_src src = { sigs, pubs, msgs, msg_off, msg_len, 64, 32, msg_len, NULL };
     DEV_ENTER(ok);
     rc = verify_on(c.e, ok, &src, n, (hipStream_t)stream, NULL, 0);
     leave(&c);
@@ -771,7 +775,7 @@ int ed25519_verify_records_dev(uint8_t *ok, const uint8_t *records, size_t strid
 {
     if (!records_ok(stride, sig_off, pub_off, msg_off, msg_len)) return -(int)hipErrorInvalidValue;
     const edk_verify_src src = { records + sig_off, records + pub_off, records + msg_off, NULL, msg_len,
-                                 stride, stride, stride };
+                                 stride, stride, stride, NULL };
     DEV_ENTER(ok);
     rc = verify_on(c.e, ok, &src, n, (hipStream_t)stream, NULL, 0);
     leave(&c);
@@ -781,7 +785,7 @@ int ed25519_verify_records_dev(uint8_t *ok, const uint8_t *records, size_t strid
 int ed25519_verify_batch_rlc_dev(uint8_t *ok, uint32_t *stats, const uint8_t *sigs, const uint8_t *pubs,
                                  const uint8_t *msgs, const uint64_t *msg_off, size_t msg_len, size_t n, void *stream)
 {
-    const edk_verify_src src = { sigs, pubs, msgs, msg_off, msg_len, 64, 32, msg_len };
+    const edk_verify_src src = { sigs, pubs, msgs, msg_off, msg_len, 64, 32, msg_len, NULL };
     DEV_ENTER(ok);
     rc = rlc_on(c.e, ok, stats, &src, n, (hipStream_t)stream);
     leave(&c);
@@ -942,7 +946,7 @@ int ed25519_verify_batch_multi_dev(uint8_t *const ok_full[], const uint8_t *cons
         size_t lo, hi;
         eddsa_amd_shard_bounds(n_total, d, g, &lo, &hi);
         if (hi - lo != n_total / (size_t)g) even = 0;
-        const edk_verify_src src = { sigs[d], pubs[d], msgs[d], NULL, msg_len, 64, 32, msg_len };
+        const edk_verify_src src = { sigs[d], pubs[d], msgs[d], NULL, msg_len, 64, 32, msg_len, NULL };
         TRY(hipSetDevice(g_multi.dev[d]));
         rc = verify_on(g_eng[g_multi.dev[d]], ok_full[d] + lo, &src, hi - lo, (hipStream_t)streams[d], NULL, 0);
     }

@@ -69,6 +69,8 @@ typedef struct {
   const uint8_t *sigs, *pubs, *msgs;
   const uint64_t* msg_off;
   size_t msg_len, sig_stride, pub_stride, msg_stride;
+  const uint64_t* msg_end;   /* ragged messages: the LAST entry of the call's offset table = the size of the message buffer; every
+                                item's span is clamped into it (lanes.h: msg_span).  verify_on / rlc_on fill it in. */
 } edk_verify_src;
 
 /* bulk_done (or NULL): recorded on `stream` once every kernel that fills the chip has been queued, before the stream
@@ -108,8 +110,9 @@ hipError_t edk_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* point
                       const edk_fixed_ws* ws, hipStream_t stream);
 hipError_t edk_genpub(uint8_t* pubs, const uint8_t* secs, size_t n, const uint32_t* comb,
                       const edk_fixed_ws* ws, hipStream_t stream);
+/* msg_end: as in edk_verify_src (NULL with msg_off == NULL) */
 hipError_t edk_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, const uint8_t* msgs,
-                    const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* comb,
+                    const uint64_t* msg_off, const uint64_t* msg_end, size_t msg_len, size_t n, const uint32_t* comb,
                     const edk_fixed_ws* ws, hipStream_t stream);
 hipError_t edk_x25519_base(uint8_t* out, const uint8_t* scalars, size_t n, const uint32_t* comb,
                            const edk_fixed_ws* ws, hipStream_t stream);

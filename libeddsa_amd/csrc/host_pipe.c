@@ -485,6 +485,18 @@ int eddsa_amd_debug_fail_next_host_call(void)
  *     against 79-86 in order).
  * `kdone` is recorded before a verify pass waits for its exact path, so that those few latency-bound waves never hold
  * up the next chunk (each lane's stream has its own workspace). */
+/* A ragged call's offset table (m + 1 entries of the caller's memory) must not decrease, and the bytes it spans must be an
+ * amount a buffer can hold: everything below takes msg_off[k + 1] - msg_off[k] for a length.  Checked chunk by chunk, right
+ * before the chunk's offsets are first used (the walk of chunk k runs beside the GPU work of chunk k - 1); a table that
+ * fails ends the call with -hipErrorInvalidValue before a byte of that chunk is read. */
+#define MSG_BYTES_MAX ((uint64_t)1 << 46)
+static int offsets_ok(const uint64_t *off, size_t m)
+{
+    uint64_t bad = 0;
+    for (size_t t = 0; t < m; t++) bad |= (uint64_t)(off[t + 1] < off[t]);
+    return !bad && off[m] - off[0] <= MSG_BYTES_MAX;
+}
+
 static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
 {
     int rc = 0, wipes = 0;
@@ -519,6 +531,7 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
             size_t m = first << (k < 8 ? k : 8);
             if (m > stage) m = stage;
             if (!all || m > n - lo || n - lo - m < m / 2) m = n - lo;   /* (a short tail travels with the last chunk) */
+            if (ragged && !offsets_ok(j->msg_off + lo, m)) { rc = -(int)hipErrorInvalidValue; goto out; }   /* before anything of the chunk is staged */
             /* the lane's previous chunk (k - 3): the two chunks after it keep the GPU busy meanwhile */
             if (k >= PIPE_LANES && (rc = lane_drain(L, j->wipe, NULL))) goto out;    /* (every call leaves its lanes drained) */
             TRACE(1, k);
@@ -863,19 +876,19 @@ static int pipe_run(const struct hjob *j, size_t n)
 static int run_verify(RUN_ARGS)
 {
     (void)j;
-    const edk_verify_src src = { d_in[0], d_in[1], d_msgs, d_off, msg_len, 64, 32, msg_len };
+    const edk_verify_src src = { d_in[0], d_in[1], d_msgs, d_off, msg_len, 64, 32, msg_len, NULL };
     return verify_on(e, d_out, &src, m, st, kdone, g_pipe_chain == 2);
 }
 static int run_verify_rlc(RUN_ARGS)
 {
-    const edk_verify_src src = { d_in[0], d_in[1], d_msgs, d_off, msg_len, 64, 32, msg_len };
+    const edk_verify_src src = { d_in[0], d_in[1], d_msgs, d_off, msg_len, 64, 32, msg_len, NULL };
     RUN_DONE(rlc_on(e, d_out, j->stats, &src, m, st));
 }
 static int run_verify_records(RUN_ARGS)
 {
     (void)d_msgs; (void)d_off;
     const edk_verify_src src = { d_in[0] + j->rec_sig, d_in[0] + j->rec_pub, d_in[0] + j->rec_msg, NULL, msg_len,
-                                 j->in_w[0], j->in_w[0], j->in_w[0] };
+                                 j->in_w[0], j->in_w[0], j->in_w[0], NULL };
     return verify_on(e, d_out, &src, m, st, kdone, g_pipe_chain == 2);
 }
 static int run_sign(RUN_ARGS)

@@ -56,20 +56,13 @@ ED_DEV void store32(uint8_t* base, size_t item, size_t stride, const uint32_t w[
   }
 }
 
-ED_DEV void msg_span(const uint8_t*& m, size_t& mlen, const uint8_t* msgs, const uint64_t* msg_off,
-                     size_t msg_len, size_t item) {
-  if (msg_off) { m = msgs + msg_off[item]; mlen = (size_t)(msg_off[item + 1] - msg_off[item]); }
-  else { m = msgs + item * msg_len; mlen = msg_len; }
-}
-
 // one verify item: R, S, A as words and the message span (packed arrays or fixed-size records)
 ED_DEV void verify_item(uint32_t rw[8], uint32_t sw[8], uint32_t aw[8], const uint8_t*& m, size_t& mlen,
                         const edk_verify_src& s, size_t item) {
   load32(rw, s.sigs, item, s.sig_stride);
   load32(sw, s.sigs + 32, item, s.sig_stride);
   load32(aw, s.pubs, item, s.pub_stride);
-  if (s.msg_off) { m = s.msgs + s.msg_off[item]; mlen = (size_t)(s.msg_off[item + 1] - s.msg_off[item]); }
-  else { m = s.msgs + item * s.msg_stride; mlen = s.msg_len; }
+  msg_span(m, mlen, s.msgs, s.msg_off, s.msg_end, s.msg_len, s.msg_stride, item);
 }
 
 // copy a table of `words` 32-bit words (a multiple of 4, 16-byte aligned) from HBM into LDS (whole block)
@@ -180,8 +173,7 @@ k_verify_prepare(edk_verify_src src, size_t n, uint32_t* digits,
   const uint8_t* m; size_t mlen;
   load32(rw, src.sigs, item, src.sig_stride);
   load32(aw, src.pubs, item, src.pub_stride);
-  if (src.msg_off) { m = src.msgs + src.msg_off[item]; mlen = (size_t)(src.msg_off[item + 1] - src.msg_off[item]); }
-  else { m = src.msgs + item * src.msg_stride; mlen = src.msg_len; }
+  msg_span(m, mlen, src.msgs, src.msg_off, src.msg_end, src.msg_len, src.msg_stride, item);
   uint4* d = reinterpret_cast<uint4*>(digits + 16 * i);
   verify_hash_lane(tw, rw, aw, m, mlen);
   d[0] = make_uint4(tw[0], tw[1], tw[2], tw[3]); d[1] = make_uint4(tw[4], tw[5], tw[6], tw[7]);
@@ -775,7 +767,7 @@ k_encode_finish(uint8_t* out, uint32_t* acc, size_t n, int K) {
 template <int PARTS>
 __global__ void __launch_bounds__(POINT_BLOCK, 512 / POINT_BLOCK)
 k_sign_point(uint32_t* accout, uint32_t* aux, const uint8_t* secs, const uint8_t* msgs,
-             const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* comb, uint32_t* tiles) {
+             const uint64_t* msg_off, const uint64_t* msg_end, size_t msg_len, size_t n, const uint32_t* comb, uint32_t* tiles) {
   __shared__ alignas(16) uint32_t lds_comb[COMB_IMG_WORDS];
   stage_table(lds_comb, comb, COMB_IMG_WORDS);
   __shared__ uint32_t lds_shares[PARTS == 1 ? 1 : 2 * 40 * 64];
@@ -786,7 +778,7 @@ k_sign_point(uint32_t* accout, uint32_t* aux, const uint8_t* secs, const uint8_t
   for (unsigned it = 0; point_tile<PARTS>(i, it, n, tiles); it++) {
     const size_t item = i < n ? i : n - 1;
     const uint8_t* m; size_t mlen;
-    msg_span(m, mlen, msgs, msg_off, msg_len, item);
+    msg_span(m, mlen, msgs, msg_off, msg_end, msg_len, msg_len, item);
     uint32_t sk[8], aw[8], rw[8];
     load32(sk, secs, item, 32);
     sign_scalars_lane(aw, rw, sk, m, mlen);
@@ -807,7 +799,7 @@ k_sign_point(uint32_t* accout, uint32_t* aux, const uint8_t* secs, const uint8_t
 
 struct sign_finish_policy {
   uint8_t* sigs; uint32_t* acc; uint32_t* aux; const uint8_t* pubs; const uint8_t* msgs;
-  const uint64_t* msg_off; size_t msg_len; size_t n; int K;
+  const uint64_t* msg_off; const uint64_t* msg_end; size_t msg_len; size_t n; int K;
   ED_DEV void den(int k, fe& z) const {
     const finish_pos p = finish_at(k, acc, K);
     fe_set(z, 1);
@@ -823,7 +815,7 @@ struct sign_finish_policy {
     encode_lane(Rw, x, y, zinv);
     load32(pub, pubs, p.i, 32);
     const uint8_t* m; size_t mlen;
-    msg_span(m, mlen, msgs, msg_off, msg_len, p.i);
+    msg_span(m, mlen, msgs, msg_off, msg_end, msg_len, msg_len, p.i);
     sc t;
     sign_challenge_lane(t, Rw, pub, m, mlen);              // the secret scalars are fetched only after the hash
     uint32_t aw[8], rw[8];
@@ -841,8 +833,8 @@ struct sign_finish_policy {
 
 __global__ void __launch_bounds__(BLOCK, 2)
 k_sign_finish(uint8_t* sigs, uint32_t* acc, uint32_t* aux, const uint8_t* pubs, const uint8_t* msgs,
-              const uint64_t* msg_off, size_t msg_len, size_t n, int K) {
-  finish_batch8(sign_finish_policy{sigs, acc, aux, pubs, msgs, msg_off, msg_len, n, K}, acc);
+              const uint64_t* msg_off, const uint64_t* msg_end, size_t msg_len, size_t n, int K) {
+  finish_batch8(sign_finish_policy{sigs, acc, aux, pubs, msgs, msg_off, msg_end, msg_len, n, K}, acc);
 }
 
 template <int PARTS>
@@ -1497,11 +1489,11 @@ hipError_t edk_genpub(uint8_t* pubs, const uint8_t* secs, size_t n, const uint32
 }
 
 hipError_t edk_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, const uint8_t* msgs,
-                    const uint64_t* msg_off, size_t msg_len, size_t n, const uint32_t* comb,
+                    const uint64_t* msg_off, const uint64_t* msg_end, size_t msg_len, size_t n, const uint32_t* comb,
                     const edk_fixed_ws* ws, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  EDK_POINT_LAUNCH(k_sign_point, n, ws->acc, ws->aux, secs, msgs, msg_off, msg_len, n, comb);
-  hipLaunchKernelGGL(k_sign_finish, EDK_FINISH_GRID(n), sigs, ws->acc, ws->aux, pubs, msgs, msg_off, msg_len, n, (int)finish_k(n));
+  EDK_POINT_LAUNCH(k_sign_point, n, ws->acc, ws->aux, secs, msgs, msg_off, msg_end, msg_len, n, comb);
+  hipLaunchKernelGGL(k_sign_finish, EDK_FINISH_GRID(n), sigs, ws->acc, ws->aux, pubs, msgs, msg_off, msg_end, msg_len, n, (int)finish_k(n));
   return hipGetLastError();
 }
 

@@ -48,6 +48,22 @@ ED_DEV void shl256(uint32_t w[8]) {
   w[0] <<= S;
 }
 
+// The message of item `item`: msgs + item * stride, len bytes (off == nullptr), or the ragged span off[item] .. off[item + 1].
+// A ragged span is clamped into [0, *end) - *end is the table's own last entry, which the caller vouches for as the size of
+// the message buffer - and to a length that is not negative: a table that is not non-decreasing (the host-pointer entry
+// points refuse one with hipErrorInvalidValue; a table in device memory cannot be inspected without a pass of its own)
+// never makes a lane read outside [msgs, msgs + *end).  Such an item is hashed over the clamped span.
+ED_DEV void msg_span(const uint8_t*& m, size_t& mlen, const uint8_t* msgs, const uint64_t* off, const uint64_t* end,
+                     size_t len, size_t stride, size_t item) {
+  if (off) {
+    const uint64_t total = *end;
+    uint64_t lo = off[item], hi = off[item + 1];
+    lo = lo < total ? lo : total;
+    hi = hi < lo ? lo : hi < total ? hi : total;
+    m = msgs + lo; mlen = (size_t)(hi - lo);
+  } else { m = msgs + item * stride; mlen = len; }
+}
+
 // x25519.c:137-140: clamp copy
 ED_DEV void clamp(uint32_t s[8]) {
   s[0] &= 0xfffffff8u;

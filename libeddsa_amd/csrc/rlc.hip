@@ -109,8 +109,7 @@ k_rlc_hash(edk_verify_src src, size_t n, uint32_t* ts, uint32_t* leaf) {
   load_words8(aw, src.pubs + i * src.pub_stride);
   load_words8(sw, src.sigs + i * src.sig_stride + 32);
   const uint8_t* m; size_t mlen;
-  if (src.msg_off) { m = src.msgs + src.msg_off[i]; mlen = (size_t)(src.msg_off[i + 1] - src.msg_off[i]); }
-  else { m = src.msgs + i * src.msg_stride; mlen = src.msg_len; }
+  msg_span(m, mlen, src.msgs, src.msg_off, src.msg_end, src.msg_len, src.msg_stride, i);
   rlc_hash_lane(tw, sw, lf, rw, aw, src.sigs + i * src.sig_stride + 32, m, mlen);
   uint4* o = reinterpret_cast<uint4*>(ts + 16 * i);
   o[0] = make_uint4(tw[0], tw[1], tw[2], tw[3]); o[1] = make_uint4(tw[4], tw[5], tw[6], tw[7]);

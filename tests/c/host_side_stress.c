@@ -164,6 +164,26 @@ int main(int argc, char **argv)
         CHECK(stats[0] + stats[1] == NE, "batch verification statistics: %u + %u items", stats[0], stats[1]);
         eddsa_amd_set_rlc_min_items((size_t)3 << 17);
     }
+    {   /* an offset table that runs backwards, in the first chunk and in a later one, and one whose span no buffer holds: the
+         * call is refused (hipErrorInvalidValue = 1) before the chunk's bytes are touched - the sanitizers would see the
+         * read of msg_off[k + 1] - msg_off[k] ~ 2^64 bytes - and the next call works */
+        uint64_t offb[NE + 1];
+        const int spots[3] = { 7, NE / 2, NE - 2 };
+        for (int sidx = 0; sidx < 3; sidx++) {
+            memcpy(offb, off5, sizeof(offb));
+            offb[spots[sidx]] = offb[spots[sidx] + 1] + 3;           /* item spots[sidx] would have a negative length */
+            CHECK(ed25519_verify_batch(ok, bad, g_pub, shifted, offb, 0, NE) == -1, "a decreasing offset table was accepted (verify, entry %d)", spots[sidx]);
+            CHECK(ed25519_sign_batch(sig, g_sec, g_pub, shifted, offb, 0, NE) == -1, "a decreasing offset table was accepted (sign, entry %d)", spots[sidx]);
+            RC(eddsa_amd_secret_residue(res));   /* (the chunks before the refused one have run: their secrets are gone like any failed call's) */
+            CHECK(res[0] == 0 && res[2] == 0, "a refused sign call left secrets behind: %llu %llu", (unsigned long long)res[0], (unsigned long long)res[2]);
+            CHECK(ed25519_verify_batch_rlc(ok, NULL, bad, g_pub, shifted, offb, 0, NE) == -1, "a decreasing offset table was accepted (batch verification)");
+        }
+        memcpy(offb, off5, sizeof(offb));
+        offb[NE] = (uint64_t)1 << 62;
+        CHECK(ed25519_verify_batch(ok, bad, g_pub, shifted, offb, 0, NE) == -1, "an offset table spanning 2^62 bytes was accepted");
+        RC(ed25519_verify_batch(ok, bad, g_pub, shifted, off5, 0, NE));
+        for (int i = 0; i < NE; i++) CHECK(ok[i] == (i % 3 != 0), "verify after refused calls: item %d", i);
+    }
     free(shifted);
 
     /* ---- 2b. armed: a failed call is an error return, the next one works, nothing secret stays ---- */

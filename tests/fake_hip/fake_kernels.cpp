@@ -244,7 +244,7 @@ hipError_t edk_genpub(uint8_t* pubs, const uint8_t* secs, size_t n, const uint32
   return hipSuccess;
 }
 
-hipError_t edk_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, const uint8_t* msgs, const uint64_t* msg_off, size_t msg_len,
+hipError_t edk_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, const uint8_t* msgs, const uint64_t* msg_off, const uint64_t* /*msg_end*/, size_t msg_len,
                     size_t n, const uint32_t* comb, const edk_fixed_ws* ws, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   own_fixed(ws, n, stream); own(sigs, 64 * n, "signatures"); own(secs, 32 * n, "secret keys"); own(pubs, 32 * n, "public keys");

@@ -87,6 +87,17 @@ def test_layer_kats_and_loose_operands(hostcheck, golden):
     no_violations(hostcheck)
 
 
+def test_sha512_length_field_beyond_32_bits(hostcheck):
+    """lib/sha512.c:196-203 writes the bit length as 128 bits; csrc/sha512.h keeps it in one 64-bit word.  A message of
+    2^29 + 5 bytes has a bit length of 2^32 + 40 - the first that needs the upper half of that word - and one lane of the
+    device would take a minute over it, so the device SOURCE hashes it here, against hashlib; and the same around the
+    sizes the GPU suite runs on the device (tests/test_gpu_messages.py)"""
+    for n in (16384 - 17, 65536 + 112, (1 << 20) + 17, (1 << 29) + 5):
+        m = (hashlib.sha512(n.to_bytes(8, "little")).digest() * (n // 64 + 1))[:n]
+        assert call(hostcheck, "hc_sha512", 64, m, SZ(n)) == hashlib.sha512(m).digest(), n
+    no_violations(hostcheck)
+
+
 def test_all_ones_operands_stay_in_bounds(hostcheck):
     """worst-case limbs: every limb of both operands at its maximum, at the loose-operand limits"""
     ones = b"\xff" * 32
