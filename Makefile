@@ -13,7 +13,9 @@ LIB     := libeddsa_amd/libeddsa_amd.so
 HIPFLAGS := -O3 --offload-arch=$(ARCH) -fPIC -fvisibility=hidden -DEDDSA_BUILD -Iinclude -I$(CSRC) -mllvm -amdgpu-dpp-combine=false
 CFLAGS   := -std=c11 -O2 -fPIC -fvisibility=hidden -Wall -Wextra -DEDDSA_BUILD -Iinclude -I$(CSRC) -I$(ROCM)/include
 
-all: $(LIB) oracle
+PROBE   := libeddsa_amd/libeddsa_amd_probe.so
+
+all: $(LIB) $(PROBE) oracle
 
 $(BUILD)/kernels.o: $(CSRC)/kernels.hip $(wildcard $(CSRC)/*.h)
 	@mkdir -p $(BUILD)
@@ -33,6 +35,12 @@ $(BUILD)/rlc.o: $(CSRC)/rlc.hip $(wildcard $(CSRC)/*.h)
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+# The layer probes (include/eddsa_amd_probe.h): test infrastructure, a library of its own - nothing of it is linked into $(LIB)
+probe: $(PROBE)
+$(PROBE): $(CSRC)/probe.hip $(wildcard $(CSRC)/*.h) include/eddsa_amd_probe.h
+	@mkdir -p $(BUILD)
+	$(HIPCC) -O3 --offload-arch=$(ARCH) -fPIC -fvisibility=hidden -DEDDSA_PROBE_BUILD -Iinclude -I$(CSRC) -mllvm -amdgpu-dpp-combine=false -shared $< -o $@
+
 oracle:
 	$(MAKE) -C oracle all
 
@@ -41,7 +49,7 @@ microbench:
 	$(HIPCC) -O3 --offload-arch=$(ARCH) -I$(CSRC) tools/microbench/fe_rates.hip -o tools/microbench/fe_rates.bin
 
 clean:
-	rm -rf $(BUILD) $(LIB) libeddsa_amd/libeddsa.so.0
+	rm -rf $(BUILD) $(LIB) $(PROBE) libeddsa_amd/libeddsa.so.0
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle microbench clean
+.PHONY: all oracle probe microbench clean

@@ -94,11 +94,36 @@ def make_workload(op, n, first, device, seed=None, config=None):
     return {"sigs": up(sig), "pubs": up(pk), "msgs": up(msg), "expect": up(expect), "valid": valid}
 
 
+PMC_PATH = os.path.join(ROOT, "profiles", "pmc_summary.json")
+_PMC_CACHE = {}
+
+
 def pmc_profile():
+    """The committed counter summary - but only if it was measured on THIS tree's device code: tools/summarize_profile.py
+    stores the hash of the kernel sources with the counters (tools/source_hash.py) and a summary recorded from other
+    sources is not printed (the line must not keep quoting stale counters after a kernel change).
+    -> (per-kernel dict, None) or ({}, the reason)."""
+    if PMC_PATH in _PMC_CACHE:
+        return _PMC_CACHE[PMC_PATH]
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+        prof = json.load(open(PMC_PATH))
     except (OSError, ValueError):
-        return {}
+        res = ({}, "no counter summary committed (tools/profile.sh)")
+    else:
+        import source_hash
+        want, have = source_hash.device_source_hash(), (prof.get("_source") or {}).get("sha256")
+        if have != want:
+            res = ({}, f"profiles/pmc_summary.json was recorded from other kernel sources (its hash {str(have)[:12]}, this tree "
+                       f"{want[:12]}): re-run tools/profile.sh")
+        else:
+            res = (prof, None)
+    _PMC_CACHE[PMC_PATH] = res
+    return res
+
+
+def pmc_note():
+    """why the counter fields of this line are null, or None"""
+    return pmc_profile()[1]
 
 
 def pmc_traffic(kernel):
@@ -107,7 +132,7 @@ def pmc_traffic(kernel):
     (KB; gfx950 reports half the bytes of 16-byte-per-lane reads, MI355X_MICROARCH.md, HBM).
     None when no profile has been committed."""
     try:
-        prof = pmc_profile()
+        prof = pmc_profile()[0]
         ks = [prof["ed::" + name.strip()] for name in kernel.split("+")]
         fetch, write = sum(k["FETCH_SIZE"] for k in ks), sum(k["WRITE_SIZE"] for k in ks)
         return {"bytes": (2.0 * fetch + write) * 1024.0, "fetch_size_kb_raw": fetch, "write_size_kb_raw": write,
@@ -121,7 +146,7 @@ def pmc_valu_busy(kernel):
     x 4 clocks (one VALU instruction per SIMD per 4 clocks, profiles/r01_valu_rates.txt) / (1024 SIMDs x
     GRBM_GUI_ACTIVE / 8 XCDs).  None when the profile lacks the counters."""
     try:
-        ks = [pmc_profile()["ed::" + name.strip()] for name in kernel.split("+")]
+        ks = [pmc_profile()[0]["ed::" + name.strip()] for name in kernel.split("+")]
         return {"value": 4.0 * sum(k["SQ_INSTS_VALU"] for k in ks) / (1024.0 * sum(k["GRBM_GUI_ACTIVE"] for k in ks) / 8.0),
                 "source": PMC_SOURCE}
     except (KeyError, TypeError, ZeroDivisionError):
@@ -132,7 +157,7 @@ def pmc_executed(kernel, items):
     """VALU lane-instructions per item that `kernel` executed in the committed PMC pass (SQ_INSTS_VALU counts
     wave-instructions, 64 lanes each)"""
     try:
-        ks = [pmc_profile()["ed::" + name.strip()] for name in kernel.split("+")]
+        ks = [pmc_profile()[0]["ed::" + name.strip()] for name in kernel.split("+")]
         return {"value": 64.0 * sum(k["SQ_INSTS_VALU"] for k in ks) / items, "source": PMC_SOURCE}
     except (KeyError, TypeError, ZeroDivisionError):
         return None
@@ -478,6 +503,7 @@ def roofline_of(op, n, k_ms, phases, ms_per_step, passes):
         "bound": "valu", "kernel": kernel, "achieved": achieved, "peak": PEAK_TMUL32,
         "unit": "Tmul32/s", "frac": achieved / PEAK_TMUL32, "traffic": pmc_traffic(kernel),
         "valu_busy": pmc_valu_busy(kernel), "executed_valu_per_item": pmc_executed(kernel, 1 << 20),
+        "counters_note": pmc_note(),                 # why traffic / valu_busy / executed_valu_per_item are null, or null
         "kernel_ms": main_ms, "items_per_launch": items, "canonical_mul32_per_item": k_mul32,
         "whole_pass": {"kernels_ms": k_ms, "canonical_mul32_per_item": MUL32[op],
                        "achieved": n * MUL32[op] / (k_ms * 1e-3) / 1e12,

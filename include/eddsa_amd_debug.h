@@ -3,12 +3,13 @@
  *
  * Nothing here is part of the contract a caller binds (that is include/eddsa.h, the reference's own 13 symbols,
  * lib/eddsa.h:44-113, plus the batched forms of include/eddsa_amd.h).  The functions below exist for the repository's
- * tests, bench.py and the scripts under tools/: route selection (same verdicts on every route), probes that run single
- * layers of the device code on caller-given inputs, counters, traces, and two fault injectors.
+ * tests, bench.py and the scripts under tools/: route selection (same verdicts on every route), counters, traces, and
+ * two fault injectors.  (The probes that run single layers of the device code on caller-given inputs are a library of
+ * their own, libeddsa_amd_probe.so / include/eddsa_amd_probe.h: this library holds no kernel that is not a product kernel.)
  *
- * The fault injectors and the layer probe are INERT unless the hooks were armed with eddsa_amd_debug_init(device,
- * EDDSA_AMD_TEST_HOOKS): unarmed they return EDDSA_AMD_HOOKS_OFF and change nothing, so a stray call in a production
- * process cannot make anybody's next signature check fail.  eddsa_amd_shutdown disarms them.
+ * The fault injectors are INERT unless the hooks were armed with eddsa_amd_debug_init(device, EDDSA_AMD_TEST_HOOKS):
+ * unarmed they return EDDSA_AMD_HOOKS_OFF and change nothing, so a stray call in a production process cannot make
+ * anybody's next signature check fail.  eddsa_amd_shutdown disarms them.
  */
 #ifndef EDDSA_AMD_DEBUG_H
 #define EDDSA_AMD_DEBUG_H
@@ -36,31 +37,6 @@ EDDSA_AMD_DECL int eddsa_amd_debug_fail_hip_call(int nth);
 /* checked HIP calls the verify passes have made since the last eddsa_amd_debug_fail_hip_call (so that a test can walk
  * nth over every one of them) */
 EDDSA_AMD_DECL int eddsa_amd_debug_hip_calls(void);
-
-/* ---- layer probes [armed]: one layer of the device code on caller-given inputs (host memory), one lane per item
- *      (form 0) or, where a four-lane form exists, a quad per item exchanging operands by DPP (form 1) ----
- * in: n items of in_w bytes, out: n items of out_w bytes; the widths are fixed per op and checked.
- *   op                        in (bytes)                                   out
- *   EDL_FE_MUL                a 32 | b 32                                  32   fld_mul  reference lib/fld.c:209-244
- *   EDL_FE_SQ                 a 32                                         32   fld_sq   lib/fld.c:249-280
- *   EDL_FE_INV                a 32                                         32   fld_inv  lib/fld.c:578-645
- *   EDL_FE_POW2523            a 32                                         32   fld_pow2523 lib/fld.c:657-709
- *   EDL_FE_MUL_LOOSE          a 32 | b 32 | ka 1 | kb 1 | pad 6            32   (ka a)(kb b), ka <= 7, kb <= 3: operands at the
- *                                                                               documented limb bounds (csrc/fe25519.h:10-16)
- *   EDL_SC_REDUCE32 / 64      x 32 / x 64                                  32   sc_import lib/sc.c:191-214
- *   EDL_SC_MULADD             a 32 | b 32 | c 32                           32   a b + c mod l, lib/sc.c:241-266
- *   EDL_SHA512                len 8 (LE) | message, padded to in_w - 8     64   lib/sha512.c:127-210
- *   EDL_ED_IMPORT_EXPORT      enc 32                                       33   ed_import, ed_export lib/ed.c:100-169 | on-curve flag
- *   EDL_ED_SCALE_BASE         x 32 (reduced mod l first)                   32   ed_scale_base lib/ed.c:397-430 (comb from LDS, shuffle select)
- *   EDL_ED_DUAL_SCALE         s 32 | t 32 | q 32                           32   ed_dual_scale lib/ed.c:455-507 in the reference's order;
- *                                                                               form 0 literal, form 2 with uniform control flow,
- *                                                                               form 1 the four-lane chain (set-up + chain of the exact path)
- *   EDL_GE_DBL_ADD            p 32 | k 2 (LE) | pad 6                      32   enc(2 P + k B): form 0 ge_dbl + ge_add_niels, form 1 quad_dbl +
- *                                                                               quad_add_entry (the windowed evaluation's two steps)
- */
-enum { EDL_FE_MUL = 1, EDL_FE_SQ, EDL_FE_INV, EDL_FE_POW2523, EDL_FE_MUL_LOOSE, EDL_SC_REDUCE32, EDL_SC_REDUCE64,
-       EDL_SC_MULADD, EDL_SHA512, EDL_ED_IMPORT_EXPORT, EDL_ED_SCALE_BASE, EDL_ED_DUAL_SCALE, EDL_GE_DBL_ADD };
-EDDSA_AMD_DECL int eddsa_amd_debug_layer(int op, int form, uint8_t *out, size_t out_w, const uint8_t *in, size_t in_w, size_t n);
 
 /* ---- route selection (a measurement and test aid; the verdicts are the same on every route) ----
  * 0 (default): every pass checks u*(S*B - t*A - R) = 0 with half-length u, v = u*t mod 8l (132 doublings instead of
@@ -92,10 +68,6 @@ EDDSA_AMD_DECL int eddsa_amd_combiner_stats(uint64_t out[2]);
  * i < 22, k < 32 (the reference's ed_lookup[i][k], lib/ed.c:41-43, is (k+1)*256^i*B: the same comb with 4-bit windows;
  * row 0 coincides for k < 8); each entry 32 words: 10 radix-2^25.5 limbs of y-x, y+x, 2dxy, then 2 words of padding */
 EDDSA_AMD_DECL int eddsa_amd_dump_tables(uint32_t *base16_words, uint32_t *comb_words);
-/* the device's search for the half-length pair (u, v), v = u*t mod 8l, on n given scalars t < l (32 bytes each, host
- * memory); out48 per item: v (20 bytes, little-endian) | |u| (20) | u < 0 (1) | found (1) | 6 bytes of padding.
- * wide != 0: |u|, v < 2^138 (what passes below 2^18 items use) instead of 2^134 */
-EDDSA_AMD_DECL int eddsa_amd_debug_halve(uint8_t *out48, const uint8_t *t32, size_t n, int wide);
 /* the half-length route re-verifies every pair with integers before it is used (u t = v mod 8 l) and falls back to
  * (u, v) = (1, t) when the check fails; *count = how often that has happened on the default device since its
  * workspaces were allocated.  Waits for the device.  Expected, and observed over the 2^24-item batch: 0 */

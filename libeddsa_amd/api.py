@@ -100,7 +100,7 @@ LAYER_OPS = {"fe_mul": 1, "fe_sq": 2, "fe_inv": 3, "fe_pow2523": 4, "fe_mul_loos
 
 
 def debug_init(device=0, hooks=True):
-    """eddsa_amd_init(device), then arm (or disarm) the fault injectors and the layer probe"""
+    """eddsa_amd_init(device), then arm (or disarm) the fault injectors"""
     _check(library().eddsa_amd_debug_init(int(device), ctypes.c_uint(1 if hooks else 0)), "eddsa_amd_debug_init")
 
 
@@ -124,17 +124,33 @@ def debug_teardown_errors():
     return int(library().eddsa_amd_debug_teardown_errors(ctypes.byref(first))), int(first.value)
 
 
+_PROBE = None
+
+
+def probe_library():
+    """libeddsa_amd_probe.so (include/eddsa_amd_probe.h): the layer probes, test infrastructure built from the same device
+    source as the product's kernels and loaded BESIDE the product - libeddsa_amd.so holds none of its kernels."""
+    global _PROBE
+    if _PROBE is None:
+        path = os.path.join(_HERE, "libeddsa_amd_probe.so")
+        if not os.path.exists(path):
+            raise EddsaAmdError(f"{path} is missing: build it with `make probe`")
+        library()                                  # (the one HIP runtime of the process is settled there)
+        _PROBE = ctypes.CDLL(path)
+    return _PROBE
+
+
 def debug_layer(op, items, out_w, form=0):
-    """run one layer of the device code (include/eddsa_amd_debug.h) on `items` (equal-length byte strings): -> list of
-    out_w-byte results.  Needs debug_init(hooks=True)."""
+    """run one layer of the device code (include/eddsa_amd_probe.h) on `items` (equal-length byte strings): -> list of
+    out_w-byte results.  Runs on the current HIP device through the probe library."""
     code = LAYER_OPS[op] if isinstance(op, str) else int(op)
     n = len(items)
     in_w = len(items[0]) if n else 32
     assert all(len(x) == in_w for x in items)
     buf = np.frombuffer(b"".join(items), np.uint8).copy() if n else np.zeros(1, np.uint8)
     out = np.zeros(max(n, 1) * out_w, np.uint8)
-    _check(library().eddsa_amd_debug_layer(ctypes.c_int(code), ctypes.c_int(form), _np_ptr(out), _c_size(out_w), _np_ptr(buf),
-                                           _c_size(in_w), _c_size(n)), f"eddsa_amd_debug_layer({op})")
+    _check(probe_library().eddsa_amd_probe_layer(ctypes.c_int(code), ctypes.c_int(form), _np_ptr(out), _c_size(out_w), _np_ptr(buf),
+                                                 _c_size(in_w), _c_size(n)), f"eddsa_amd_probe_layer({op})")
     return [out[out_w * i:out_w * (i + 1)].tobytes() for i in range(n)]
 
 
@@ -165,8 +181,8 @@ def debug_halve(ts, wide=False):
     n = len(ts)
     tin = np.frombuffer(b"".join(int(t).to_bytes(32, "little") for t in ts), np.uint8).copy()
     out = np.zeros(48 * max(n, 1), np.uint8)
-    _check(library().eddsa_amd_debug_halve(out.ctypes.data_as(ctypes.c_void_p), tin.ctypes.data_as(ctypes.c_void_p), _c_size(n),
-                                            ctypes.c_int(int(bool(wide)))), "eddsa_amd_debug_halve")
+    _check(probe_library().eddsa_amd_probe_halve(out.ctypes.data_as(ctypes.c_void_p), tin.ctypes.data_as(ctypes.c_void_p), _c_size(n),
+                                                 ctypes.c_int(int(bool(wide)))), "eddsa_amd_probe_halve")
     res = []
     for i in range(n):
         row = out[48 * i:48 * i + 48].tobytes()

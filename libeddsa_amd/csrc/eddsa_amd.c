@@ -36,6 +36,7 @@ const char *eddsa_amd_strerror(int err)
     if (err == 0) return "success";
     if (err == ERR_NOT_GFX950) return "eddsa_amd: device is not gfx950 (MI355X); no code object for it";
     if (err == ERR_RCCL_MISSING) return "eddsa_amd: librccl.so.1 could not be loaded (needed for the multi-device result gather)";
+    if (err == EDDSA_AMD_HOOKS_OFF) return "eddsa_amd: test hooks not armed (eddsa_amd_debug_init)";
     if (err <= ERR_RCCL_BASE) {
         if (g_multi.GetErrorString) return g_multi.GetErrorString(ERR_RCCL_BASE - err);
         return "eddsa_amd: RCCL error";
@@ -372,6 +373,7 @@ void eddsa_amd_shutdown(void)
     }
     g_default = -1;
     __atomic_store_n(&g_hooks_armed, 0, __ATOMIC_RELEASE);
+    edk_debug_counting(0);
     (void)edk_debug_fail_in(0);
     if (saved >= 0) HIP_NOTE(hipSetDevice(saved));   /* teardown: nothing to report to */
     pthread_rwlock_unlock(&g_table);
@@ -387,6 +389,7 @@ int eddsa_amd_debug_init(int device, unsigned flags)
     const int rc = eddsa_amd_init(device);
     if (rc) return rc;
     __atomic_store_n(&g_hooks_armed, (flags & EDDSA_AMD_TEST_HOOKS) != 0, __ATOMIC_RELEASE);
+    edk_debug_counting((flags & EDDSA_AMD_TEST_HOOKS) != 0);
     if (!(flags & EDDSA_AMD_TEST_HOOKS)) (void)edk_debug_fail_in(0);
     return 0;
 }
@@ -401,31 +404,6 @@ int eddsa_amd_debug_fail_hip_call(int nth)
 int eddsa_amd_debug_hip_calls(void)
 {
     return edk_debug_fail_in(-1);
-}
-
-/* one layer of the device code on caller-given inputs (host memory): see include/eddsa_amd_debug.h */
-int eddsa_amd_debug_layer(int op, int form, uint8_t *out, size_t out_w, const uint8_t *in, size_t in_w, size_t n)
-{
-    struct call c;
-    uint8_t *d_in = NULL, *d_out = NULL;
-    int rc;
-    if (!__atomic_load_n(&g_hooks_armed, __ATOMIC_ACQUIRE)) return EDDSA_AMD_HOOKS_OFF;
-    if (!edk_debug_layer_widths_ok(op, form, in_w, out_w)) return -(int)hipErrorInvalidValue;
-    rc = enter(&c, -1);
-    if (rc) return rc;
-    if (n == 0) goto out;
-    TRY(hipMalloc((void **)&d_in, n * in_w));
-    TRY(hipMalloc((void **)&d_out, n * out_w));
-    TRY(hipMemcpy(d_in, in, n * in_w, hipMemcpyHostToDevice));
-    TRY(hipMemset(d_out, 0, n * out_w));
-    TRY(edk_debug_layer(op, form, d_out, out_w, d_in, in_w, n, c.e->base16, c.e->comb_img, NULL));
-    TRY(hipStreamSynchronize(NULL));
-    TRY(hipMemcpy(out, d_out, n * out_w, hipMemcpyDeviceToHost));
-out:
-    if (d_in) HIP_NOTE(hipFree(d_in));     /* probe buffers: public test data */
-    if (d_out) HIP_NOTE(hipFree(d_out));
-    leave(&c);
-    return rc;
 }
 
 int eddsa_amd_dump_tables(uint32_t *base16_words, uint32_t *comb_words)
@@ -448,28 +426,6 @@ void eddsa_amd_set_verify_algo(int algo)
     pthread_rwlock_wrlock(&g_table);
     g_verify_algo = algo >= 1 && algo <= 3 ? algo : 0;
     pthread_rwlock_unlock(&g_table);
-}
-
-/* diagnostic for the tests: the device's pair search (csrc/halve.h) on n given scalars t (32 bytes each, < l);
- * out48: v (20 bytes) | |u| (20) | u < 0 (1) | found (1) | padding (6) per item.  wide: the bound 2^138 of passes
- * below 2^18 items instead of 2^134.  Host pointers. */
-int eddsa_amd_debug_halve(uint8_t *out48, const uint8_t *t32, size_t n, int wide)
-{
-    struct call c;
-    uint8_t *d_t = NULL, *d_o = NULL;
-    int rc = enter(&c, -1);
-    if (rc) return rc;
-    if (n == 0) goto out;
-    TRY(hipMalloc((void **)&d_t, n * 32));
-    TRY(hipMalloc((void **)&d_o, n * 48));
-    TRY(hipMemcpy(d_t, t32, n * 32, hipMemcpyHostToDevice));
-    TRY(edk_debug_halve(d_o, d_t, n, wide, NULL));
-    TRY(hipMemcpy(out48, d_o, n * 48, hipMemcpyDeviceToHost));
-out:
-    if (d_t) HIP_NOTE(hipFree(d_t));
-    if (d_o) HIP_NOTE(hipFree(d_o));
-    leave(&c);
-    return rc;
 }
 
 /* diagnostic for the tests: how many half-length pairs the exact integer check (csrc/lanes.h: verify_half_scalars_lane)

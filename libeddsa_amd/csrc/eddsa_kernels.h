@@ -116,14 +116,12 @@ hipError_t edk_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, con
                     const edk_fixed_ws* ws, hipStream_t stream);
 hipError_t edk_x25519_base(uint8_t* out, const uint8_t* scalars, size_t n, const uint32_t* comb,
                            const edk_fixed_ws* ws, hipStream_t stream);
-hipError_t edk_debug_halve(uint8_t* out /* 48 bytes per item, device */, const uint8_t* t /* 32 per item, device */, size_t n, int wide, hipStream_t stream);
 /* test surface (include/eddsa_amd_debug.h).  edk_debug_fail_in: nth > 0 arms the fault (the nth checked HIP call of the
  * verify passes from now on reports hipErrorUnknown instead of being made) and restarts the count; 0 disarms; < 0 only
  * returns the number of checked calls made since the count was restarted */
 int edk_debug_fail_in(int nth);
-int edk_debug_layer_widths_ok(int op, int form, size_t in_w, size_t out_w);
-hipError_t edk_debug_layer(int op, int form, uint8_t* out, size_t out_w, const uint8_t* in, size_t in_w, size_t n,
-                           const uint32_t* base16, const uint32_t* comb_img, hipStream_t stream);
+/* the checked calls are counted only while this is on (armed hooks): an unarmed process bumps no shared counter in its passes */
+void edk_debug_counting(int on);
 hipError_t edk_pk_to_x(uint8_t* out, const uint8_t* in, size_t n, hipStream_t stream);
 hipError_t edk_sk_to_x(uint8_t* out, const uint8_t* in, size_t n, hipStream_t stream);
 

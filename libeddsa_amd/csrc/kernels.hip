@@ -16,6 +16,7 @@
 //   k_init_tables    generates what the reference ships as lib/ed_lookup64.h
 #include "eddsa_kernels.h"
 #include "edk_checked.h"
+#include "kernel_io.h"
 #include "lanes.h"
 #include "quad_lanes.h"
 
@@ -25,37 +26,6 @@ namespace ed {
 
 constexpr int BLOCK = 256;
 
-// ---- packed byte-array access: 32 bytes per item as eight little-endian words ---------------
-
-ED_DEV void load32(uint32_t w[8], const uint8_t* base, size_t item, size_t stride) {
-  const uint8_t* p = base + item * stride;
-  if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-    const uint4 a = reinterpret_cast<const uint4*>(p)[0];
-    const uint4 b = reinterpret_cast<const uint4*>(p)[1];
-    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
-    w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-      w[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) |
-             ((uint32_t)p[4 * i + 3] << 24);
-  }
-}
-
-ED_DEV void store32(uint8_t* base, size_t item, size_t stride, const uint32_t w[8]) {
-  uint8_t* p = base + item * stride;
-  if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-    reinterpret_cast<uint4*>(p)[0] = make_uint4(w[0], w[1], w[2], w[3]);
-    reinterpret_cast<uint4*>(p)[1] = make_uint4(w[4], w[5], w[6], w[7]);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      p[4 * i] = (uint8_t)w[i]; p[4 * i + 1] = (uint8_t)(w[i] >> 8);
-      p[4 * i + 2] = (uint8_t)(w[i] >> 16); p[4 * i + 3] = (uint8_t)(w[i] >> 24);
-    }
-  }
-}
-
 // one verify item: R, S, A as words and the message span (packed arrays or fixed-size records)
 ED_DEV void verify_item(uint32_t rw[8], uint32_t sw[8], uint32_t aw[8], const uint8_t*& m, size_t& mlen,
                         const edk_verify_src& s, size_t item) {
@@ -63,14 +33,6 @@ ED_DEV void verify_item(uint32_t rw[8], uint32_t sw[8], uint32_t aw[8], const ui
   load32(sw, s.sigs + 32, item, s.sig_stride);
   load32(aw, s.pubs, item, s.pub_stride);
   msg_span(m, mlen, s.msgs, s.msg_off, s.msg_end, s.msg_len, s.msg_stride, item);
-}
-
-// copy a table of `words` 32-bit words (a multiple of 4, 16-byte aligned) from HBM into LDS (whole block)
-ED_DEV void stage_table(uint32_t* lds, const uint32_t* src, int words) {
-  word4* d = reinterpret_cast<word4*>(lds);
-  const word4* s = reinterpret_cast<const word4*>(src);
-  for (int j = threadIdx.x; j < words / 4; j += (int)blockDim.x) d[j] = s[j];
-  __syncthreads();
 }
 
 // Append to a work list: the lanes of the wave that `want` a slot get consecutive ones from ONE atomic (a pass of 2^20
@@ -1027,200 +989,6 @@ k_verify_main_sums_quad(uint8_t* ok, const uint32_t* hdigits, const uint32_t* su
   ok[i] = (uint8_t)(neutral && (fl & 4) != 0);
 }
 
-// diagnostic (eddsa_amd_debug_halve): halve_scalar_lane on the device for given t; out = v (20 bytes) | |u| (20) |
-// u < 0 (1) | found (1) | 6 bytes of padding per item
-template <int BITS>
-__global__ void __launch_bounds__(BLOCK) k_debug_halve(uint8_t* out, const uint8_t* t, size_t n) {
-  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= n) return;
-  uint32_t tw[8], vw[5], uw[5];
-  load32(tw, t, i, 32);
-  bool uneg;
-  const bool found = halve_scalar_lane<BITS>(vw, uw, uneg, tw);
-  uint32_t* o = reinterpret_cast<uint32_t*>(out + 48 * i);
-#pragma unroll
-  for (int k = 0; k < 5; k++) { o[k] = vw[k]; o[5 + k] = uw[k]; }
-  o[10] = (uneg ? 1u : 0u) | (found ? 0x100u : 0u);
-  o[11] = 0;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Layer probes (include/eddsa_amd_debug.h: eddsa_amd_debug_layer): ONE layer of the device code on caller-given inputs,
-// so that the golden layer vectors (tests/golden/layer_kats.json, pinned to the reference's static library) reach the
-// GPU as such and not only as parts of whole operations - what the device toolchain makes of the limb arithmetic and of
-// the DPP exchanges is the one thing the host build of this source (tests/host_check/) cannot vouch for.
-// One lane per item; the four-lane forms below.  The op codes are those of the header.
-// ---------------------------------------------------------------------------------------------
-enum { L_FE_MUL = 1, L_FE_SQ, L_FE_INV, L_FE_POW2523, L_FE_MUL_LOOSE, L_SC_REDUCE32, L_SC_REDUCE64, L_SC_MULADD, L_SHA512,
-       L_ED_IMPORT_EXPORT, L_ED_SCALE_BASE, L_ED_DUAL_SCALE, L_GE_DBL_ADD };
-
-ED_DEV void ldw(uint32_t w[8], const uint8_t* p) { load32(w, p, 0, 0); }
-ED_DEV void stw(uint8_t* p, const uint32_t w[8]) { store32(p, 0, 0, w); }
-
-// scratch (EDL_ED_DUAL_SCALE only): per item 2 x REF_JSF_LEN digit bytes + 160 words (form 2: the uniform chain's storage)
-constexpr size_t LAYER_SCRATCH_BYTES = 2 * ((REF_JSF_LEN + 3) / 4 * 4) + 160 * 4;
-
-__global__ void __launch_bounds__(64)
-k_debug_layer(int op, int form, uint8_t* out, size_t out_w, const uint8_t* in, size_t in_w, size_t n, const uint32_t* base16,
-              uint8_t* scratch) {
-  const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
-  if (i >= n) return;
-  const uint8_t* a = in + i * in_w;
-  uint8_t* o = out + i * out_w;
-  uint32_t w[8], r[8];
-  fe x, y;
-  if (op == L_FE_MUL || op == L_FE_MUL_LOOSE) {
-    ldw(w, a); fe_frombytes(x, w); ldw(w, a + 32); fe_frombytes(y, w);
-    if (op == L_FE_MUL_LOOSE) {                  // f = ka a (ka <= 7), g = kb b (kb <= 3): the documented operand limits
-      const int ka = a[64], kb = a[65];
-      fe fx, gy;
-      fe_set(fx, 0); fe_set(gy, 0);
-      for (int k = 0; k < ka; k++) fe_add(fx, fx, x);
-      for (int k = 0; k < kb; k++) fe_add(gy, gy, y);
-      x = fx; y = gy;
-    }
-    fe_mul(x, x, y);
-    fe_tobytes(r, x); stw(o, r);
-  } else if (op == L_FE_SQ || op == L_FE_INV || op == L_FE_POW2523) {
-    ldw(w, a); fe_frombytes(x, w);
-    if (op == L_FE_SQ) fe_sq(x, x); else if (op == L_FE_INV) fe_inv(x, x); else fe_pow2523(x, x);
-    fe_tobytes(r, x); stw(o, r);
-  } else if (op == L_SC_REDUCE32 || op == L_SC_REDUCE64) {
-    uint32_t w16[16];
-    sc t;
-    ldw(w16, a);
-    if (op == L_SC_REDUCE64) { ldw(w16 + 8, a + 32); sc_from_words<16>(t, w16); } else sc_from_words<8>(t, w16);
-    sc_to_words(r, t); stw(o, r);
-  } else if (op == L_SC_MULADD) {
-    sc p, q, c;
-    ldw(w, a); sc_from_words<8>(p, w); ldw(w, a + 32); sc_from_words<8>(q, w); ldw(w, a + 64); sc_from_words<8>(c, w);
-    sc_mul(p, p, q); sc_add(p, c, p);
-    sc_to_words(r, p); stw(o, r);
-  } else if (op == L_SHA512) {
-    uint32_t d[16];
-    size_t len = 0;
-    for (int k = 7; k >= 0; k--) len = (len << 8) | a[k];
-    sha512_prefix_msg<0>(d, nullptr, a + 8, len);
-    stw(o, d); stw(o + 32, d + 8);
-  } else if (op == L_ED_IMPORT_EXPORT) {
-    ge p; bool oc;
-    ldw(w, a);
-    ge_frombytes(p, oc, w, false);
-    ge_tobytes(r, p); stw(o, r);
-    o[32] = oc ? 1 : 0;
-  } else if (op == L_ED_DUAL_SCALE) {            // forms 0 (the literal chain) and 2 (uniform control flow); form 1 is k_debug_dual_scale_quad
-    uint32_t sw[8], tw[8];
-    sc s, t;
-    ldw(w, a); sc_from_words<8>(s, w); sc_to_words(sw, s);
-    ldw(w, a + 32); sc_from_words<8>(t, w); sc_to_words(tw, t);
-    ldw(w, a + 64);
-    ge Q, R; bool oc;
-    ge_frombytes(Q, oc, w, false);
-    ge_niels pcB;
-    niels_load(pcB, base16 + TABLE_ENTRY_WORDS);
-    if (form == 2) {
-      uint8_t* sp = scratch + i * LAYER_SCRATCH_BYTES;
-      int8_t* ux = reinterpret_cast<int8_t*>(sp);
-      int8_t* uy = ux + (REF_JSF_LEN + 3) / 4 * 4;
-      uint32_t* pts = reinterpret_cast<uint32_t*>(sp + 2 * ((REF_JSF_LEN + 3) / 4 * 4));
-      ref_dual_scale_uniform(R, sw, tw, Q, pcB, ux, uy, pts, 1);
-    } else {
-      ref_dual_scale(R, sw, tw, Q, pcB);
-    }
-    ge_tobytes(r, R); stw(o, r);
-  } else if (op == L_GE_DBL_ADD) {               // enc(2 P + k B), k < 65536 from the k B table: the windowed evaluation's two steps
-    ge P; bool oc;
-    ldw(w, a);
-    ge_frombytes(P, oc, w, false);
-    const uint32_t k = (uint32_t)a[32] | ((uint32_t)a[33] << 8);
-    ge_dbl(P, P, true);
-    ge_niels nb;
-    niels_load(nb, base16 + TABLE_ENTRY_WORDS * (k > 32768u ? 32768u : k));
-    ge_add_niels(P, P, nb, false);
-    ge_tobytes(r, P); stw(o, r);
-  }
-}
-
-// ed_scale_base with the comb staged in LDS and the shuffle lookup, as the point kernels run it (every lane of a wave
-// active: idle lanes redo the last item)
-__global__ void __launch_bounds__(POINT_BLOCK, 512 / POINT_BLOCK)
-k_debug_scale_base(uint8_t* out, const uint8_t* in, size_t n, const uint32_t* comb) {
-  __shared__ alignas(16) uint32_t lds_comb[COMB_IMG_WORDS];
-  stage_table(lds_comb, comb, COMB_IMG_WORDS);
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t w[8], xw[8], r[8];
-  load32(w, in, i < n ? i : n - 1, 32);
-  sc x;
-  sc_from_words<8>(x, w); sc_to_words(xw, x);
-  ge p;
-  scale_base_lane<1>(p, xw, lds_comb, 0);
-  if (i >= n) return;
-  ge_tobytes(r, p);
-  store32(out, i, 32, r);
-}
-
-// The four-lane forms (quad_lanes.h), one wave per block, 16 items per wave.
-// EDL_ED_DUAL_SCALE: set-up and chain of the exact path on a given (s, t, q): the lanes first build what k_verify_prepare
-// would have left - the digit words and entry 1 of the item's table, here the cached form of Q itself - in scratch.
-// scratch per item: 16 digit words | 2 table entries (64 words) | the chain's slot (QUAD_ITEM_WORDS)
-constexpr size_t LAYER_QUAD_SCRATCH_WORDS = 16 + 2 * VERIFY_ENTRY_WORDS + QUAD_ITEM_WORDS;
-__global__ void __launch_bounds__(QUAD_CHAIN_BLOCK, 2)
-k_debug_dual_scale_quad(uint8_t* out, const uint8_t* in, size_t n, const uint32_t* base16, uint32_t* scratch) {
-  __shared__ uint32_t lds_dig[QUAD_CHAIN_ITEMS * QUAD_DIGIT_WORDS];
-  const size_t quad = threadIdx.x >> 2;
-  const size_t g = (size_t)blockIdx.x * QUAD_CHAIN_ITEMS + quad;
-  const bool live = g < n;
-  const size_t i = live ? g : n - 1;             // (whole waves run: a quad past the end redoes the last item into its own slot)
-  const int q = (int)(threadIdx.x & 3u);
-  uint32_t* sp = scratch + g * LAYER_QUAD_SCRATCH_WORDS;
-  uint32_t* digits = sp; uint32_t* tab = sp + 16; uint32_t* item = sp + 16 + 2 * VERIFY_ENTRY_WORDS;
-  const uint8_t* a = in + i * 96;
-  if (q == 0) {
-    uint32_t w[8], sw[8], tw[8];
-    sc s, t;
-    ldw(w, a); sc_from_words<8>(s, w); sc_to_words(sw, s);
-    ldw(w, a + 32); sc_from_words<8>(t, w); sc_to_words(tw, t);
-    words_add_pattern(tw, 0x88888888u);
-    words_add_pattern(sw, 0x80008000u);
-    for (int k = 0; k < 8; k++) { digits[k] = tw[k]; digits[8 + k] = sw[k]; }
-  } else if (q == 1) {
-    uint32_t w[8];
-    ge Q; bool oc;
-    ldw(w, a + 64);
-    ge_frombytes(Q, oc, w, false);
-    ge_cached c;
-    ge_to_cached(c, Q);
-    cached_store(tab, 1, c);
-  }
-  __syncthreads();
-  uint32_t* dig = lds_dig + quad * QUAD_DIGIT_WORDS;
-  verify_exact_setup_quad(digits, tab, base16 + TABLE_ENTRY_WORDS, item, dig, q);
-  __syncthreads();
-  uint32_t wd[8];
-  exact_chain_encode_quad(wd, item, dig, q);
-  if (live && q == 1) store32(out, g, 32, wd);
-}
-
-// EDL_GE_DBL_ADD with a coordinate per lane: quad_dbl, then quad_add_entry from the k B table
-__global__ void __launch_bounds__(QUAD_CHAIN_BLOCK, 2)
-k_debug_dbl_add_quad(uint8_t* out, const uint8_t* in, size_t n, const uint32_t* base16) {
-  const size_t g = ((size_t)blockIdx.x * QUAD_CHAIN_BLOCK + threadIdx.x) >> 2;
-  const bool live = g < n;
-  const uint8_t* a = in + (live ? g : n - 1) * 40;
-  const int q = (int)(threadIdx.x & 3u);
-  uint32_t w[8];
-  ge P; bool oc;
-  ldw(w, a);
-  ge_frombytes(P, oc, w, false);
-  const uint32_t k = (uint32_t)a[32] | ((uint32_t)a[33] << 8);
-  fe r = q == 0 ? P.X : q == 1 ? P.Y : q == 2 ? P.T : P.Z;
-  quad_dbl(r, q);
-  quad_add_entry(r, base16 + TABLE_ENTRY_WORDS * (k > 32768u ? 32768u : k), false, false, q);
-  uint32_t wd[8];
-  quad_encode(wd, r);
-  if (live && q == 1) store32(out, g, 32, wd);
-}
-
 }  // namespace ed
 
 // =============================================================================================
@@ -1261,20 +1029,17 @@ hipError_t edk_x25519(uint8_t* out, const uint8_t* scalars, const uint8_t* point
   return hipGetLastError();
 }
 
-hipError_t edk_debug_halve(uint8_t* out, const uint8_t* t, size_t n, int wide, hipStream_t stream) {
-  if (n == 0) return hipSuccess;
-  if (wide) hipLaunchKernelGGL(k_debug_halve<HALF_BITS_SMALL>, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, out, t, n);
-  else hipLaunchKernelGGL(k_debug_halve<HALF_BITS>, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, out, t, n);
-  return hipGetLastError();
-}
-
 // the test hook of edk_checked.h: checked calls made since the count was restarted, and the call that is to fail
-static std::atomic<int> g_checked{0}, g_fail_at{0};
+static std::atomic<int> g_checked{0}, g_fail_at{0}, g_counting{0};
 int edk_fault_tick(void) {
-  const int k = g_checked.fetch_add(1, std::memory_order_relaxed) + 1;
+  // Unarmed (every production pass): one relaxed load of a line nobody writes.  The calls are counted only while a fault is
+  // pending or a test has restarted the count (g_counting): no shared counter is bumped on the hot path otherwise.
   int at = g_fail_at.load(std::memory_order_relaxed);
+  if (at == 0 && !g_counting.load(std::memory_order_relaxed)) return 0;
+  const int k = g_checked.fetch_add(1, std::memory_order_relaxed) + 1;
   return at != 0 && k == at && g_fail_at.compare_exchange_strong(at, 0);
 }
+void edk_debug_counting(int on) { g_counting.store(on != 0); }
 int edk_debug_fail_in(int nth) {
   if (nth < 0) return g_checked.load();
   g_fail_at.store(0);
@@ -1412,49 +1177,6 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   if (bulk_done && !bulk_early) EDK_DO(hipEventRecord(bulk_done, stream));
   if (ws->exact_offcurve) EDK_DO(hipStreamWaitEvent(stream, ws->ev_exact, 0));   // complete when both paths are
   return hipSuccess;
-}
-
-int edk_debug_layer_widths_ok(int op, int form, size_t in_w, size_t out_w) {
-  if (form < 0 || form > 2) return 0;
-  switch (op) {
-    case L_FE_MUL: return form == 0 && in_w == 64 && out_w == 32;
-    case L_FE_SQ: case L_FE_INV: case L_FE_POW2523: case L_SC_REDUCE32: case L_ED_SCALE_BASE: return form == 0 && in_w == 32 && out_w == 32;
-    case L_FE_MUL_LOOSE: return form == 0 && in_w == 72 && out_w == 32;
-    case L_SC_REDUCE64: return form == 0 && in_w == 64 && out_w == 32;
-    case L_SC_MULADD: return form == 0 && in_w == 96 && out_w == 32;
-    case L_SHA512: return form == 0 && in_w >= 8 && out_w == 64;
-    case L_ED_IMPORT_EXPORT: return form == 0 && in_w == 32 && out_w == 33;
-    case L_ED_DUAL_SCALE: return in_w == 96 && out_w == 32;
-    case L_GE_DBL_ADD: return form <= 1 && in_w == 40 && out_w == 32;
-  }
-  return 0;
-}
-
-hipError_t edk_debug_layer(int op, int form, uint8_t* out, size_t out_w, const uint8_t* in, size_t in_w, size_t n,
-                           const uint32_t* base16, const uint32_t* comb_img, hipStream_t stream) {
-  if (n == 0) return hipSuccess;
-  if (!edk_debug_layer_widths_ok(op, form, in_w, out_w)) return hipErrorInvalidValue;
-  void* scratch = nullptr;
-  hipError_t e = hipSuccess;
-  const unsigned qblocks = (unsigned)((n + QUAD_CHAIN_ITEMS - 1) / QUAD_CHAIN_ITEMS);
-  if (op == L_ED_SCALE_BASE) {
-    hipLaunchKernelGGL(k_debug_scale_base, dim3((unsigned)((n + POINT_BLOCK - 1) / POINT_BLOCK)), dim3(POINT_BLOCK), 0, stream, out, in, n, comb_img);
-  } else if (op == L_ED_DUAL_SCALE && form == 1) {
-    if ((e = hipMalloc(&scratch, (size_t)qblocks * QUAD_CHAIN_ITEMS * LAYER_QUAD_SCRATCH_WORDS * 4)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_debug_dual_scale_quad, dim3(qblocks), dim3(QUAD_CHAIN_BLOCK), 0, stream, out, in, n, base16, (uint32_t*)scratch);
-  } else if (op == L_GE_DBL_ADD && form == 1) {
-    hipLaunchKernelGGL(k_debug_dbl_add_quad, dim3(qblocks), dim3(QUAD_CHAIN_BLOCK), 0, stream, out, in, n, base16);
-  } else {
-    if (op == L_ED_DUAL_SCALE && form == 2 && (e = hipMalloc(&scratch, n * LAYER_SCRATCH_BYTES)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_debug_layer, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, op, form, out, out_w, in, in_w, n, base16, (uint8_t*)scratch);
-  }
-  e = hipGetLastError();
-  if (scratch) {                                   // a probe, not a hot path: wait, then release
-    const hipError_t e2 = hipStreamSynchronize(stream);
-    if (e == hipSuccess) e = e2;
-    (void)hipFree(scratch);                        // (teardown of a test buffer: public data, nothing to report to)
-  }
-  return e;
 }
 
 #define EDK_GRID(n) dim3((unsigned)(((n) + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream

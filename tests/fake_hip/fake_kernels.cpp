@@ -132,6 +132,7 @@ int edk_fault_tick(void) {
   int at = g_fail_at.load();
   return at != 0 && k == at && g_fail_at.compare_exchange_strong(at, 0);
 }
+void edk_debug_counting(int) {}
 int edk_debug_fail_in(int nth) {
   if (nth < 0) return g_checked.load();
   g_fail_at.store(0); g_checked.store(0); g_fail_at.store(nth);
@@ -296,26 +297,5 @@ hipError_t edk_sk_to_x(uint8_t* out, const uint8_t* in, size_t n, hipStream_t st
   enq(stream, [=] { for (size_t i = 0; i < n; i++) { uint32_t w[8], o[8]; rd(w, in + 32 * i); sk_to_x_lane(o, w); wr(out + 32 * i, o); } });
   return hipSuccess;
 }
-
-hipError_t edk_debug_halve(uint8_t* out, const uint8_t* t, size_t n, int wide, hipStream_t stream) {
-  own_stream(stream); own(out, 48 * n, "halve out"); own(t, 32 * n, "halve in");
-  enq(stream, [=] {
-    for (size_t i = 0; i < n; i++) {
-      uint32_t tw[8], vw[5], uw[5];
-      rd(tw, t + 32 * i);
-      bool ng;
-      const bool found = wide ? halve_scalar_lane<HALF_BITS_SMALL>(vw, uw, ng, tw) : halve_scalar_lane<HALF_BITS>(vw, uw, ng, tw);
-      uint32_t o[12];
-      for (int k = 0; k < 5; k++) { o[k] = vw[k]; o[5 + k] = uw[k]; }
-      o[10] = (ng ? 1u : 0u) | (found ? 0x100u : 0u); o[11] = 0;
-      memcpy(out + 48 * i, o, 48);
-    }
-  });
-  return hipSuccess;
-}
-
-// the layer probes exist to test what the DEVICE toolchain makes of the code: nothing to probe in this build
-int edk_debug_layer_widths_ok(int, int, size_t, size_t) { return 0; }
-hipError_t edk_debug_layer(int, int, uint8_t*, size_t, const uint8_t*, size_t, size_t, const uint32_t*, const uint32_t*, hipStream_t) { return hipErrorNotSupported; }
 
 }  // extern "C"

@@ -77,8 +77,56 @@ def test_the_hooks_are_inert_until_armed():
     off = -100002
     assert lib.eddsa_amd_debug_fail_next_host_call() == off
     assert lib.eddsa_amd_debug_fail_hip_call(3) == off
-    out = ctypes.create_string_buffer(32)
-    assert lib.eddsa_amd_debug_layer(1, 0, out, ctypes.c_size_t(32), bytes(64), ctypes.c_size_t(64), ctypes.c_size_t(1)) == off
+    lib.eddsa_amd_strerror.restype = ctypes.c_char_p
+    assert b"hooks not armed" in lib.eddsa_amd_strerror(off)      # (not whatever HIP calls error 100002)
+
+
+def test_the_layer_probes_are_a_library_of_their_own():
+    """the probe kernels (k_debug_layer spilled 107 registers) and their entry points used to ship inside
+    libeddsa_amd.so.  Now: libeddsa_amd_probe.so exports exactly what include/eddsa_amd_probe.h declares, the product
+    exports nothing of the kind, its device code holds no probe kernel, and no product kernel spills a vector register
+    or uses scratch memory (code-object metadata of the shipped library)"""
+    probe = os.path.join(ROOT, "libeddsa_amd", "libeddsa_amd_probe.so")
+    if not os.path.exists(probe):
+        subprocess.check_call(["make", "-C", ROOT, "probe"])
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "eddsa_amd_probe.h")).read(), flags=re.S)
+    declared = set(re.findall(r"EDDSA_PROBE_DECL\s+[\w\s\*]+?\b(\w+)\s*\(", text))
+    assert declared == {"eddsa_amd_probe_layer", "eddsa_amd_probe_halve"}
+    out = subprocess.check_output(["nm", "-D", "--defined-only", probe], text=True)
+    assert {l.split()[-1] for l in out.splitlines() if " T " in l} == declared
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib_path()], text=True)
+    assert not [l for l in out.splitlines() if "probe" in l or "debug_layer" in l or "debug_halve" in l]
+    ldd = subprocess.check_output(["ldd", probe], text=True)
+    assert "libeddsa" not in ldd and "oracle" not in ldd             # self-contained: HIP and libc only
+    # the product's code objects (one per .hip file, bundled in .hip_fatbin): kernel names and resources from their metadata
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-readelf")):
+        pytest.skip("no ROCm LLVM tools here")
+    import struct
+    import tempfile
+    notes = ""
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, "fat.bin")
+        subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, _lib_path(), os.path.join(d, "scratch.so")])
+        blob = open(fat, "rb").read()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        starts = [m.start() for m in re.finditer(magic, blob)]
+        assert len(starts) == 2                                       # kernels.hip and rlc.hip
+        for k, at in enumerate(starts):
+            (count,) = struct.unpack_from("<Q", blob, at + len(magic))
+            pos = at + len(magic) + 8
+            for _ in range(count):
+                off, size, tlen = struct.unpack_from("<QQQ", blob, pos)
+                triple = blob[pos + 24:pos + 24 + tlen].decode()
+                pos += 24 + tlen
+                if "gfx950" in triple:
+                    co = os.path.join(d, f"co{k}")
+                    open(co, "wb").write(blob[at + off:at + off + size])
+                    notes += subprocess.check_output([os.path.join(llvm, "llvm-readelf"), "--notes", co], text=True)
+    names = re.findall(r"\.name:\s+(\S+)", notes)
+    assert len(names) > 30 and not [n for n in names if "debug" in n or "probe" in n], [n for n in names if "debug" in n]
+    assert all(int(v) == 0 for v in re.findall(r"\.vgpr_spill_count:\s+(\d+)", notes))
+    assert all(int(v) == 0 for v in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes))
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -303,14 +351,28 @@ def test_bench_helpers_without_gpu(tmp_path, monkeypatch):
     assert bench.MUL32_X25519 == 1292 * 100 + 1278 * 55 + 256 * 10 == 202050
     assert bench.MUL32_SIGN == 506 * 100 + 254 * 55 == 64570
     assert abs(bench.PEAK_TMUL32 - 39.3216) < 1e-9
-    prof = tmp_path / "profiles"
-    prof.mkdir()
-    (prof / "pmc_summary.json").write_text(json.dumps({
-        "ed::k_a": {"FETCH_SIZE": 1000.0, "WRITE_SIZE": 10.0}, "ed::k_b": {"FETCH_SIZE": 24.0, "WRITE_SIZE": 6.0}}))
-    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    import source_hash
+    here = source_hash.device_source_hash()
+    assert len(here) == 64 and "kernels.hip" in source_hash.device_source_files() and "probe.hip" not in source_hash.device_source_files()
+    summary = {"ed::k_a": {"FETCH_SIZE": 1000.0, "WRITE_SIZE": 10.0, "SQ_INSTS_VALU": 512.0, "GRBM_GUI_ACTIVE": 32.0},
+               "ed::k_b": {"FETCH_SIZE": 24.0, "WRITE_SIZE": 6.0}, "_source": {"sha256": here}}
+    path = tmp_path / "pmc_summary.json"
+    path.write_text(json.dumps(summary))
+    monkeypatch.setattr(bench, "PMC_PATH", str(path))
+    bench._PMC_CACHE.clear()
     t = bench.pmc_traffic("k_a + k_b")
     assert t["bytes"] == (2 * 1024.0 + 16.0) * 1024.0 and t["fetch_size_kb_raw"] == 1024.0
     assert bench.pmc_traffic("k_missing") is None
+    assert bench.pmc_valu_busy("k_a")["value"] == 4.0 * 512 / (1024 * 32 / 8) and bench.pmc_note() is None
+    # counters recorded from OTHER kernel sources are not printed - one changed hex digit of the recorded
+    # hash (as after any edit of csrc/ without a new tools/profile.sh run), or a summary without a hash at all
+    for broken in ({**summary, "_source": {"sha256": ("0" if here[0] != "0" else "1") + here[1:]}},
+                   {k: v for k, v in summary.items() if k != "_source"}):
+        path.write_text(json.dumps(broken))
+        bench._PMC_CACHE.clear()
+        assert bench.pmc_traffic("k_a + k_b") is None and bench.pmc_valu_busy("k_a") is None and bench.pmc_executed("k_a", 64) is None
+        assert "other kernel sources" in bench.pmc_note()
+    bench._PMC_CACHE.clear()
 
 
 def test_c_shard_bounds_match_the_python_sharder():

@@ -1,7 +1,7 @@
 """Device-side layer KATs: every group of tests/golden/layer_kats.json - vectors produced
 by the reference's static library (fld_mul/sq/inv/pow2523 lib/fld.c:209-280,578-709, sc_import/sc_mul lib/sc.c:191-266,
 ed_import/ed_export/ed_scale_base/ed_dual_scale lib/ed.c:100-169,397-507, SHA-512 lib/sha512.c:127-210) - runs ON THE GPU
-as a layer, through the probe entry point eddsa_amd_debug_layer, in the one-lane form and, where it exists, in the
+as a layer, through the probe library's entry point eddsa_amd_probe_layer, in the one-lane form and, where it exists, in the
 four-lane (DPP) form, including operands at the documented limb bounds.  What the device toolchain makes of the limb
 arithmetic and of the lane exchanges is the one thing the host build of the same source cannot vouch for (the
 v_subrev_u32_dpp trap, DESIGN.md 7, was caught by a whole-operation KAT that happened to cover one limb).  Also here:
@@ -37,15 +37,16 @@ def probe(engine):
     engine.debug_init(0, False)
 
 
-def test_the_probe_is_inert_until_armed(engine):
+def test_the_hooks_are_inert_until_armed_and_the_probe_checks_its_arguments(engine):
     engine.debug_init(0, False)
-    with pytest.raises(engine.EddsaAmdError):
-        engine.debug_layer("fe_sq", [bytes(32)], 32)
     assert engine.debug_fail_hip_call(1) == engine.HOOKS_OFF and engine.debug_fail_next_host_call() == engine.HOOKS_OFF
     engine.debug_init(0, True)
+    # the layer probes are a library of their own (libeddsa_amd_probe.so), loaded beside the product: nothing to arm
     assert engine.debug_layer("fe_sq", [le(3)], 32) == [le(9)]
     with pytest.raises(engine.EddsaAmdError):                    # widths are checked per op
         engine.debug_layer("fe_mul", [bytes(32)], 32)
+    with pytest.raises(engine.EddsaAmdError):                    # a SHA-512 item whose length field exceeds its slot
+        engine.debug_layer("sha512", [(100).to_bytes(8, "little") + bytes(40)], 64)
     engine.debug_init(0, False)
 
 
@@ -125,7 +126,7 @@ def test_group_layer_kats_on_the_device(probe, golden, oracle):
     assert probe.debug_layer("ed_scale_base", xs, 32) == want
 
 
-def test_dual_scale_in_the_references_order_on_the_device_all_three_forms(probe, golden, oracle):
+def test_dual_scale_in_the_references_order_on_the_device_all_four_forms(probe, golden, oracle):
     """ed_dual_scale (lib/ed.c:455-507) replayed formula by formula: the literal chain, the uniform one, and the four-lane
     chain of the exact path (set-up and chain, DPP exchanges) - on curve points and on 'points' that are not on the curve,
     where the bytes depend on the exact sequence of formulas"""
@@ -145,7 +146,7 @@ def test_dual_scale_in_the_references_order_on_the_device_all_three_forms(probe,
     flags = probe.debug_layer("ed_import_export", [x[64:] for x in extra], 33)
     off = sum(1 for f in flags if f[32] == 0)
     assert off > 50                                               # plenty of off-curve inputs among them
-    for form in (0, 2, 1):
+    for form in (0, 2, 1, 3):                                     # 3: the one-lane throughput form (k_verify_exact_lane_*: table entries, stretches)
         got = probe.debug_layer("ed_dual_scale", items + extra, 32, form=form)
         bad = [i for i, (g, w) in enumerate(zip(got, want + extra_want)) if g.hex() != w]
         assert not bad, (form, bad[:10])

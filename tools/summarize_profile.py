@@ -60,6 +60,10 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc", "pmc_fetch_x25519", 
                 if "_" in sub.replace("pmc_", "", 1) or not any(c in out.get(k, {}) for c in cs):
                     out.setdefault(k, {}).update({c: sum(v) / len(v) for c, v in cs.items()})
                     out[k].update(meta[k])
+# what these counters were measured on: bench.py prints them only for the tree they belong to (tools/source_hash.py)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import source_hash
+out["_source"] = {"sha256": source_hash.device_source_hash(), "files": source_hash.device_source_files(), "tag": tag}
 for name in (f"{tag}_pmc_summary.json", "pmc_summary.json"):
     json.dump(out, open(os.path.join(dst, name), "w"), indent=1, sort_keys=True)
 for f in glob.glob(os.path.join(src, "bench_stats*.log")):
