@@ -31,7 +31,9 @@
 #include "eddsa_amd_debug.h"
 #include "eddsa_kernels.h"
 
+#ifndef CHUNK_MAX                     /* (tests/fake_hip builds one variant with tiny passes: tests/c/multi_passes.c) */
 #define CHUNK_MAX ((size_t)1 << 20)   /* verify items per workspace pass: 1.6 GB of HBM workspace */
+#endif
 #define MARK_SLOTS 256                /* profiled verify passes kept for eddsa_amd_verify_phase_ms */
 #define MAX_DEVICES 64
 

@@ -265,6 +265,11 @@ static void put(struct ihipStream_t *s, struct task t)
     s->tail = n;
 }
 
+/* deferred model: queued tasks that something has FORCED to run so far (a synchronisation, an event wait, a blocking copy) - a host
+ * side that enqueues without ever waiting leaves it unchanged (tests/c/multi_passes.c) */
+static long g_tasks_run;
+long fake_hip_tasks_run(void) { pthread_mutex_lock(&g_q); long v = g_tasks_run; pthread_mutex_unlock(&g_q); return v; }
+
 /* run the head of s until it is empty, or (ev != NULL) until record `gen` of ev has run.  g_q is held. */
 static void drain(struct ihipStream_t *s, struct ihipEvent_t *ev, long gen)
 {
@@ -276,7 +281,7 @@ static void drain(struct ihipStream_t *s, struct ihipEvent_t *ev, long gen)
         if (t->kind == T_WAIT && t->ev && t->ev->done < t->gen) drain(t->from, t->ev, t->gen);    /* the record it waits for, and what precedes it there */
         s->head = t->next;
         if (!s->head) s->tail = NULL;
-        if (t->kind == T_RUN) t->fn(t->arg);
+        if (t->kind == T_RUN) { g_tasks_run++; t->fn(t->arg); }
         else if (t->kind == T_RECORD && t->ev && t->ev->done < t->gen) t->ev->done = t->gen;
         free(t);
     }

@@ -16,6 +16,7 @@ void fake_hip_enqueue(struct ihipStream_t *s, void (*fn)(void *), void *arg);   
 void fake_hip_enqueue_group(int n, struct ihipStream_t *const *streams, void (*fn)(void *), void *const *args);   /* one task per (resolved) stream, queued together */
 struct ihipStream_t *fake_hip_resolve_stream(struct ihipStream_t *s);           /* NULL -> the current device's default stream */
 void fake_hip_run_until(struct ihipStream_t *s, const volatile int *flag);      /* inside a task only: run s until one of its tasks sets *flag */
+long fake_hip_tasks_run(void);                            /* deferred model: queued tasks that a host-side wait has forced to run so far */
 long fake_hip_calls(void);                                /* fallible runtime calls made so far (all threads) */
 void fake_hip_fail_call(long ordinal);                    /* the call with that ordinal fails instead of doing its work (one shot; 0: disarm) */
 long fake_hip_faults_fired(void);                         /* how many armed ordinals were reached */

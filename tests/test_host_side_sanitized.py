@@ -10,6 +10,8 @@ Run under -fsanitize=thread and -fsanitize=address,undefined:
                               ed25519_verify_batch_multi_dev over 2, 3 and 8 devices - equal shards (one grouped in-place
                               all-gather) and 2^k - 3 items (unequal shards: one broadcast per shard) - every device's
                               gathered vector equal to the single-device verdicts
+  tests/c/multi_passes.c      ed25519_verify_batch_multi_dev with seven passes per device (a build with passes of 64 items): in the
+                              deferred model no queued task may be forced to run inside the call - no device waits on another
   tests/c/threaded_callers.c  64 threads looping over the eddsa.h single-item functions: the flat combiner
   tests/c/host_side_stress.c  multi-chunk pipelines with ragged messages, the fault hooks, the trace switched on and off
                               under load, two concurrent shutdowns beside callers, nothing leaked
@@ -58,7 +60,7 @@ def build(request):
     r = subprocess.run(["make", "-C", FAKE, "-j4", "SAN=" + san], capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     out = os.path.join(FAKE, "_build", san)
-    for exe in ("multi_device", "threaded_callers", "host_side_stress", "host_fault_walk", "selftest_dropin"):
+    for exe in ("multi_device", "threaded_callers", "host_side_stress", "host_fault_walk", "selftest_dropin", "multi_passes"):
         # test binaries against the fake runtime: they must not pull in the real one
         ldd = subprocess.check_output(["ldd", os.path.join(out, exe)], text=True)
         assert "libamdhip64" not in ldd and "libfakehip.so" in ldd, ldd
@@ -83,6 +85,18 @@ def test_multi_device_entry_points_over_several_devices(build, msgs, devices, de
     text = run(out, "multi_device", [os.path.join(GOLD, "ed25519_table.bin"), msgs, 96, 253], devices, defer=defer)
     assert f"multi_device: ok ({devices} devices" in text
     assert f"fake RCCL ran 1 all-gather and {devices} broadcasts over {devices} ranks" in text   # both forms of the gather ran
+
+
+@pytest.mark.parametrize("devices", [2, 8])
+def test_no_device_waits_on_another_with_many_passes_per_device(build, devices):
+    """ed25519_verify_batch_multi_dev enqueues the devices' passes from ONE host thread.  With the host side
+    built for passes of 64 items, shards of 389 items are seven passes per device - more than the four workspaces of a
+    device's pool - and in the deferred model any host-side wait inside the call would force queued tasks to run:
+    tests/c/multi_passes.c requires that none does, that every device's queue is full when the call returns, and that
+    every device ends with the single-device verdicts"""
+    san, out = build
+    text = run(out, "multi_passes", [os.path.join(GOLD, "ed25519_table.bin")], devices, defer=1)
+    assert f"multi_passes: ok ({devices} devices" in text
 
 
 @pytest.mark.parametrize("defer", [0, 1])
