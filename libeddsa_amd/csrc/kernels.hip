@@ -185,10 +185,13 @@ constexpr int QUAD_SPREAD_WAVES = 256;           // a short work list is spread 
 #endif
 constexpr size_t EXACT_DENSE_MIN_N = (size_t)1 << EXACT_DENSE_LOG2;   // passes from this size on pack the chain's items 16 to the wave whatever their number
 #ifndef EXACT_LANE_MIN_LOG2
-#define EXACT_LANE_MIN_LOG2 15
+#define EXACT_LANE_MIN_LOG2 13
 #endif
 constexpr size_t EXACT_LANE_MIN_LISTED = (size_t)1 << EXACT_LANE_MIN_LOG2;   // work lists from this length on go to k_verify_exact_lane_* ...
-constexpr size_t EXACT_LANE_MIN_N = (size_t)1 << 16;                          // ... in passes of at least this many items
+#ifndef EXACT_LANE_MIN_N_LOG2
+#define EXACT_LANE_MIN_N_LOG2 16
+#endif
+constexpr size_t EXACT_LANE_MIN_N = (size_t)1 << EXACT_LANE_MIN_N_LOG2;      // ... in passes of at least this many items
 static_assert((size_t)EDK_EXACT_SLOTS * QUAD_ITEM_WORDS * 4 <= EDK_EXACT_PAD_BYTES, "scratchpad too small");
 static_assert(EDK_EXACT_SLOTS % QUAD_CHAIN_ITEMS == 0, "whole waves");
 
@@ -1105,14 +1108,10 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
     const uint32_t lane_min = n >= EXACT_LANE_MIN_N ? (uint32_t)EXACT_LANE_MIN_LISTED : 0u;
     EDK_DO(hipEventRecord(ws->ev_prepared, stream));
     EDK_DO(hipStreamWaitEvent(ws->side, ws->ev_prepared, 0));
-    for (size_t first = 0; first < n; first += (size_t)EDK_EXACT_SLOTS) {
-      const size_t qi = n - first < (size_t)EDK_EXACT_SLOTS ? n - first : (size_t)EDK_EXACT_SLOTS;
-      const size_t dense = (qi + QUAD_CHAIN_ITEMS - 1) / QUAD_CHAIN_ITEMS, spread = qi < (size_t)QUAD_SPREAD_WAVES ? qi : (size_t)QUAD_SPREAD_WAVES;
-      EDK_LAUNCH(k_verify_exact_quad, dim3((unsigned)(dense > spread ? dense : spread)), dim3(QUAD_CHAIN_BLOCK), 0, ws->side, ok,
-                 src.sigs, src.sig_stride, ws->digits, ws->table, ws->offlist, ws->offcount, base16, ws->exact_pad, first,
-                 (int)(n >= EXACT_DENSE_MIN_N), lane_min);
-      if (lane_min != 0 && first + (size_t)EDK_EXACT_SLOTS >= (size_t)lane_min) break;   // a list that reaches the next stretch is the one-lane kernels'
-    }
+    // The one-lane kernels go FIRST on the side stream: when the list is short they end at once, and they must do so while
+    // the chip still has room for their (large) blocks - queued behind the four-lane chain they reached the dispatcher a
+    // millisecond into a full k_verify_main_half, where each of their 512 idle blocks had to wait for two wave slots of one
+    // SIMD to fall free together (profiles/r05_exact_lane.txt: same-box A/B, 107.2 -> 107.9 M/s on config 2).
     if (lane_min != 0) {
       const unsigned lane_blocks = blocks < EXACT_LANE_BLOCKS ? blocks : EXACT_LANE_BLOCKS;
       // (the scratchpad of the four-lane chain is free when these run: it holds their per-tile counts)
@@ -1120,6 +1119,14 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
                  ws->offcount, base16, ws->exact_pad, lane_min);
       EDK_LAUNCH(k_verify_exact_lane_chain, dim3(lane_blocks), dim3(BLOCK), 0, ws->side, ok, src.sigs, src.sig_stride, ws->table, ws->rtable,
                  ws->offlist, ws->offcount, ws->exact_pad, lane_min);
+    }
+    for (size_t first = 0; first < n; first += (size_t)EDK_EXACT_SLOTS) {
+      const size_t qi = n - first < (size_t)EDK_EXACT_SLOTS ? n - first : (size_t)EDK_EXACT_SLOTS;
+      const size_t dense = (qi + QUAD_CHAIN_ITEMS - 1) / QUAD_CHAIN_ITEMS, spread = qi < (size_t)QUAD_SPREAD_WAVES ? qi : (size_t)QUAD_SPREAD_WAVES;
+      EDK_LAUNCH(k_verify_exact_quad, dim3((unsigned)(dense > spread ? dense : spread)), dim3(QUAD_CHAIN_BLOCK), 0, ws->side, ok,
+                 src.sigs, src.sig_stride, ws->digits, ws->table, ws->offlist, ws->offcount, base16, ws->exact_pad, first,
+                 (int)(n >= EXACT_DENSE_MIN_N), lane_min);
+      if (lane_min != 0 && first + (size_t)EDK_EXACT_SLOTS >= (size_t)lane_min) break;   // a list that reaches the next stretch is the one-lane kernels'
     }
     EDK_DO(hipEventRecord(ws->ev_exact, ws->side));
   }

@@ -30,7 +30,7 @@ ed.debug_init(0, True)
 flags = ed.debug_layer("ed_import_export", [bytes(r) for r in garbage[:400000].cpu().numpy()], 33)
 off = np.array([f[32] == 0 for f in flags])
 idx_off = np.nonzero(off)[0]
-for k in (32768, 65000, 65536, 65537, 66000, 70000, 131072):
+for k in (2048, 4096, 8192, 16384, 32768, 65536, 131072):
     keys = pk.clone()
     sel = torch.from_numpy(idx_off[:k]).cuda()
     keys[sel] = garbage[sel]

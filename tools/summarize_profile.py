@@ -28,7 +28,7 @@ def kernel_name(raw):
 
 
 rows = []
-for sub in ("stats_all", "stats", "stats_x25519", "stats_sign", "stats_rlc"):
+for sub in ("stats_all", "stats", "stats_x25519", "stats_sign", "stats_rlc", "stats_exact"):
     for f in glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv")):
         for r in csv.DictReader(open(f)):
             if kernel_name(r["Name"]).startswith("ed::"):
@@ -43,7 +43,7 @@ if rows:
 
 out = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc", "pmc_fetch_x25519", "pmc_write_x25519",
-            "pmc_fetch_sign", "pmc_write_sign", "pmc_sq_x25519", "pmc_sq_sign"):
+            "pmc_fetch_sign", "pmc_write_sign", "pmc_sq_x25519", "pmc_sq_sign", "pmc_sq_exact", "pmc_fetch_exact"):
     for f in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         meta = {}
@@ -55,6 +55,8 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc", "pmc_fetch_x25519", 
                        "Scratch_Size": int(r["Scratch_Size"]), "Grid_Size": int(r["Grid_Size"]),
                        "Workgroup_Size": int(r["Workgroup_Size"])}
         for k, cs in agg.items():
+            if sub.endswith("_exact") and "exact_lane" not in k:
+                continue                       # (that workload's other kernels ran over mixed list lengths: the bench passes speak for them)
             if k.startswith("ed::"):
                 # the verify workload builder also runs sign/genpub once; prefer the op's own pass
                 if "_" in sub.replace("pmc_", "", 1) or not any(c in out.get(k, {}) for c in cs):
