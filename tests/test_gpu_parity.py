@@ -195,6 +195,40 @@ def test_off_curve_keys_take_the_exact_path(engine, oracle):
         engine.set_offcurve_mode(True)
 
 
+@pytest.mark.parametrize("n", [1 << 16, (1 << 18) + 77])
+def test_both_forms_of_the_exact_path_around_their_threshold(engine, oracle, n):
+    """Which form replays the reference's chain for the keys that are no curve points is decided on the device by the length of
+    the work list: below 8192 entries the four-lane chain (k_verify_exact_quad), from there on one lane per item
+    (k_verify_exact_lane_setup / _chain; csrc/kernels.hip: EXACT_LANE_MIN_LISTED).  Passes with exactly 8191, 8192 and 8193 such
+    keys - and none, and one - on both routes that have the choice (2^16 items: three-lane preparation; 2^18 + 77: one lane per
+    item), genuine signatures and R = 0 under the bad keys: every verdict as the oracle's"""
+    rng = np.random.default_rng(n)
+    m = 4096
+    sk = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    msg = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    pk = oracle.genpub_batch(sk)
+    sig = oracle.sign_batch(sk, pk, msg, 32)
+    reps = (n + m - 1) // m
+    sig_n, pk_n, msg_n = (np.tile(a, (reps, 1))[:n].copy() for a in (sig, pk, msg))
+    # 8200 distinct strings that are no curve points (the probe library's ed_import reports the flag)
+    engine.debug_init(0, True)
+    try:
+        cand = rng.integers(0, 256, (20000, 32), dtype=np.uint8)
+        flags = engine.debug_layer("ed_import_export", [bytes(r) for r in cand], 33)
+    finally:
+        engine.debug_init(0, False)
+    off = cand[np.array([f[32] == 0 for f in flags])][:8200]
+    assert len(off) == 8200
+    spots = rng.permutation(n)[:8200]
+    for k in (0, 1, 8191, 8192, 8193):
+        keys, s2 = pk_n.copy(), sig_n.copy()
+        keys[spots[:k]] = off[:k]
+        s2[spots[:k:5], :32] = 0                     # R = 0 under some of them (the Z = 0 corner of the chain)
+        want = oracle.verify_batch(s2, keys, msg_n, 32)
+        assert want.sum() == n - k
+        assert np.array_equal(engine.ed25519_verify_batch(dev(s2), dev(keys), dev(msg_n), msg_len=32).cpu().numpy(), want), k
+
+
 def test_every_item_through_the_reference_order_kernels(engine):
     """self-check mode 2: all 70 000 items (more than the 65 536 the setup/chain kernels take, so the
     strided k_verify_exact runs too) are decided by the replay of the reference's JSF/Shamir chain;
