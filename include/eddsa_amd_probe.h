@@ -44,7 +44,9 @@ extern "C" {
  *                                                                               form 0 literal, form 2 with uniform control flow,
  *                                                                               form 1 the four-lane chain (set-up + chain of the exact path),
  *                                                                               form 3 the one-lane throughput form (set-up into the item's
- *                                                                               table, the chain stretch by stretch: k_verify_exact_lane_*)
+ *                                                                               table, the chain stretch by stretch), form 4 two items per
+ *                                                                               lane (this item and the next of the batch) in units of work, as
+ *                                                                               k_verify_exact_lane_chain walks them
  *   EDL_GE_DBL_ADD            p 32 | k 2 (LE) | pad 6                      32   enc(2 P + k B): form 0 ge_dbl + ge_add_niels, form 1 quad_dbl +
  *                                                                               quad_add_entry (the windowed evaluation's two steps)
  */

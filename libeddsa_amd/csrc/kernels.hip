@@ -246,8 +246,8 @@ k_verify_exact_quad(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const u
 // The set-up writes into the item's OWN workspace - Q + B and Q - B over entries 2 and 3 of its table, the digit string
 // over the first words of its rtable slot - which nobody reads for such an item: the windowed kernels skip it (on the
 // half-length route they do not even visit it, see k_verify_prepare) or discard what they compute from it.
-// Work is handed out to WAVES, one (stretch, tile) unit at a time from a counter: a tile is 64 entries of the list, a stretch a
-// quarter of the chain (lanes.h: EXACT_SEGS), the accumulators cross from stretch to stretch through the items' workspace and
+// Work is handed out to WAVES, one (stretch, tile) unit at a time from a counter: a tile is 128 entries of the list (two per lane),
+// a stretch EXACT_PAIR_ITERS iterations of the walk (lanes.h: exact_pair_iterations; the last one runs to the end), the accumulators cross from stretch to stretch through the items' workspace and
 // a wave that draws stretch s of a tile waits for the tile's stretch s - 1 (tile_done; units are drawn in the order stretch 0 of
 // every tile, stretch 1 of every tile, ..., so the wait is over before it starts unless the list is shorter than the chip).
 // Why not one chain per lane per launch slot: beside k_verify_main_half half of these blocks become resident late, and with a
@@ -273,7 +273,8 @@ k_verify_exact_lane_chain(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, c
                           const uint32_t* offlist, uint32_t* offcount, uint32_t* tile_done, uint32_t min_listed) {
   const size_t listed = *offcount;
   if (listed < min_listed) return;
-  const unsigned tiles = (unsigned)((listed + 63) / 64), units = tiles * (unsigned)EXACT_SEGS;
+  // a tile is 128 entries of the list: a lane walks TWO chains, entries L and 64 + L of the tile (lanes.h: exact_pair_iterations)
+  const unsigned tiles = (unsigned)((listed + 127) / 128), units = tiles * (unsigned)EXACT_SEGS;
   const unsigned lane = threadIdx.x & 63u;
   // no more waves than tiles: one that drew a later stretch of a tile still in its first would only hold, waiting, a slot
   // that a wave of k_verify_main_half could use
@@ -291,18 +292,36 @@ k_verify_exact_lane_chain(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, c
         while (__hip_atomic_load(tile_done + tile, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seg) __builtin_amdgcn_s_sleep(16);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
-    const size_t g = (size_t)tile * 64 + lane;
-    const bool live = g < listed;
-    const size_t i = offlist[live ? g : listed - 1];             // an idle lane redoes the last entry (and stores nothing)
-    uint32_t rw[8];
-    load32(rw, sigs, i, sig_stride);
-    uint32_t* slot = rtable + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS);
-    const bool same = verify_exact_chain_segment_lane((int)seg, rw, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), offcount + EDK_BENTRY_WORD,
-                                                      slot + EXACT_DIGITS_AT, 1, slot + EXACT_STATE_AT, live);
-    if (seg == (unsigned)EXACT_SEGS - 1) {
-      if (live) ok[i] = (uint8_t)same;
+    const size_t ga = (size_t)tile * 128 + lane, gb = ga + 64;
+    const bool live_a = ga < listed, live_b = gb < listed;
+    const uint32_t ia = offlist[live_a ? ga : listed - 1], ib = offlist[live_b ? gb : listed - 1];   // (an idle half walks nothing and stores nothing)
+    constexpr uint32_t SLOT = VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS;
+    ge ra, rb;
+    exact_walk wa, wb;
+    if (seg == 0) {
+      ge_neutral(ra); ge_neutral(rb);
+      wa = exact_walk_start(rtable + (size_t)ia * SLOT + EXACT_DIGITS_AT, 1, live_a);
+      wb = exact_walk_start(rtable + (size_t)ib * SLOT + EXACT_DIGITS_AT, 1, live_b);
     } else {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");         // every lane's accumulator is out before the count says so
+      exact_walk_load(ra, wa, rtable + (size_t)ia * SLOT + EXACT_STATE_AT);
+      exact_walk_load(rb, wb, rtable + (size_t)ib * SLOT + EXACT_STATE_AT);
+      if (!live_a) { wa.i = -1; wa.pend = false; }
+      if (!live_b) { wb.i = -1; wb.pend = false; }
+    }
+    const bool last = seg == (unsigned)EXACT_SEGS - 1;
+    exact_pair_iterations(ra, wa, rb, wb, table, rtable + EXACT_DIGITS_AT, SLOT, ia, ib, offcount + EDK_BENTRY_WORD, last ? -1 : EXACT_PAIR_ITERS);
+    if (last) {
+      uint32_t rwa[8], rwb[8];
+      load32(rwa, sigs, ia, sig_stride);
+      load32(rwb, sigs, ib, sig_stride);
+      bool same_a, same_b;
+      exact_pair_verdicts(same_a, same_b, ra, rb, rwa, rwb);
+      if (live_a) ok[ia] = (uint8_t)same_a;
+      if (live_b) ok[ib] = (uint8_t)same_b;
+    } else {
+      if (live_a) exact_walk_store(rtable + (size_t)ia * SLOT + EXACT_STATE_AT, ra, wa);
+      if (live_b) exact_walk_store(rtable + (size_t)ib * SLOT + EXACT_STATE_AT, rb, wb);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");         // every lane's accumulators are out before the count says so
       if (lane == 0) __hip_atomic_fetch_add(tile_done + tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }

@@ -1015,6 +1015,177 @@ ED_DEV bool verify_exact_chain_segment_lane(int seg, const uint32_t rw[8], const
   return exact_chain_verdict(r, rw);
 }
 
+// ---------------------------------------------------------------------------------------------
+// TWO items per lane.  A joint sparse form has a digit pair in every second step, and a wave of 64 items has one in every
+// step: run step by step, the chain's addition phase (8 M of the step's 13 M + 4 S) does useful work in half of its lanes.  Here a
+// lane carries two items, each at its own step, and an iteration is ONE addition phase - for the item with an addition
+// pending; of two, the one further behind - followed by a doubling phase per item: an item moves one step per iteration unless
+// it loses the addition to its neighbour (a quarter of the iterations), ~300 iterations of 2 D + 1 A for two chains instead of
+// 2 x 261 of D + A.  Same formulas on the same values in the same order per item (ed.c:479-506), so the same bytes.
+// ---------------------------------------------------------------------------------------------
+struct exact_walk { int i; bool pend; };         // i: the step whose addition (pend) or doubling comes next; -1: the chain is done
+
+ED_DEV uint32_t exact_nibble(const uint32_t* dig, int dstride, int i) {
+  const int j = i < 0 ? 0 : i;
+  return (dig[(j >> 3) * dstride] >> (4 * (j & 7))) & 15u;
+}
+ED_DEV void ge_select(ge& r, const ge& v, bool flag) {
+  fe_cmov(r.X, v.X, flag); fe_cmov(r.Y, v.Y, flag); fe_cmov(r.Z, v.Z, flag); fe_cmov(r.T, v.T, flag);
+}
+// the walk of an item before its first iteration: at the top digit, its addition pending if the digit pair is not (0, 0)
+ED_DEV exact_walk exact_walk_start(const uint32_t* dig, int dstride, bool live) {
+  exact_walk w;
+  w.i = live ? REF_JSF_LEN - 1 : -1;
+  w.pend = live && exact_nibble(dig, dstride, REF_JSF_LEN - 1) != 5u;
+  return w;
+}
+// which item the next addition phase serves: 0 none, 1 the first, 2 the second
+ED_DEV int exact_pair_choice(const exact_walk& a, const exact_walk& b) {
+  return a.pend && b.pend ? (a.i >= b.i ? 1 : 2) : a.pend ? 1 : b.pend ? 2 : 0;
+}
+// r += (neg ? -q : q), q a packed cached entry as loaded: ge_cached_cneg + ge_add_cached with the entry's four factors unpacked
+// one at a time, each right before its multiplication (forty registers less alive than with the entry unpacked up front)
+ED_DEV void ge_add_raw(ge& r, const cached_raw& raw, bool neg) {
+  fe a, b, c, d, e, f, g, h, m;
+  uint32_t w[8];
+  // negating the addend swaps y-x with y+x and negates 2d t (ed.c:245-273)
+#define RAW_WORDS(k) { w[0] = raw.q[2 * (k)].x; w[1] = raw.q[2 * (k)].y; w[2] = raw.q[2 * (k)].z; w[3] = raw.q[2 * (k)].w; \
+                       w[4] = raw.q[2 * (k) + 1].x; w[5] = raw.q[2 * (k) + 1].y; w[6] = raw.q[2 * (k) + 1].z; w[7] = raw.q[2 * (k) + 1].w; }
+#define RAW_WORDS_SEL(k0, k1) { w[0] = neg ? raw.q[2 * (k1)].x : raw.q[2 * (k0)].x; w[1] = neg ? raw.q[2 * (k1)].y : raw.q[2 * (k0)].y; \
+                                w[2] = neg ? raw.q[2 * (k1)].z : raw.q[2 * (k0)].z; w[3] = neg ? raw.q[2 * (k1)].w : raw.q[2 * (k0)].w; \
+                                w[4] = neg ? raw.q[2 * (k1) + 1].x : raw.q[2 * (k0) + 1].x; w[5] = neg ? raw.q[2 * (k1) + 1].y : raw.q[2 * (k0) + 1].y; \
+                                w[6] = neg ? raw.q[2 * (k1) + 1].z : raw.q[2 * (k0) + 1].z; w[7] = neg ? raw.q[2 * (k1) + 1].w : raw.q[2 * (k0) + 1].w; }
+  RAW_WORDS_SEL(0, 1)
+  fe_unpack(m, w);
+  fe_sub(a, r.Y, r.X);                          // 3u
+  fe_mul(a, a, m);
+  RAW_WORDS_SEL(1, 0)
+  fe_unpack(m, w);
+  fe_add(b, r.Y, r.X);                          // 2u
+  fe_mul(b, b, m);
+  RAW_WORDS(2)
+  fe_unpack(m, w);
+  { fe n; fe_neg(n, m); fe_cmov(m, n, neg); }   // < 2u: fine as a second operand
+  fe_mul(c, r.T, m);
+  RAW_WORDS(3)
+  fe_unpack(m, w);
+  fe_mul(d, r.Z, m);
+#undef RAW_WORDS
+#undef RAW_WORDS_SEL
+  fe_sub(e, b, a);                              // 3u
+  fe_sub(f, d, c);                              // 3u
+  fe_add(g, d, c);                              // 2u
+  fe_add(h, b, a);                              // 2u
+  fe_mul(r.X, e, f);
+  fe_mul(r.Y, g, h);
+  fe_mul(r.Z, g, f);
+  fe_mul(r.T, e, h);
+}
+
+ED_DEV void ge_cswap(ge& a, ge& b, bool flag) {
+  fe_cswap(a.X, b.X, flag); fe_cswap(a.Y, b.Y, flag); fe_cswap(a.Z, b.Z, flag); fe_cswap(a.T, b.T, flag);
+}
+// `iters` iterations (iters < 0: until both items of every lane of the wave are done; the host build: of this lane).
+// An item is named by its slot number: its table is at tabs + slot * slot_words, its digit string at digs + slot * slot_words
+// (two 32-bit numbers per lane instead of four pointers: the kernel has no register to spare).
+// The item the addition phase serves is brought into the FIRST register set by a conditional exchange of the two sets (and of
+// their walks and slot numbers) and stays there: one exchange per iteration instead of a copy in and a copy out, and no third
+// accumulator alive during the addition.  The sets are put back at the end.
+ED_DEV void exact_pair_iterations(ge& ra, exact_walk& wa, ge& rb, exact_walk& wb, const uint32_t* tabs, const uint32_t* digs,
+                                  uint32_t slot_words, uint32_t item_a, uint32_t item_b, const uint32_t* bentry, int iters) {
+#define EXACT_TAB(item) (tabs + (size_t)(item) * slot_words)
+#define EXACT_DIG(item) (digs + (size_t)(item) * slot_words)
+  bool flipped = false;
+  int sel = exact_pair_choice(wa, wb);
+  exact_step st = exact_step_of(sel == 2 ? exact_nibble(EXACT_DIG(item_b), 1, wb.i) : exact_nibble(EXACT_DIG(item_a), 1, wa.i));
+  st.skip = st.skip || sel == 0;
+  const uint32_t* entry = exact_entry_of(st, EXACT_TAB(sel == 2 ? item_b : item_a), bentry);
+  struct { word4 q[4]; } half;
+  {
+    const word4* e4 = reinterpret_cast<const word4*>(entry);
+#pragma unroll
+    for (int q = 0; q < 4; q++) half.q[q] = e4[q];
+  }
+#pragma unroll 1
+  for (int it = 0;; it++) {
+#ifdef ED_HOST_CHECK
+    if (iters >= 0 ? it == iters : (wa.i < 0 && wb.i < 0)) break;
+#else
+    if (iters >= 0 ? it == iters : !__any(wa.i >= 0 || wb.i >= 0)) break;
+#endif
+    {                                            // the addition phase (ed.c:480-501) for the chosen item: in the first set
+      // the second half of the entry (2d t, 2 z): requested now, used two multiplications further down
+      cached_raw raw;
+      {
+        const word4* e4 = reinterpret_cast<const word4*>(entry);
+#pragma unroll
+        for (int q = 0; q < 4; q++) { raw.q[q] = half.q[q]; raw.q[4 + q] = e4[4 + q]; }
+      }
+      const bool x = sel == 2;
+      ge_cswap(ra, rb, x);
+      { const exact_walk t = wa; wa = x ? wb : wa; wb = x ? t : wb; }
+      { const uint32_t t = item_a; item_a = x ? item_b : item_a; item_b = x ? t : item_b; }
+      flipped = flipped != x;
+      // (a branch, not a select: the lanes without an addition sit the phase out under the execution mask and their
+      // accumulator needs no second copy - with selects here and below the kernel spilled 58 registers)
+      if (sel != 0) ge_add_raw(ra, raw, st.neg);
+      wa.pend = wa.pend && sel == 0;
+    }
+    // what the doubling phases below do, and whom the NEXT addition phase serves, follow from the digits alone
+    const bool go_a = wa.i >= 0 && !wa.pend, go_b = wb.i >= 0 && !wb.pend;       // the item leaves its step in this iteration
+    const bool dbl_a = go_a && wa.i > 0, dbl_b = go_b && wb.i > 0;               // ed.c:503-505: no doubling after the last digit
+    if (go_a) { wa.i = wa.i - 1; wa.pend = wa.i >= 0 && exact_nibble(EXACT_DIG(item_a), 1, wa.i) != 5u; }
+    if (go_b) { wb.i = wb.i - 1; wb.pend = wb.i >= 0 && exact_nibble(EXACT_DIG(item_b), 1, wb.i) != 5u; }
+    sel = exact_pair_choice(wa, wb);
+    st = exact_step_of(sel == 2 ? exact_nibble(EXACT_DIG(item_b), 1, wb.i) : exact_nibble(EXACT_DIG(item_a), 1, wa.i));
+    st.skip = st.skip || sel == 0;
+    entry = exact_entry_of(st, EXACT_TAB(sel == 2 ? item_b : item_a), bentry);
+    // The FIRST half of the next entry (y-x, y+x: 16 registers) is requested between the two doublings and arrives behind the
+    // second; the whole entry this early (32 registers across a doubling) left the kernel 10 registers short, and none of it
+    // (a load in front of the addition) cost 5 % of VALU-busy.
+    if (dbl_a) ref_double(ra, ra);
+    {
+      const word4* e4 = reinterpret_cast<const word4*>(entry);
+#pragma unroll
+      for (int q = 0; q < 4; q++) half.q[q] = e4[q];
+    }
+    if (dbl_b) ref_double(rb, rb);
+  }
+  ge_cswap(ra, rb, flipped);
+  { const exact_walk t = wa; wa = flipped ? wb : wa; wb = flipped ? t : wb; }
+#undef EXACT_TAB
+#undef EXACT_DIG
+}
+
+// the accumulator and the walk of an item between two units of work: EXACT_STATE_WORDS + 2 words of its workspace
+ED_DEV void exact_walk_store(uint32_t* st, const ge& r, const exact_walk& w) {
+  exact_state_store(st, r);
+  st[EXACT_STATE_WORDS] = (uint32_t)w.i; st[EXACT_STATE_WORDS + 1] = w.pend ? 1u : 0u;
+}
+ED_DEV void exact_walk_load(ge& r, exact_walk& w, const uint32_t* st) {
+  exact_state_load(r, st);
+  w.i = (int)st[EXACT_STATE_WORDS]; w.pend = st[EXACT_STATE_WORDS + 1] != 0;
+}
+
+// ed_export of both results on ONE inversion (ed.c:155-169; fld_inv(0) = 0: a zero Z contributes 1 to the shared product and gets the
+// inverse 0 by hand), then the byte comparisons (ed25519-sha512.c:176-180)
+ED_DEV void exact_pair_verdicts(bool& same_a, bool& same_b, const ge& ra, const ge& rb, const uint32_t rwa[8], const uint32_t rwb[8]) {
+  fe one, zero, za = ra.Z, zb = rb.Z, p, u, zia, zib;
+  fe_set(one, 1); fe_set(zero, 0);
+  const bool nza = !fe_iszero(za), nzb = !fe_iszero(zb);
+  fe_cmov(za, one, !nza); fe_cmov(zb, one, !nzb);
+  fe_mul(p, za, zb);
+  fe_inv(u, p);
+  fe_mul(zia, u, zb);
+  fe_mul(zib, u, za);
+  fe_cmov(zia, zero, !nza); fe_cmov(zib, zero, !nzb);
+  same_a = verify_encode_lane(ra.X, ra.Y, zia, rwa);
+  same_b = verify_encode_lane(rb.X, rb.Y, zib, rwb);
+}
+
+// the iterations of a unit of work: the first EXACT_SEGS - 1 units of a tile run this many, the last one runs to the end
+constexpr int EXACT_PAIR_ITERS = 75;
+
 // the whole chain of one item in one go (host build; the kernels run it stretch by stretch)
 ED_DEV bool verify_exact_chain_table_lane(const uint32_t rw[8], const uint32_t* tab, const uint32_t* bentry,
                                           const uint32_t* dig, int dstride) {

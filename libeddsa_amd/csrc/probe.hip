@@ -75,6 +75,9 @@ constexpr size_t LAYER_SCRATCH_BYTES = 2 * ((REF_JSF_LEN + 3) / 4 * 4) + 160 * 4
 // form 3: four table entries | 36 digit words | the accumulator between stretches | 16 digit words | padding | the shared entry; 128-byte aligned slots
 constexpr size_t LAYER_TABLE_SCRATCH_BYTES = (4 * VERIFY_ENTRY_WORDS + 36 + EXACT_STATE_WORDS + 16 + 4 + VERIFY_ENTRY_WORDS) * 4;
 static_assert(LAYER_TABLE_SCRATCH_BYTES % 128 == 0, "entries are 128-byte lines");
+// form 4: two table slots | two slots for digits (at +64 words) and walks (at +128) | the shared entry
+constexpr size_t LAYER_PAIR_SCRATCH_BYTES = (4 * VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS + VERIFY_ENTRY_WORDS) * 4;
+static_assert(LAYER_PAIR_SCRATCH_BYTES % 128 == 0, "entries are 128-byte lines");
 
 __global__ void __launch_bounds__(64)
 k_debug_layer(int op, int form, uint8_t* out, size_t out_w, const uint8_t* in, size_t in_w, size_t n, const uint32_t* base16,
@@ -135,7 +138,36 @@ k_debug_layer(int op, int form, uint8_t* out, size_t out_w, const uint8_t* in, s
     ge_frombytes(Q, oc, w, false);
     ge_niels pcB;
     niels_load(pcB, base16 + TABLE_ENTRY_WORDS);
-    if (form == 3) {                              // the one-lane throughput form: set-up into the item's own table, the chain stretch by stretch
+    if (form == 4) {                              // two items per lane, as k_verify_exact_lane_chain walks them: this item and the next one of the batch
+      constexpr uint32_t SLOT = VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS;
+      uint32_t* sp = reinterpret_cast<uint32_t*>(scratch + i * LAYER_PAIR_SCRATCH_BYTES);
+      uint32_t* tabs = sp; uint32_t* digs = sp + 2 * SLOT; uint32_t* bentry = sp + 4 * SLOT;
+      exact_bentry_store(bentry);
+      for (int which = 0; which < 2; which++) {
+        const uint8_t* b = in + ((i + (size_t)which) % n) * in_w;
+        uint32_t digits[16], bw[8];
+        sc bs, bt;
+        ldw(bw, b); sc_from_words<8>(bs, bw); sc_to_words(digits + 8, bs);
+        ldw(bw, b + 32); sc_from_words<8>(bt, bw); sc_to_words(digits, bt);
+        words_add_pattern(digits, 0x88888888u);
+        words_add_pattern(digits + 8, 0x80008000u);
+        ldw(bw, b + 64);
+        ge P; bool poc;
+        ge_frombytes(P, poc, bw, false);
+        ge_cached c;
+        ge_to_cached(c, P);
+        cached_store(tabs + which * SLOT, 1, c);
+        verify_exact_setup_table_lane(tabs + which * SLOT, digs + which * SLOT + 64, 1, digits, base16 + TABLE_ENTRY_WORDS);
+      }
+      ge rb;
+      ge_neutral(R); ge_neutral(rb);
+      exact_walk wa = exact_walk_start(digs + 64, 1, true), wb = exact_walk_start(digs + SLOT + 64, 1, true);
+      for (int seg = 0; seg < EXACT_SEGS; seg++) {   // units of work with the accumulators and walks handed on through memory
+        if (seg) { exact_walk_load(R, wa, digs + 128); exact_walk_load(rb, wb, digs + SLOT + 128); }
+        exact_pair_iterations(R, wa, rb, wb, tabs, digs + 64, SLOT, 0, 1, bentry, seg == EXACT_SEGS - 1 ? -1 : EXACT_PAIR_ITERS);
+        exact_walk_store(digs + 128, R, wa); exact_walk_store(digs + SLOT + 128, rb, wb);
+      }
+    } else if (form == 3) {                       // the one-lane throughput form: set-up into the item's own table, the chain stretch by stretch
       uint32_t* sp = reinterpret_cast<uint32_t*>(scratch + i * LAYER_TABLE_SCRATCH_BYTES);
       uint32_t* tab = sp; uint32_t* dig = sp + 4 * VERIFY_ENTRY_WORDS; uint32_t* state = dig + 36; uint32_t* digits = state + EXACT_STATE_WORDS;
       uint32_t* bentry = sp + LAYER_TABLE_SCRATCH_BYTES / 4 - VERIFY_ENTRY_WORDS;
@@ -261,8 +293,8 @@ k_debug_dbl_add_quad(uint8_t* out, const uint8_t* in, size_t n, const uint32_t* 
 using namespace ed;
 
 static int layer_widths_ok(int op, int form, size_t in_w, size_t out_w) {
-  if (form < 0 || form > 3) return 0;
-  if (form == 3 && op != L_ED_DUAL_SCALE) return 0;
+  if (form < 0 || form > 4) return 0;
+  if (form >= 3 && op != L_ED_DUAL_SCALE) return 0;
   switch (op) {
     case L_FE_MUL: return form == 0 && in_w == 64 && out_w == 32;
     case L_FE_SQ: case L_FE_INV: case L_FE_POW2523: case L_SC_REDUCE32: case L_ED_SCALE_BASE: return form == 0 && in_w == 32 && out_w == 32;
@@ -271,7 +303,7 @@ static int layer_widths_ok(int op, int form, size_t in_w, size_t out_w) {
     case L_SC_MULADD: return form == 0 && in_w == 96 && out_w == 32;
     case L_SHA512: return form == 0 && in_w >= 8 && out_w == 64;
     case L_ED_IMPORT_EXPORT: return form == 0 && in_w == 32 && out_w == 33;
-    case L_ED_DUAL_SCALE: return in_w == 96 && out_w == 32;                         // forms 0..3
+    case L_ED_DUAL_SCALE: return in_w == 96 && out_w == 32;                         // forms 0..4
     case L_GE_DBL_ADD: return form <= 1 && in_w == 40 && out_w == 32;
   }
   return 0;
@@ -294,6 +326,7 @@ static hipError_t layer_launch(int op, int form, uint8_t* out, size_t out_w, con
   } else {
     if (op == L_ED_DUAL_SCALE && form == 2 && (e = hipMalloc(&scratch, n * LAYER_SCRATCH_BYTES)) != hipSuccess) return e;
     if (op == L_ED_DUAL_SCALE && form == 3 && (e = hipMalloc(&scratch, n * LAYER_TABLE_SCRATCH_BYTES)) != hipSuccess) return e;
+    if (op == L_ED_DUAL_SCALE && form == 4 && (e = hipMalloc(&scratch, n * LAYER_PAIR_SCRATCH_BYTES)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_debug_layer, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, op, form, out, out_w, in, in_w, n, base16, (uint8_t*)scratch);
   }
   e = hipGetLastError();

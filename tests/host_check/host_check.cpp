@@ -203,6 +203,59 @@ void hc_dual_scale_exact_table(uint8_t out[32], const uint8_t s[32], const uint8
   ge_tobytes(o, R); wr(out, o);
 }
 
+// two of those side by side in one lane, as k_verify_exact_lane_chain walks them (lanes.h: exact_pair_iterations): units of
+// `unit` iterations with the accumulators and walks handed on through memory (unit <= 0: one go), the last one to the end
+static void table_setup(uint32_t* tab, uint32_t* dig, const uint8_t s[32], const uint8_t t[32], const uint8_t q[32]) {
+  uint32_t w[8], digits[16];
+  sc x, y;
+  rd(w, s); sc_from_words<8>(x, w); sc_to_words(digits + 8, x);
+  rd(w, t); sc_from_words<8>(y, w); sc_to_words(digits, y);
+  words_add_pattern(digits, 0x88888888u);
+  words_add_pattern(digits + 8, 0x80008000u);
+  rd(w, q);
+  ge Q; bool oc;
+  ge_frombytes(Q, oc, w, false);
+  ge_cached c;
+  ge_to_cached(c, Q);
+  cached_store(tab, 1, c);
+  verify_exact_setup_table_lane(tab, dig, 1, digits, tables().b16() + TABLE_ENTRY_WORDS);
+}
+int hc_dual_scale_exact_pair(uint8_t out_a[32], uint8_t out_b[32], const uint8_t a96[96], const uint8_t b96[96], int have_b, int unit) {
+  constexpr uint32_t SLOT = VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS;       // two workspace slots each, as the kernel's table / rtable
+  alignas(16) uint32_t tabs[2 * SLOT], digs[2 * SLOT], bentry[VERIFY_ENTRY_WORDS];
+  alignas(16) uint32_t st_a[EXACT_STATE_WORDS + 4], st_b[EXACT_STATE_WORDS + 4];
+  uint32_t *tab_a = tabs, *tab_b = tabs + SLOT, *dig_a = digs, *dig_b = digs + SLOT, o[8];
+  exact_bentry_store(bentry);
+  table_setup(tab_a, dig_a, a96, a96 + 32, a96 + 64);
+  table_setup(tab_b, dig_b, b96, b96 + 32, b96 + 64);
+  ge ra, rb;
+  ge_neutral(ra); ge_neutral(rb);
+  exact_walk wa = exact_walk_start(dig_a, 1, true), wb = exact_walk_start(dig_b, 1, have_b != 0);
+  int units = 0;
+  if (unit <= 0) {
+    exact_pair_iterations(ra, wa, rb, wb, tabs, digs, SLOT, 0, 1, bentry, -1);
+  } else {
+    for (int seg = 0; seg < EXACT_SEGS; seg++, units++) {
+      if (seg) { exact_walk_load(ra, wa, st_a); exact_walk_load(rb, wb, st_b); }
+      exact_pair_iterations(ra, wa, rb, wb, tabs, digs, SLOT, 0, 1, bentry, seg == EXACT_SEGS - 1 ? -1 : unit);
+      exact_walk_store(st_a, ra, wa); exact_walk_store(st_b, rb, wb);
+    }
+  }
+  if (wa.i >= 0 || wb.i >= 0) return -1;
+  // the encodings, through the shared inversion: compare with all-zero R and read the bytes off separately
+  ge_tobytes(o, ra); wr(out_a, o);
+  ge_tobytes(o, rb); wr(out_b, o);
+  uint32_t rwa[8], rwb[8];
+  rd(rwa, out_a); rd(rwb, out_b);
+  bool sa, sb;
+  exact_pair_verdicts(sa, sb, ra, rb, rwa, rwb);
+  if (!sa || (have_b && !sb)) return -2;             // the shared-inversion export must reproduce ge_tobytes' bytes
+  rwa[0] ^= 1u;
+  exact_pair_verdicts(sa, sb, ra, rb, rwa, rwb);
+  if (sa) return -3;
+  return 0;
+}
+
 // ed_dual_scale in the reference's order on an arbitrary 32-byte "point" (cf. orc_ed_dual_scale)
 void hc_dual_scale_exact(uint8_t out[32], const uint8_t s[32], const uint8_t t[32], const uint8_t q[32], int uniform) {
   uint32_t w[8], sw[8], tw[8], o[8];

@@ -164,6 +164,20 @@ def test_exact_chain_for_off_curve_points(hostcheck, oracle, golden):
             assert call(hostcheck, "hc_dual_scale_exact_table", 32, s, t, q, uniform) == want.raw
             off += call(hostcheck, "hc_ed_import_export", 32, q) is not None and hostcheck.hc_ed_import_export(ctypes.create_string_buffer(32), q) == 0
     assert off > 60                                   # plenty of genuinely off-curve inputs were exercised
+    # two items per lane (lanes.h: exact_pair_iterations, what k_verify_exact_lane_chain runs): pairs of the triples above
+    # - equal, different, a lone first item - in one go and in units of 75 / 40 / 1 iterations, both results as the oracle's
+    trip = [(rb(32) if i % 7 else bytes(32), rb(32) if i % 5 else bytes(32), rb(32)) for i in range(40)] + \
+           [(H(s), H(t), H(q)) for s, t, q, _ in k["ed_dual_scale"][:12]]
+    def ref(s, t, q):
+        want = ctypes.create_string_buffer(32)
+        oracle.lib.orc_ed_dual_scale(want, s, t, q)
+        return want.raw
+    for n, (x, y) in enumerate(zip(trip, trip[1:] + trip[:1])):
+        for unit in (0, 75, 40, 1)[: 4 if n < 6 else 2]:
+            oa, ob = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+            have_b = n % 4 != 3
+            assert hostcheck.hc_dual_scale_exact_pair(oa, ob, b"".join(x), b"".join(y), int(have_b), unit) == 0, (n, unit)
+            assert oa.raw == ref(*x) and (not have_b or ob.raw == ref(*y)), (n, unit)
     for c in golden("verify_edges.json"):
         msg = H(c["msg"])
         assert hostcheck.hc_verify_exact(H(c["sig"]), H(c["pub"]), msg, SZ(len(msg))) == int(c["accept"]), c["name"]

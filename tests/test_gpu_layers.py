@@ -126,7 +126,7 @@ def test_group_layer_kats_on_the_device(probe, golden, oracle):
     assert probe.debug_layer("ed_scale_base", xs, 32) == want
 
 
-def test_dual_scale_in_the_references_order_on_the_device_all_four_forms(probe, golden, oracle):
+def test_dual_scale_in_the_references_order_on_the_device_all_five_forms(probe, golden, oracle):
     """ed_dual_scale (lib/ed.c:455-507) replayed formula by formula: the literal chain, the uniform one, and the four-lane
     chain of the exact path (set-up and chain, DPP exchanges) - on curve points and on 'points' that are not on the curve,
     where the bytes depend on the exact sequence of formulas"""
@@ -146,7 +146,7 @@ def test_dual_scale_in_the_references_order_on_the_device_all_four_forms(probe, 
     flags = probe.debug_layer("ed_import_export", [x[64:] for x in extra], 33)
     off = sum(1 for f in flags if f[32] == 0)
     assert off > 50                                               # plenty of off-curve inputs among them
-    for form in (0, 2, 1, 3):                                     # 3: the one-lane throughput form (k_verify_exact_lane_*: table entries, stretches)
+    for form in (0, 2, 1, 3, 4):                                  # 3: one lane per item over table entries, in stretches; 4: two items per lane (k_verify_exact_lane_chain)
         got = probe.debug_layer("ed_dual_scale", items + extra, 32, form=form)
         bad = [i for i, (g, w) in enumerate(zip(got, want + extra_want)) if g.hex() != w]
         assert not bad, (form, bad[:10])
