@@ -40,13 +40,17 @@ EDDSA_AMD_DECL int eddsa_amd_debug_hip_calls(void);
 
 /* ---- route selection (a measurement and test aid; the verdicts are the same on every route) ----
  * 0 (default): every pass checks u*(S*B - t*A - R) = 0 with half-length u, v = u*t mod 8l (132 doublings instead of
- * 252; csrc/halve.h) - passes of up to 24 576 items with four lanes per item, larger ones with one (passes of
- * 257 .. 2^18 - 1 items with u, v < 2^138 and 35 windows, and passes below 2^18 items with a three-lane preparation);
+ * 252; csrc/halve.h) - passes of up to 24 576 items with four lanes per item, larger ones with one; passes of 257 ..
+ * 2^19 - 1 items search u, v < 2^138 and run 35 windows, larger ones 2^134 and 34; passes of 24 577 .. 2^18 - 1 items
+ * prepare with three lanes per item (the constants: csrc/kernels.hip PAIR_ONE_MIN_N, PAIR_ONE_MAX_N, HALF_WIDE_MIN_N);
  * 1: the full-length evaluation of S*B - t*A (four lanes per item up to 2^14 items); 2: the half-length one with one
- * lane per item whatever the size; 3: the arrangement of 24 577 .. 2^18 items at any size below 2^18. */
+ * lane per item whatever the size; 3: the arrangement of 24 577 .. 2^18 - 1 items at any size below 2^18. */
 EDDSA_AMD_DECL void eddsa_amd_set_verify_algo(int algo);
-/* items of the first chunk of a host-pointer call and of its later stages; 0 = the defaults (2^16 for verify, 2^17
- * otherwise, then doubling - for verify up to 2^18 with the rest of the call as the last chunk, for the other operations up to 2^18) */
+/* items of the first chunk of a host-pointer call and the cap of its later chunks; 0 = the defaults: the first chunk 2^16
+ * (verify) or 2^17 items, every later one twice its predecessor up to 2^20 (verify: CHUNK_MAX, one workspace pass) or 2^18 (the
+ * other operations), a tail shorter than half a chunk travelling with the last one - so a verify call of 2^20 items is
+ * 2^16 + 2^17 + 2^18 + the rest in one, and one of 2^22 adds chunks of 2^19 and 2^20 (a last chunk of up to 1.5 x 2^20 is two
+ * passes on one workspace) */
 EDDSA_AMD_DECL void eddsa_amd_set_pipeline(size_t first_chunk, size_t stage_chunk);
 /* how the kernels of consecutive chunks of a host-pointer call are ordered.  -1 (default): each operation's own
  * setting; 0: side by side; 1: in chunk order; 2: in chunk order, a verify chunk starting beside the previous chunk's

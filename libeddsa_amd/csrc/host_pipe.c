@@ -634,6 +634,7 @@ out:
 #define COMBINE_MAX_BYTES ((size_t)1 << 20)  /* ... and its message bytes */
 #define COMBINE_MAX_BATCH 16384              /* items per combined launch */
 #define COMBINE_MAX_BATCH_BYTES ((size_t)64 << 20)   /* ... and its message bytes (pinned staging of the packed batch) */
+#define COMBINE_RETRY_GIVE_UP 4               /* request-by-request retries of a failed launch that may fail alike in a row before the rest are given the launch's error */
 #define COMBINE_GATHER_NS 80000              /* how long a leader elected under contention waits for the callers of the previous batch */
 
 struct creq { const struct hjob *j; size_t n; int rc, done; struct creq *next; };
@@ -818,10 +819,16 @@ static int combiner_submit(struct engine *e, const struct hjob *j, size_t n)
             /* A merged launch shares one status, and the eddsa.h callers abort() on failure: before anybody is told, every
              * request gets a run of its own (a transient error, or the packed batch's staging allocation, need not concern
              * the others; a request that is itself the cause fails again, alone) */
+            /* ... but not without end: a batch holds up to 16 384 requests, and when the cause is the device (lost, out of
+             * memory) every retry stages secrets, fails, waits and wipes while all callers stay blocked.  After
+             * COMBINE_RETRY_GIVE_UP retries in a row that end with the batch's own error the rest are told that error. */
+            int same = 0;
             for (struct creq *r = batch; r; r = r->next) {
+                if (same >= COMBINE_RETRY_GIVE_UP) { r->rc = rc; continue; }
                 struct hjob alone = *r->j;
                 alone.traced = 1;
                 r->rc = pipe_run_on(e, &alone, r->n);
+                same = r->rc == rc ? same + 1 : 0;
             }
         }
         pthread_mutex_lock(&q->lk);

@@ -7,7 +7,8 @@
 //   k_x25519_*       x25519.c:129-150 do_x25519                      (config 3)
 //   k_verify_*       ed25519-sha512.c:148-181 ed25519_verify        (config 2, 4): prepare / halve / main_half by
 //                    default (half-length scalars, halve.h), prepare / main / finish for the full-length route,
-//                    *_pair / *_quad forms for small passes, k_verify_exact_quad for keys that are not curve points
+//                    *_pair / *_quad forms for small passes; for keys that are not curve points k_verify_exact_quad (short
+//                    work lists, four lanes per item) and k_verify_exact_lane_setup / _chain (long ones, two items per lane)
 //   k_sign_*         ed25519-sha512.c:84-123 sign                    (config 5)
 //   k_genpub_point + k_encode_finish          ed25519-sha512.c:53-67 genpub
 //   k_x25519_base_*  x25519.c:158-197 do_x25519_base
@@ -170,12 +171,12 @@ k_verify_prepare(edk_verify_src src, size_t n, uint32_t* digits,
 // disturb every SIMD a little instead of a few a lot: single-wave chain blocks (16 items) spread over the
 // whole chip, the short four-lane chain, no displacement.  Cost of the exact path on config 2: 0.94 ms in
 // round 1, 0.4 ms in round 2, 0.05 ms now (profiles/r04_small_grid.txt has what it costs passes of one or two rounds).
-// The work list may be as long as the pass (a caller can send nothing but garbage keys: ed_import never fails, ed.c:100-149):
-// a launch takes EDK_EXACT_SLOTS entries - 4096 waves of 16 items, one scratchpad slot each - and edk_verify queues one
-// launch per stretch of that length the pass could fill, one after the other on the side stream; those that find their
-// stretch empty end at once.  (Until round 4 the entries beyond 65536 went to a one-lane kernel that spilled 518
-// registers; a loop over the stretches inside this kernel spilled 40-90 of its 128: the compiler keeps the chain's loop
-// invariants live across the next round's set-up.)
+// The work list may be as long as the pass (a caller can send nothing but garbage keys: ed_import never fails, ed.c:100-149).
+// This kernel serves SHORT lists - below EXACT_LANE_MIN_LISTED entries in passes of EXACT_LANE_MIN_N items or more, every list of
+// a smaller pass (at most its 65 535 items: EDK_EXACT_SLOTS scratchpad slots, 4096 waves of 16) - and ends at once when the list
+// is longer: that one belongs to k_verify_exact_lane_* below, one lane per item at the occupancy of a kernel that fills the
+// chip.  (Rounds 1-4 walked long lists with this kernel in stretches of 65 536: 34 M items/s, and a pass of 2^20 random keys
+// 26 ms; now 14: profiles/r05_exact_lane.txt.)
 constexpr int QUAD_BLOCK = 256;                  // k_verify_main_quad
 constexpr int QUAD_CHAIN_BLOCK = 64;             // k_verify_exact_quad: one wave, up to 16 items
 constexpr int QUAD_CHAIN_ITEMS = QUAD_CHAIN_BLOCK / 4;
@@ -204,16 +205,14 @@ static_assert(EDK_EXACT_SLOTS % QUAD_CHAIN_ITEMS == 0, "whole waves");
 // live in LDS (33 words per item), the addends in the HBM scratchpad, one slot per quad of the grid.
 __global__ void __launch_bounds__(QUAD_CHAIN_BLOCK, 2)
 k_verify_exact_quad(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const uint32_t* digits, const uint32_t* table,
-                    const uint32_t* offlist, const uint32_t* offcount, const uint32_t* base16, uint32_t* pad, size_t first, int dense,
+                    const uint32_t* offlist, const uint32_t* offcount, const uint32_t* base16, uint32_t* pad, int dense,
                     uint32_t lane_min) {
   __shared__ uint32_t lds_dig[QUAD_CHAIN_ITEMS * QUAD_DIGIT_WORDS];
   __builtin_amdgcn_s_setprio(3);                 // small passes wait for the chain: 1-3 % there; no difference beside a full k_verify_main
-  // this launch's stretch of the work list: entries first .. first + EDK_EXACT_SLOTS - 1 (edk_verify launches one kernel per
-  // stretch the pass could fill; all but the first find nothing to do unless the caller sent thousands of garbage keys)
   const size_t listed = *offcount;
-  if (listed <= first) return;
+  if (listed == 0) return;
   if (lane_min != 0 && listed >= lane_min) return;   // a list this long belongs to the one-lane kernels (k_verify_exact_lane_*)
-  const size_t count = listed - first < (size_t)EDK_EXACT_SLOTS ? listed - first : (size_t)EDK_EXACT_SLOTS;
+  const size_t count = listed < (size_t)EDK_EXACT_SLOTS ? listed : (size_t)EDK_EXACT_SLOTS;   // (never more: see the launcher's static_assert)
   // items per wave: 16 in a pass whose main kernel outlasts the chain anyway (dense: the chain's total work is what counts
   // there - every wave issues the chain's 300 k instructions however few items it carries, and in the host pipeline, where
   // the chunks' kernels fill one another's gaps, 557 items spread three to the wave cost a 2^16-item chunk a quarter of its
@@ -225,7 +224,7 @@ k_verify_exact_quad(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const u
   const size_t g = (size_t)blockIdx.x * per + quad;
   if (quad >= per || g >= count) return;
   const int q = (int)(threadIdx.x & 3u);
-  const size_t i = offlist[first + g];
+  const size_t i = offlist[g];
   uint32_t* item = pad + g * QUAD_ITEM_WORDS;
   uint32_t* dig = lds_dig + quad * QUAD_DIGIT_WORDS;
   verify_exact_setup_quad(digits + 16 * i, table + i * (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS), base16 + TABLE_ENTRY_WORDS, item, dig, q);
@@ -236,13 +235,14 @@ k_verify_exact_quad(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const u
   if (q == 1) ok[i] = (uint8_t)same;
 }
 
-// The exact path for LONG work lists: one lane per item (lanes.h: verify_exact_setup_table_lane,
-// verify_exact_chain_table_lane), two kernels of persistent blocks behind the four-lane launches on the side stream.  Which
-// form serves a pass is decided on the device, by the length of the list: below `min_listed` entries these kernels end at
-// once and k_verify_exact_quad does the work (its single-wave blocks answer soonest and disturb a full main kernel least);
-// from there on it is the other way round - a wave of the four-lane chain carries 16 items through 300 k instructions, a
-// wave of this one 64 through 620 k, and a caller who sends nothing but garbage keys (47 % of random strings are no curve
-// point) is served at the rate of a kernel that fills the chip: profiles/r05_exact_lane.txt.
+// The exact path for LONG work lists: lanes.h: verify_exact_setup_table_lane, one lane per item, then exact_pair_iterations,
+// TWO items per lane sharing one addition phase - two kernels of persistent blocks on the side stream, ahead of the four-lane
+// launch.  Which form serves a pass is decided on the device, by the length of the list: below `min_listed` entries these
+// kernels end at once and k_verify_exact_quad does the work (its single-wave blocks answer soonest and disturb a full main
+// kernel least); from there on it is the other way round - a wave of the four-lane chain carries 16 items through 300 k
+// instructions (1.2 M lane slots per item), a wave of this one 128 through 1.2 M (594 k per item), and a caller who sends
+// nothing but garbage keys (47 % of random strings are no curve point) is served at the rate of a kernel that fills the chip:
+// profiles/r05_exact_lane.txt.
 // The set-up writes into the item's OWN workspace - Q + B and Q - B over entries 2 and 3 of its table, the digit string
 // over the first words of its rtable slot - which nobody reads for such an item: the windowed kernels skip it (on the
 // half-length route they do not even visit it, see k_verify_prepare) or discard what they compute from it.
@@ -1139,13 +1139,15 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
       EDK_LAUNCH(k_verify_exact_lane_chain, dim3(lane_blocks), dim3(BLOCK), 0, ws->side, ok, src.sigs, src.sig_stride, ws->table, ws->rtable,
                  ws->offlist, ws->offcount, ws->exact_pad, lane_min);
     }
-    for (size_t first = 0; first < n; first += (size_t)EDK_EXACT_SLOTS) {
-      const size_t qi = n - first < (size_t)EDK_EXACT_SLOTS ? n - first : (size_t)EDK_EXACT_SLOTS;
+    {
+      // one launch: a list it would serve has fewer entries than the scratchpad has slots (lane_min != 0: fewer than lane_min;
+      // else the pass itself is smaller than EXACT_LANE_MIN_N)
+      static_assert(EXACT_LANE_MIN_LISTED <= (size_t)EDK_EXACT_SLOTS && EXACT_LANE_MIN_N <= (size_t)EDK_EXACT_SLOTS, "the four-lane chain's list fits its scratchpad");
+      const size_t qi = lane_min != 0 ? (size_t)lane_min : n;
       const size_t dense = (qi + QUAD_CHAIN_ITEMS - 1) / QUAD_CHAIN_ITEMS, spread = qi < (size_t)QUAD_SPREAD_WAVES ? qi : (size_t)QUAD_SPREAD_WAVES;
       EDK_LAUNCH(k_verify_exact_quad, dim3((unsigned)(dense > spread ? dense : spread)), dim3(QUAD_CHAIN_BLOCK), 0, ws->side, ok,
-                 src.sigs, src.sig_stride, ws->digits, ws->table, ws->offlist, ws->offcount, base16, ws->exact_pad, first,
+                 src.sigs, src.sig_stride, ws->digits, ws->table, ws->offlist, ws->offcount, base16, ws->exact_pad,
                  (int)(n >= EXACT_DENSE_MIN_N), lane_min);
-      if (lane_min != 0 && first + (size_t)EDK_EXACT_SLOTS >= (size_t)lane_min) break;   // a list that reaches the next stretch is the one-lane kernels'
     }
     EDK_DO(hipEventRecord(ws->ev_exact, ws->side));
   }
