@@ -26,3 +26,5 @@ timed("mode 2 (every item through the exact path)", pk)
 ed.set_offcurve_mode(True)
 timed("valid", pk)
 timed("random keys", garbage)
+half = pk.clone(); half[::2] = garbage[::2]
+timed("every second key random", half)
