@@ -90,12 +90,14 @@ static void ws_release(struct vslot *v)
     if (v->ws.rtable) HIP_NOTE(hipFree(v->ws.rtable));
     if (v->ws.offlist) HIP_NOTE(hipFree(v->ws.offlist));
     if (v->ws.onlist) HIP_NOTE(hipFree(v->ws.onlist));
+    if (v->ws.perm) HIP_NOTE(hipFree(v->ws.perm));
+    if (v->ws.lenbins) HIP_NOTE(hipFree(v->ws.lenbins));
     if (v->ws.offcount) HIP_NOTE(hipFree(v->ws.offcount));
     if (v->ws.exact_pad) HIP_NOTE(hipFree(v->ws.exact_pad));
     if (v->ws.sums) HIP_NOTE(hipFree(v->ws.sums));
     v->ws.capacity = 0;
     v->ws.digits = v->ws.table = v->ws.acc = v->ws.offlist = v->ws.offcount = v->ws.exact_pad = NULL;
-    v->ws.hdigits = v->ws.rtable = v->ws.sums = v->ws.onlist = NULL;
+    v->ws.hdigits = v->ws.rtable = v->ws.sums = v->ws.onlist = v->ws.perm = v->ws.lenbins = NULL;
     v->ws.flags = NULL;
 }
 
@@ -104,6 +106,8 @@ static void fws_release(struct vslot *v)
     wipe_free(v->fws.acc, v->fws.capacity * ACC_WORDS * sizeof(uint32_t));
     wipe_free(v->fws.aux, v->fws.capacity * 16 * sizeof(uint32_t));
     if (v->fws.tiles) HIP_NOTE(hipFree(v->fws.tiles));
+    if (v->fws.perm) HIP_NOTE(hipFree(v->fws.perm));
+    if (v->fws.lenbins) HIP_NOTE(hipFree(v->fws.lenbins));
     memset(&v->fws, 0, sizeof(v->fws));
 }
 
@@ -134,6 +138,8 @@ static int fws_reserve(struct vslot *v, size_t items, hipStream_t st)
      * with the kernels of a non-blocking stream and could land after their first stores */
     TRY(hipMemsetAsync(v->fws.acc, 0, cap * ACC_WORDS * sizeof(uint32_t), st));
     TRY(hipMemsetAsync(v->fws.aux, 0, cap * 16 * sizeof(uint32_t), st));
+    TRY(hipMalloc((void **)&v->fws.perm, cap * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&v->fws.lenbins, 2 * EDK_LEN_BINS * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&v->fws.tiles, 256));
     TRY(hipMemsetAsync(v->fws.tiles, 0, 256, st));
     v->fws.capacity = cap;
@@ -159,6 +165,8 @@ static int ws_reserve(struct vslot *v, size_t items)
     TRY(hipMalloc((void **)&v->ws.flags, cap));
     TRY(hipMalloc((void **)&v->ws.offlist, cap * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&v->ws.onlist, cap * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&v->ws.perm, cap * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&v->ws.lenbins, 2 * EDK_LEN_BINS * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&v->ws.offcount, 256));
     TRY(hipMemset(v->ws.offcount, 0, 256));
     TRY(hipStreamSynchronize(NULL));      /* the pass's stream does not wait for the null stream */

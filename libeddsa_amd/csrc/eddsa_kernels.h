@@ -22,6 +22,7 @@
 #define VERIFY_TABLE_WORDS_PER_TILE (VERIFY_TABLE_ENTRIES * VERIFY_ENTRY_WORDS * 256)
 #define VERIFY_TILE 256            /* items per tile = threads per block */
 #define EDK_HALF_DIGIT_WORDS 28     /* = HALF_DIGIT_WORDS of lanes.h */
+#define EDK_LEN_BINS 2048           /* bins of the per-pass counting sort of ragged messages by length (kernels.hip: k_len_*) */
 #define EDK_REFUSED_WORD 8
 #define EDK_ONLIST_WORD 1           /* word of edk_verify_ws.offcount: the length of onlist */
 #define EDK_EXACT_UNIT_WORD 2        /* word of edk_verify_ws.offcount: the next unit of work of k_verify_exact_lane_chain */
@@ -51,6 +52,8 @@ typedef struct edk_verify_ws {
   uint32_t* offlist;  /* capacity words: the exact path's work list (keys off the curve; large passes: items without a short pair) */
   uint32_t* onlist;   /* capacity words: the items the windowed evaluation decides (every other item); the half-length route's
                          k_verify_halve / k_verify_main_half run over this list */
+  uint32_t* perm;     /* capacity words: ragged passes: the items in order of message length (kernels.hip: msg_order) */
+  uint32_t* lenbins;  /* 2 * EDK_LEN_BINS words: that sort's counts and cursors */
   uint32_t* offcount; /* 64 words, zeroed at allocation: [0] the length of offlist, [EDK_ONLIST_WORD] the length of onlist, [EDK_EXACT_UNIT_WORD]
                          (all three zeroed by every pass), [EDK_REFUSED_WORD] half-length pairs that the exact check of lanes.h: verify_half_scalars_lane
                          refused since allocation (diagnostic), [EDK_BENTRY_WORD..] the shared entry of the one-lane exact path */
@@ -85,6 +88,8 @@ typedef struct edk_fixed_ws {
   size_t capacity;
   uint32_t* acc;      /* capacity * ACC_WORDS words: projective result, lane-interleaved per tile */
   uint32_t* aux;      /* capacity * 16 words: sign's secret scalars a, r between its two kernels (zeroed after use) */
+  uint32_t* perm;     /* capacity words, and */
+  uint32_t* lenbins;  /* 2 * EDK_LEN_BINS words: sign's ragged messages in order of length, as in edk_verify_ws */
   uint32_t* tiles;    /* 64 words; [0] the next 64-item tile a wave of a persistent point kernel takes (zeroed by the launcher before
                          every such launch): kernels.hip, point_tile */
 } edk_fixed_ws;

@@ -109,6 +109,62 @@ __global__ void __launch_bounds__(64) k_init_comb_image(uint32_t* img, const uin
 }
 
 // ---------------------------------------------------------------------------------------------
+// Ragged messages in order of length.  A lane hashes its message block by block and a wave ends with its longest message:
+// with lengths drawn from 0 .. 4 KiB a pass of 2^20 items spent a third of its hashing beside finished lanes (verify 15.7 ->
+// 12.4 ms, sign 13.3 -> 8.6 ms when the SAME items are handed over sorted: profiles/r05_msglen.txt).  So the kernels that hash
+// take their items through a permutation - position g of the grid works on item perm[g] - built per pass by a counting sort on
+// the number of 128-byte blocks, longest first (three small kernels, ~20 us); everything an item leaves in the workspace stays
+// indexed by the item, so no other kernel knows.  Passes of at least MSG_ORDER_MIN_N items with an offset table only.
+// ---------------------------------------------------------------------------------------------
+constexpr int LEN_BINS = EDK_LEN_BINS;           // key = min(length / 128, LEN_BINS - 1), counted from the long end
+constexpr size_t MSG_ORDER_MIN_N = (size_t)1 << 12;
+
+ED_DEV uint32_t len_bin(const uint64_t* off, const uint64_t* end, size_t item) {
+  const uint8_t* m; size_t mlen;
+  msg_span(m, mlen, nullptr, off, end, 0, 0, item);            // (the clamped span: what the hashing kernels will read)
+  const size_t blocks = mlen >> 7;
+  return (uint32_t)(LEN_BINS - 1) - (uint32_t)(blocks < (size_t)LEN_BINS - 1 ? blocks : (size_t)LEN_BINS - 1);
+}
+
+// bins[b] += items of bin b (per block in LDS first: a pass whose messages all have one length would otherwise send 2^20 atomics to one word)
+__global__ void __launch_bounds__(BLOCK) k_len_count(uint32_t* bins, const uint64_t* off, const uint64_t* end, size_t n) {
+  __shared__ uint32_t h[LEN_BINS];
+  for (int b = threadIdx.x; b < LEN_BINS; b += BLOCK) h[b] = 0;
+  __syncthreads();
+  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < n) atomicAdd(&h[len_bin(off, end, i)], 1u);
+  __syncthreads();
+  for (int b = threadIdx.x; b < LEN_BINS; b += BLOCK) if (h[b]) atomicAdd(bins + b, h[b]);
+}
+// bins[LEN_BINS + b] = items in the bins before b (one block)
+__global__ void __launch_bounds__(BLOCK) k_len_starts(uint32_t* bins) {
+  __shared__ uint32_t part[BLOCK];
+  constexpr int PER = LEN_BINS / BLOCK;
+  uint32_t local[PER], sum = 0;
+#pragma unroll
+  for (int k = 0; k < PER; k++) { local[k] = sum; sum += bins[threadIdx.x * PER + k]; }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  uint32_t before = 0;
+  for (int t = 0; t < (int)threadIdx.x; t++) before += part[t];
+#pragma unroll
+  for (int k = 0; k < PER; k++) bins[LEN_BINS + threadIdx.x * PER + k] = before + local[k];
+}
+// perm[start of the item's bin ...] = item: a block reserves its share of every bin with one atomic per bin
+__global__ void __launch_bounds__(BLOCK) k_len_place(uint32_t* perm, uint32_t* bins, const uint64_t* off, const uint64_t* end, size_t n) {
+  __shared__ uint32_t h[LEN_BINS], base[LEN_BINS];
+  for (int b = threadIdx.x; b < LEN_BINS; b += BLOCK) h[b] = 0;
+  __syncthreads();
+  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  uint32_t bin = 0, rank = 0;
+  if (i < n) { bin = len_bin(off, end, i); rank = atomicAdd(&h[bin], 1u); }
+  __syncthreads();
+  for (int b = threadIdx.x; b < LEN_BINS; b += BLOCK) if (h[b]) base[b] = atomicAdd(bins + LEN_BINS + b, h[b]);
+  __syncthreads();
+  if (i < n) perm[base[bin] + rank] = (uint32_t)i;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Ed25519 verify, the full-length route (passes of up to QUAD_MAIN_MAX_N items, eddsa_amd_set_verify_algo(1), the
 // reject mode; larger passes take the half-length route further down, which shares k_verify_prepare and the exact
 // path).  Three kernels per chunk, so that each stays inside its register budget and its own I-cache footprint
@@ -129,9 +185,11 @@ __global__ void __launch_bounds__(64) k_init_comb_image(uint32_t* img, const uin
 
 __global__ void __launch_bounds__(BLOCK, 2)
 k_verify_prepare(edk_verify_src src, size_t n, uint32_t* digits,
-                 uint32_t* table, uint8_t* flags, uint32_t* onlist, uint32_t* offlist, uint32_t* offcount, int all_exact) {
-  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  const size_t item = i < n ? i : n - 1;         // idle lanes redo the last item into their own slot
+                 uint32_t* table, uint8_t* flags, uint32_t* onlist, uint32_t* offlist, uint32_t* offcount, int all_exact, const uint32_t* perm) {
+  const size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  // position g of the grid works on item perm[g] (ragged messages in order of length, above) or on item g
+  const size_t item = perm ? perm[g < n ? g : n - 1] : (g < n ? g : n - 1);
+  const size_t i = g < n ? item : g;             // its slot of the workspace: the item's own; idle lanes redo the last item into a slot past the pass
   uint32_t rw[8], aw[8], sw[8], tw[8];
   const uint8_t* m; size_t mlen;
   load32(rw, src.sigs, item, src.sig_stride);
@@ -151,7 +209,7 @@ k_verify_prepare(edk_verify_src src, size_t n, uint32_t* digits,
   // Two work lists: the items the windowed evaluation decides (the half-length route's k_verify_halve and
   // k_verify_main_half run over THIS list, not over the pass: a caller who sends nothing but garbage keys then pays for
   // the exact path only, not for a windowed evaluation whose result is discarded on top), and the exact path's.
-  const bool live = i < n;
+  const bool live = g < n;
   const uint32_t on_slot = wave_append(offcount + EDK_ONLIST_WORD, live && windowed);
   if (live && windowed) onlist[on_slot] = (uint32_t)i;
   const uint32_t off_slot = wave_append(offcount, live && !windowed);
@@ -751,7 +809,8 @@ k_encode_finish(uint8_t* out, uint32_t* acc, size_t n, int K) {
 template <int PARTS>
 __global__ void __launch_bounds__(POINT_BLOCK, 512 / POINT_BLOCK)
 k_sign_point(uint32_t* accout, uint32_t* aux, const uint8_t* secs, const uint8_t* msgs,
-             const uint64_t* msg_off, const uint64_t* msg_end, size_t msg_len, size_t n, const uint32_t* comb, uint32_t* tiles) {
+             const uint64_t* msg_off, const uint64_t* msg_end, size_t msg_len, size_t n, const uint32_t* comb, const uint32_t* perm,
+             uint32_t* tiles) {
   __shared__ alignas(16) uint32_t lds_comb[COMB_IMG_WORDS];
   stage_table(lds_comb, comb, COMB_IMG_WORDS);
   __shared__ uint32_t lds_shares[PARTS == 1 ? 1 : 2 * 40 * 64];
@@ -760,7 +819,9 @@ k_sign_point(uint32_t* accout, uint32_t* aux, const uint8_t* secs, const uint8_t
   size_t i;
 #pragma unroll 1
   for (unsigned it = 0; point_tile<PARTS>(i, it, n, tiles); it++) {
-    const size_t item = i < n ? i : n - 1;
+    // position i works on item perm[i] (ragged messages in order of length); the point and the secret scalars stay at the
+    // POSITION's slots of the workspace, where k_sign_finish finds them
+    const size_t item = perm ? perm[i < n ? i : n - 1] : (i < n ? i : n - 1);
     const uint8_t* m; size_t mlen;
     msg_span(m, mlen, msgs, msg_off, msg_end, msg_len, msg_len, item);
     uint32_t sk[8], aw[8], rw[8];
@@ -783,7 +844,7 @@ k_sign_point(uint32_t* accout, uint32_t* aux, const uint8_t* secs, const uint8_t
 
 struct sign_finish_policy {
   uint8_t* sigs; uint32_t* acc; uint32_t* aux; const uint8_t* pubs; const uint8_t* msgs;
-  const uint64_t* msg_off; const uint64_t* msg_end; size_t msg_len; size_t n; int K;
+  const uint64_t* msg_off; const uint64_t* msg_end; size_t msg_len; size_t n; int K; const uint32_t* perm;
   ED_DEV void den(int k, fe& z) const {
     const finish_pos p = finish_at(k, acc, K);
     fe_set(z, 1);
@@ -793,13 +854,14 @@ struct sign_finish_policy {
   ED_DEV void item(int k) const {
     const finish_pos p = finish_at(k, acc, K);
     if (p.i >= n) return;
+    const size_t it = perm ? perm[p.i] : p.i;      // the item this position carries (k_sign_point)
     fe x, y, zinv;
     acc_load(x, p.acc, 0); acc_load(y, p.acc, 1); acc_load(zinv, p.acc, 2);
     uint32_t Rw[8], Sw[8], pub[8];
     encode_lane(Rw, x, y, zinv);
-    load32(pub, pubs, p.i, 32);
+    load32(pub, pubs, it, 32);
     const uint8_t* m; size_t mlen;
-    msg_span(m, mlen, msgs, msg_off, msg_end, msg_len, msg_len, p.i);
+    msg_span(m, mlen, msgs, msg_off, msg_end, msg_len, msg_len, it);
     sc t;
     sign_challenge_lane(t, Rw, pub, m, mlen);              // the secret scalars are fetched only after the hash
     uint32_t aw[8], rw[8];
@@ -810,15 +872,15 @@ struct sign_finish_policy {
     const uint4 zero = make_uint4(0, 0, 0, 0);           // the secrets do not outlive the call in HBM
     d[0] = zero; d[1] = zero; d[2] = zero; d[3] = zero;
     sign_response_lane(Sw, t, aw, rw);
-    store32(sigs, p.i, 64, Rw);
-    store32(sigs + 32, p.i, 64, Sw);
+    store32(sigs, it, 64, Rw);
+    store32(sigs + 32, it, 64, Sw);
   }
 };
 
 __global__ void __launch_bounds__(BLOCK, 2)
 k_sign_finish(uint8_t* sigs, uint32_t* acc, uint32_t* aux, const uint8_t* pubs, const uint8_t* msgs,
-              const uint64_t* msg_off, const uint64_t* msg_end, size_t msg_len, size_t n, int K) {
-  finish_batch8(sign_finish_policy{sigs, acc, aux, pubs, msgs, msg_off, msg_end, msg_len, n, K}, acc);
+              const uint64_t* msg_off, const uint64_t* msg_end, size_t msg_len, size_t n, int K, const uint32_t* perm) {
+  finish_batch8(sign_finish_policy{sigs, acc, aux, pubs, msgs, msg_off, msg_end, msg_len, n, K, perm}, acc);
 }
 
 template <int PARTS>
@@ -915,12 +977,14 @@ k_sk_to_x(uint8_t* out, const uint8_t* in, size_t n) {
 template <int BITS>
 __global__ void __launch_bounds__(BLOCK, 2)
 k_verify_prepare_pair(edk_verify_src src, size_t n, uint32_t* digits, uint32_t* hdigits, uint32_t* table, uint32_t* rtable,
-                      uint8_t* flags, uint32_t* onlist, uint32_t* offlist, uint32_t* offcount, int all_exact, unsigned point_blocks) {
+                      uint8_t* flags, uint32_t* onlist, uint32_t* offlist, uint32_t* offcount, int all_exact, unsigned point_blocks,
+                      const uint32_t* perm) {
   if (blockIdx.x >= point_blocks) {
     // the scalars' blocks, one lane per item: hash, reduce, search the pair.  They need nothing from the points' blocks
     // and those nothing from here: the two square-root chains of an item run BESIDE its hash and its search
-    const size_t i = (size_t)(blockIdx.x - point_blocks) * BLOCK + threadIdx.x;
-    if (i >= n) return;
+    const size_t g = (size_t)(blockIdx.x - point_blocks) * BLOCK + threadIdx.x;
+    if (g >= n) return;
+    const size_t i = perm ? perm[g] : g;         // (ragged messages in order of length)
     uint32_t rw[8], aw[8], sw[8], tw[8], hd[HALF_DIGIT_WORDS];
     const uint8_t* m; size_t mlen;
     verify_item(rw, sw, aw, m, mlen, src, i);
@@ -1070,6 +1134,18 @@ int edk_debug_fail_in(int nth) {
   return 0;
 }
 
+// perm[0..n) = the items in order of message length, longest first (k_len_*): bins = 2 * LEN_BINS words of the workspace
+static hipError_t msg_order(uint32_t* perm, uint32_t* bins, const uint64_t* msg_off, const uint64_t* msg_end, size_t n, hipStream_t stream) {
+  const unsigned blocks = (unsigned)((n + BLOCK - 1) / BLOCK);
+  hipError_t e = hipMemsetAsync(bins, 0, (size_t)LEN_BINS * sizeof(uint32_t), stream);
+  if (e != hipSuccess) return e;
+  static_assert(LEN_BINS % BLOCK == 0, "k_len_starts: a thread takes LEN_BINS / BLOCK bins");
+  hipLaunchKernelGGL(k_len_count, dim3(blocks), dim3(BLOCK), 0, stream, bins, msg_off, msg_end, n);
+  hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(BLOCK), 0, stream, bins);
+  hipLaunchKernelGGL(k_len_place, dim3(blocks), dim3(BLOCK), 0, stream, perm, bins, msg_off, msg_end, n);
+  return hipGetLastError();
+}
+
 // Every HIP call below that orders work or moves data is checked (edk_checked.h): the first failure ends the pass with
 // that error.  What has been queued by then still runs; eddsa_amd.c: verify_on waits for it (both streams) before the
 // workspace can be handed out again, and the caller learns that the outputs are unspecified.
@@ -1097,17 +1173,23 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   // with pairs up to 2^134 (8.5 items in 10^5) a pass of 2048 items has such an item one time in six, one of 2^14 three
   // times in four.  Above QUAD_WIDE_MIN_N items the search goes up to 2^138 (2 in 10^7) for a 35th window in every item.
   const bool quad_wide = half_quad && n > QUAD_WIDE_MIN_N;
+  // ragged messages: the hashing kernels take their items in order of length
+  const uint32_t* perm = nullptr;
+  if (src.msg_off && n >= MSG_ORDER_MIN_N) {
+    EDK_DO(msg_order(ws->perm, ws->lenbins, src.msg_off, src.msg_end, n, stream));
+    perm = ws->perm;
+  }
   if (pair_one || quad_wide)
     EDK_LAUNCH(k_verify_prepare_pair<HALF_BITS_SMALL>, dim3(pair_point_blocks + blocks), dim3(BLOCK), 0, stream, src, n,
                ws->digits, ws->hdigits, ws->table, ws->rtable, ws->flags, ws->onlist, ws->offlist, ws->offcount, ws->exact_offcurve == 2,
-               pair_point_blocks);
+               pair_point_blocks, perm);
   else if (half_quad)
     EDK_LAUNCH(k_verify_prepare_pair<HALF_BITS>, dim3(pair_point_blocks + blocks), dim3(BLOCK), 0, stream, src, n,
                ws->digits, ws->hdigits, ws->table, ws->rtable, ws->flags, ws->onlist, ws->offlist, ws->offcount, ws->exact_offcurve == 2,
-               pair_point_blocks);
+               pair_point_blocks, perm);
   else
     EDK_LAUNCH(k_verify_prepare, dim3(blocks), dim3(BLOCK), 0, stream, src, n, ws->digits, ws->table, ws->flags, ws->onlist, ws->offlist,
-               ws->offcount, ws->exact_offcurve == 2);
+               ws->offcount, ws->exact_offcurve == 2, perm);
   // Below HALF_WIDE_MIN_N items the pass searches pairs up to 2^138 and runs 35 windows (2 t in 10^7 without a pair instead
   // of 8.5 in 10^5; 3 % more instructions in the main kernel): an item without a short pair goes through the exact path's
   // chain, and beside a main kernel of one or two rounds of resident blocks that chain costs the pass 0.3-0.4 ms (the
@@ -1242,8 +1324,14 @@ hipError_t edk_sign(uint8_t* sigs, const uint8_t* secs, const uint8_t* pubs, con
                     const uint64_t* msg_off, const uint64_t* msg_end, size_t msg_len, size_t n, const uint32_t* comb,
                     const edk_fixed_ws* ws, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  EDK_POINT_LAUNCH(k_sign_point, n, ws->acc, ws->aux, secs, msgs, msg_off, msg_end, msg_len, n, comb);
-  hipLaunchKernelGGL(k_sign_finish, EDK_FINISH_GRID(n), sigs, ws->acc, ws->aux, pubs, msgs, msg_off, msg_end, msg_len, n, (int)finish_k(n));
+  const uint32_t* perm = nullptr;                  // ragged messages: both kernels hash, both take their items in order of length
+  if (msg_off && n >= MSG_ORDER_MIN_N) {
+    const hipError_t e = msg_order(ws->perm, ws->lenbins, msg_off, msg_end, n, stream);
+    if (e != hipSuccess) return e;
+    perm = ws->perm;
+  }
+  EDK_POINT_LAUNCH(k_sign_point, n, ws->acc, ws->aux, secs, msgs, msg_off, msg_end, msg_len, n, comb, perm);
+  hipLaunchKernelGGL(k_sign_finish, EDK_FINISH_GRID(n), sigs, ws->acc, ws->aux, pubs, msgs, msg_off, msg_end, msg_len, n, (int)finish_k(n), perm);
   return hipGetLastError();
 }
 
