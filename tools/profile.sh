@@ -25,10 +25,11 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS S
 rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq_x25519 -- $CMD --op x25519 > $OUT/bench_sq_x.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq_sign -- $CMD --op sign > $OUT/bench_sq_s.log 2>&1
 # the worst case (tools/exact_lane_probe.py: every item through the exact path, then genuine signatures under random keys): the one-lane
-# exact kernels' own durations and their VALU counters
+# exact kernels' own durations, and their counters from the passes in which they have the chip to themselves ("alone": self-check mode 2 -
+# beside k_verify_main_half a kernel's cycles are not its own)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_exact -- python3 $REPO/tools/exact_lane_probe.py 20 3 > $OUT/bench_stats_exact.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq_exact -- python3 $REPO/tools/exact_lane_probe.py 20 3 > $OUT/bench_sq_exact.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_exact -- python3 $REPO/tools/exact_lane_probe.py 20 3 > $OUT/bench_fetch_exact.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq_exact -- python3 $REPO/tools/exact_lane_probe.py 20 3 alone > $OUT/bench_sq_exact.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_exact -- python3 $REPO/tools/exact_lane_probe.py 20 3 alone > $OUT/bench_fetch_exact.log 2>&1
 # the opt-in batch verification (tools/rlc_rate.py): kernel stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_rlc -- python3 $REPO/tools/rlc_rate.py 5 > $OUT/bench_stats_rlc.log 2>&1
 python3 $REPO/tools/summarize_profile.py $TAG
