@@ -290,6 +290,57 @@ def sustained_verify(w, n, seconds, local, burst_rate):
                     "clock it can hold; this is the steady state"}
 
 
+def ragged_messages(steps, device):
+    """Ragged messages: 2^18 items with lengths drawn uniformly from 0 .. 4096 bytes, in the caller's (random)
+    order, device-resident.  A lane hashes its message block by block and a wave ends with its longest message; the hashing
+    kernels take such a batch in order of length (csrc/kernels.hip: msg_order).  Signed on the GPU, verified on the GPU, a sample
+    of signatures and verdicts checked against the oracle item by item."""
+    m, top = 1 << 18, 4096
+    g = torch.Generator(device="cpu").manual_seed(20250105)
+    lens = torch.randint(0, top + 1, (m,), generator=g, dtype=torch.int64)
+    off = torch.zeros(m + 1, dtype=torch.int64)
+    off[1:] = torch.cumsum(lens, 0)
+    blob = torch.randint(0, 256, (int(off[-1]),), dtype=torch.uint8, generator=g).to(device)
+    sk = torch.randint(0, 256, (m, 32), dtype=torch.uint8, generator=g).to(device)
+    d_off = off.to(device)
+    pk = ed.ed25519_genpub_batch(sk)
+    sig = ed.ed25519_sign_batch(sk, pk, blob, msg_off=d_off)
+    bad = sig.clone()
+    bad[::9, 40] ^= 4
+    res = {}
+    for name, fn in (("verify", lambda: ed.ed25519_verify_batch(bad, pk, blob, msg_off=d_off)),
+                     ("sign", lambda: ed.ed25519_sign_batch(sk, pk, blob, msg_off=d_off))):
+        for _ in range(2):
+            out = fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = (out, e0.elapsed_time(e1) / steps)
+    ok = res["verify"][0].cpu().numpy()
+    expect = np.ones(m, np.uint8); expect[::9] = 0
+    orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))     # the checker, after the timed region
+    hs, hp, hk, hb, hsig = (t.cpu().numpy() for t in (bad, pk, sk, blob, res["sign"][0]))
+    same = bool(np.array_equal(ok, expect))
+    want_sig = ctypes.create_string_buffer(64)
+    for i in list(range(0, 96)) + list(range(m - 32, m)):
+        lo, hi = int(off[i]), int(off[i + 1])
+        mb = hb[lo:hi].tobytes()
+        same = same and bool(orc.orc_ed25519_verify(hs[i].tobytes(), hp[i].tobytes(), mb, ctypes.c_size_t(hi - lo))) == bool(ok[i])
+        orc.orc_ed25519_sign(want_sig, hk[i].tobytes(), hp[i].tobytes(), mb, ctypes.c_size_t(hi - lo))
+        same = same and want_sig.raw == hsig[i].tobytes()
+    total = int(off[-1])
+    return {"metric": "ed25519 verifies/sec on ragged messages, lengths uniform in 0 .. 4096 bytes, 2^18 items in HBM",
+            "value": m / (res["verify"][1] * 1e-3), "unit": UNIT["verify"], "ms_per_step": res["verify"][1],
+            "sign_value": m / (res["sign"][1] * 1e-3), "sign_ms_per_step": res["sign"][1], "items": m, "message_bytes": total,
+            "message_gbs_verify": total / (res["verify"][1] * 1e-3) / 1e9, "outputs_correct": same,
+            "note": "the hashing kernels take a ragged batch in order of message length (per-pass counting sort); "
+                    "profiles/r05_msglen.txt has the same batch before and after, and the long-message floor"}
+
+
 def garbage_keys(w, m, steps, device):
     """The worst case a caller can construct: the config's genuine signatures under RANDOM 32-byte keys.  ed_import never
     fails (reference lib/ed.c:100-149), about half of all strings are no curve point, and for those the reference's bytes
@@ -687,6 +738,8 @@ def main():
     if args.op == "all" and main_op == "verify" and world == 1:
         secondary["verify_garbage_keys"] = garbage_keys(w, min(n, 1 << 20), args.steps, device)
         correct = correct and secondary["verify_garbage_keys"]["outputs_correct"]
+        secondary["verify_ragged_messages"] = ragged_messages(max(2, args.steps // 2), device)
+        correct = correct and secondary["verify_ragged_messages"]["outputs_correct"]
     if args.op == "all" and main_op == "verify" and world == 1 and args.sustained > 0:
         secondary["verify_sustained"] = sustained_verify(w, n, args.sustained, local, line["value"])
         correct = correct and secondary["verify_sustained"]["outputs_correct"]

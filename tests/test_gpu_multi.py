@@ -129,6 +129,10 @@ def test_bench_default_line_carries_the_whole_metric(engine, golden):
     assert hh["outputs_correct"] is True and 0 < hh["value"] < d["value"] * 1.05
     sc = d["secondary"]["verify_small_calls"]               # the single-item function and a small batch, one caller
     assert sc["outputs_correct"] is True and 0 < sc["single_ed25519_verify_ms"] < 5 and 0 < sc["verify_batch_256_valid_ms"] < 5
+    wc = d["secondary"]["verify_garbage_keys"]               # the worst case a caller can construct: VERDICT r04 #1 asked for >= 65 M/s
+    assert wc["outputs_correct"] is True and wc["value"] > 55e6
+    rg = d["secondary"]["verify_ragged_messages"]            # ragged messages of 0 .. 4 KiB, hashed in order of length
+    assert rg["outputs_correct"] is True and rg["value"] > 30e6 and rg["sign_value"] > 30e6
     su = d["secondary"]["verify_sustained"]                 # burst and steady state side by side
     assert su["outputs_correct"] is True and su["seconds"] >= 2 and 0.5 < su["sustained_over_burst"] < 1.3
     r = d["roofline"]
