@@ -122,6 +122,37 @@ ED_DEV uint32_t sha_msg_word(const uint8_t* msg, size_t len, bool aligned, size_
   return v;
 }
 
+// The sixteen big-endian 64-bit words of a block that lies wholly inside the message, from a pointer of ANY alignment: ragged
+// messages start wherever the previous one ended.  The general path above assembles an unaligned word from four byte loads
+// behind a bounds check per word - 128 byte loads and 32 branches per block; here 33 aligned loads and one v_perm_b32 per word,
+// which shifts and swaps in one go (its selector is the pointer's low two bits).  The aligned words touched hold at least one
+// byte of the block each, so nothing outside the message's own words is read.
+ED_DEV void sha_full_block_words(uint64_t w[16], const uint8_t* p) {
+#ifdef ED_HOST_CHECK
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    uint64_t v = 0;
+    for (int t = 0; t < 8; t++) v = (v << 8) | p[8 * k + t];
+    w[k] = v;
+  }
+#else
+  const uint32_t a = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3);
+  const uint32_t* q = reinterpret_cast<const uint32_t*>(p - a);
+  uint32_t x[33];
+#pragma unroll
+  for (int j = 0; j < 32; j++) x[j] = q[j];
+  x[32] = q[a ? 32 : 31];                         // (aligned: the 33rd word is not the block's and is not touched)
+  // v_perm_b32 D, S0, S1, sel: byte i of D = byte sel[i] of the eight bytes S0:S1 (0-3: S1).  The message word at byte a of
+  // x[j+1]:x[j], most significant byte first
+  const uint32_t sel = (a + 3) | ((a + 2) << 8) | ((a + 1) << 16) | (a << 24);
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const uint32_t hi = __builtin_amdgcn_perm(x[2 * k + 1], x[2 * k], sel), lo = __builtin_amdgcn_perm(x[2 * k + 2], x[2 * k + 1], sel);
+    w[k] = ((uint64_t)hi << 32) | lo;
+  }
+#endif
+}
+
 // out[16] (little-endian words of the 64-byte digest) = SHA-512(pre[0..NPRE) || msg[0..len)).
 // NPRE is 0, 8 or 16 (so NPRE words never straddle the first block).
 template <int NPRE>
@@ -134,18 +165,24 @@ ED_DEV void sha512_prefix_msg(uint32_t out[16], const uint32_t* pre, const uint8
   const bool aligned = (reinterpret_cast<uintptr_t>(msg) & 3) == 0;
   uint64_t w[16];
   for (size_t b = 0; b < nblk; b++) {
+    // a block wholly inside the message (every block of a long message but its first, when there is a prefix, and its last
+    // one or two): no per-word bounds, any alignment
+    if ((NPRE == 0 || b > 0) && 128 * (b + 1) - 4 * (size_t)NPRE <= len) {
+      sha_full_block_words(w, msg + (128 * b - 4 * (size_t)NPRE));
+    } else {
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      uint32_t lo32, hi32;   // stream words 2k (first in byte order) and 2k+1 of this block
-      if (b == 0 && 2 * k + 1 < NPRE) {
-        hi32 = pre[2 * k];
-        lo32 = pre[2 * k + 1];
-      } else {
-        const size_t g = 32 * b + 2 * k - NPRE;
-        hi32 = sha_msg_word(msg, len, aligned, g);
-        lo32 = sha_msg_word(msg, len, aligned, g + 1);
+      for (int k = 0; k < 16; k++) {
+        uint32_t lo32, hi32;   // stream words 2k (first in byte order) and 2k+1 of this block
+        if (b == 0 && 2 * k + 1 < NPRE) {
+          hi32 = pre[2 * k];
+          lo32 = pre[2 * k + 1];
+        } else {
+          const size_t g = 32 * b + 2 * k - NPRE;
+          hi32 = sha_msg_word(msg, len, aligned, g);
+          lo32 = sha_msg_word(msg, len, aligned, g + 1);
+        }
+        w[k] = ((uint64_t)bswap32(hi32) << 32) | bswap32(lo32);
       }
-      w[k] = ((uint64_t)bswap32(hi32) << 32) | bswap32(lo32);
     }
     if (b == nblk - 1) w[15] = (uint64_t)total << 3;   // sha512.c:196-203 (high 64 bits are 0)
     sha512_compress(st, w);
