@@ -310,6 +310,10 @@ k_verify_exact_quad(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const u
 // every tile, stretch 1 of every tile, ..., so the wait is over before it starts unless the list is shorter than the chip).
 // Why not one chain per lane per launch slot: beside k_verify_main_half half of these blocks become resident late, and with a
 // fixed share of 4 chains of 2.5 ms each per lane the kernel's tail was 3 ms of a 17 ms pass (profiles/r05_exact_lane.txt).
+#ifndef EXACT_LANE_SHARE
+#define EXACT_LANE_SHARE 1
+#endif
+constexpr uint32_t EXACT_CHAIN_COST = 594;       // executed instructions per item of k_verify_exact_lane_chain, thousands
 constexpr unsigned EXACT_LANE_BLOCKS = 512;      // two resident blocks per CU
 constexpr int EXACT_DIGITS_AT = 0, EXACT_STATE_AT = 64;   // words of the item's rtable slot: the digit string; the accumulator between stretches (lines of its own)
 __global__ void __launch_bounds__(BLOCK, 2)
@@ -328,7 +332,8 @@ k_verify_exact_lane_setup(const uint32_t* digits, uint32_t* table, uint32_t* rta
 
 __global__ void __launch_bounds__(BLOCK, 2)
 k_verify_exact_lane_chain(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const uint32_t* table, uint32_t* rtable,
-                          const uint32_t* offlist, uint32_t* offcount, uint32_t* tile_done, uint32_t min_listed) {
+                          const uint32_t* offlist, uint32_t* offcount, uint32_t* tile_done, uint32_t min_listed, size_t n,
+                          uint32_t main_cost, int main_all) {
   const size_t listed = *offcount;
   if (listed < min_listed) return;
   // a tile is 128 entries of the list: a lane walks TWO chains, entries L and 64 + L of the tile (lanes.h: exact_pair_iterations)
@@ -336,7 +341,26 @@ k_verify_exact_lane_chain(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, c
   const unsigned lane = threadIdx.x & 63u;
   // no more waves than tiles: one that drew a later stretch of a tile still in its first would only hold, waiting, a slot
   // that a wave of k_verify_main_half could use
-  if ((blockIdx.x * (unsigned)BLOCK + threadIdx.x) / 64u >= tiles) return;
+  unsigned waves = tiles;
+#if EXACT_LANE_SHARE
+  // ... and no more than this kernel's SHARE of the wave slots: its persistent waves keep what they take until the list is
+  // done, the main kernel beside it fills what is left, and whichever ends first leaves the other to its own tail.  With the
+  // slots split like the work (main_cost: the main kernel's instructions per item in thousands, over the on-curve list or -
+  // main_all - over the whole pass) the two end together: a pass with every second key random 13.7 -> 12.8 ms, all random unchanged
+  // (profiles/r05_exact_lane.txt).
+  {
+    const uint64_t mine = (uint64_t)listed * EXACT_CHAIN_COST;
+    const uint64_t other = (uint64_t)(main_all ? n : (size_t)offcount[EDK_ONLIST_WORD]) * main_cost;
+    const uint64_t slots = (uint64_t)gridDim.x * (BLOCK / 64);
+    const uint64_t share = (slots * mine + (mine + other) - 1) / (mine + other);
+    // (never fewer than 512, or than there are tiles: a short list is done soonest with a wave per tile, long before the main kernel)
+    const uint64_t least = tiles < 512u ? tiles : 512u;
+    // (and only when the main kernel has the larger part: a chain that is most of the pass is soonest done with every slot it can get
+    // - all keys random, a share of 0.70: 14.3 ms with all slots, 14.7 with its share)
+    if (share * 5 < slots * 3 && share < waves) waves = (unsigned)(share < least ? least : share);
+  }
+#endif
+  if ((blockIdx.x * (unsigned)BLOCK + threadIdx.x) / 64u >= waves) return;
   for (;;) {
     unsigned u = 0;
     if (lane == 0) u = atomicAdd(offcount + EDK_EXACT_UNIT_WORD, 1u);
@@ -1218,8 +1242,11 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
       // (the scratchpad of the four-lane chain is free when these run: it holds their per-tile counts)
       EDK_LAUNCH(k_verify_exact_lane_setup, dim3(lane_blocks), dim3(BLOCK), 0, ws->side, ws->digits, ws->table, ws->rtable, ws->offlist,
                  ws->offcount, base16, ws->exact_pad, lane_min);
+      // (what runs beside it: the half-length evaluation over the on-curve list, 226 k instructions per item, or the
+      // full-length one over the whole pass, 323 k: profiles/pmc_summary.json)
+      const bool half_main = half || pair_one;
       EDK_LAUNCH(k_verify_exact_lane_chain, dim3(lane_blocks), dim3(BLOCK), 0, ws->side, ok, src.sigs, src.sig_stride, ws->table, ws->rtable,
-                 ws->offlist, ws->offcount, ws->exact_pad, lane_min);
+                 ws->offlist, ws->offcount, ws->exact_pad, lane_min, n, half_main ? 226u : 323u, half_main ? 0 : 1);
     }
     {
       // one launch: a list it would serve has fewer entries than the scratchpad has slots (lane_min != 0: fewer than lane_min;
