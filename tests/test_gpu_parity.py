@@ -229,6 +229,29 @@ def test_both_forms_of_the_exact_path_around_their_threshold(engine, oracle, n):
         assert np.array_equal(engine.ed25519_verify_batch(dev(s2), dev(keys), dev(msg_n), msg_len=32).cpu().numpy(), want), k
 
 
+def test_every_route_with_two_thirds_of_the_keys_random(engine, oracle):
+    """a pass of 2^17 items whose work list is long (a third of the keys are no curve points: the two-items-per-lane chain) on every
+    evaluation the library has - the default arrangement of that size, full-length windows (whose main kernel runs over the whole
+    pass beside the chain), half-length with one lane per item, the mid-size arrangement: the same verdict bytes, and the oracle's"""
+    import workload
+    n = 1 << 17
+    sk, msg = workload.sign_inputs(n, seed=5, config=2)
+    pk = engine.ed25519_genpub_batch(dev(sk))
+    sig = engine.ed25519_sign_batch(dev(sk), pk, dev(msg))
+    rng = np.random.default_rng(17)
+    keys = pk.cpu().numpy().copy()
+    sel = rng.permutation(n)[: n * 2 // 3]
+    keys[sel] = rng.integers(0, 256, (len(sel), 32), dtype=np.uint8)
+    want = oracle.verify_batch(sig.cpu().numpy(), keys, msg, 32)
+    assert 0 < want.sum() < n
+    try:
+        for algo in (0, 1, 2, 3):
+            engine.set_verify_algo(algo)
+            assert np.array_equal(engine.ed25519_verify_batch(sig, dev(keys), dev(msg), msg_len=32).cpu().numpy(), want), algo
+    finally:
+        engine.set_verify_algo(0)
+
+
 def test_every_item_through_the_reference_order_kernels(engine):
     """self-check mode 2: all 70 000 items (more than the 65 536 the setup/chain kernels take, so the
     strided k_verify_exact runs too) are decided by the replay of the reference's JSF/Shamir chain;
