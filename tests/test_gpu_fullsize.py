@@ -87,3 +87,22 @@ def test_reference_order_kernels_on_a_large_pass(engine):
     finally:
         engine.set_offcurve_mode(True)
     assert np.array_equal(replay, expect) and 0 < expect.sum() < n
+
+
+def test_random_keys_2_20_against_the_oracle_item_by_item(engine, oracle):
+    """the worst case at BASELINE's size: 2^20 genuine signatures of config 2 under random 32-byte keys (47 % are no curve points and
+    take the two-items-per-lane replay of the reference's chain, 493 k entries; every 16th key stays genuine; every 5th of the bad keys
+    meets R = 0, the chain's Z = 0 corner) - all 2^20 verdicts against the oracle's, which pins the reference byte for byte on keys
+    off the curve (tests/test_oracle_vs_ref.py), device pointers and, in chunks, host pointers"""
+    import workload
+    sk, msg = workload.sign_inputs(N, seed=3, config=2)
+    pk = engine.ed25519_genpub_batch(dev(sk)).cpu().numpy()
+    sig = engine.ed25519_sign_batch(dev(sk), dev(pk), dev(msg)).cpu().numpy()
+    rng = np.random.default_rng(2020)
+    keys = rng.integers(0, 256, (N, 32), dtype=np.uint8)
+    keys[3::16] = pk[3::16]
+    sig[5::80, :32] = 0
+    want = oracle.verify_batch(sig, keys, msg, 32)
+    assert want[3::16].sum() > N // 20 and want.sum() < N // 8
+    assert np.array_equal(engine.ed25519_verify_batch(dev(sig), dev(keys), dev(msg), msg_len=32).cpu().numpy(), want)
+    assert np.array_equal(engine.ed25519_verify_batch(sig, keys, msg, msg_len=32), want)
