@@ -102,6 +102,9 @@ typedef struct edk_rlc_ws {
   void* host_gok;     /* pinned host memory, one byte per group of the largest pass: the group verdicts */
 } edk_rlc_ws;
 #define EDK_RLC_HOST_BYTES 4096
+/* ragged messages: *perm = ws->perm filled with the pass's items in order of message length, or NULL (kernels.hip) */
+hipError_t edk_msg_order(const uint32_t** perm, const edk_verify_ws* ws, const uint64_t* msg_off, const uint64_t* msg_end, size_t n,
+                         hipStream_t stream);
 size_t edk_rlc_ws_bytes(size_t capacity);
 hipError_t edk_rlc_note_per_item(uint32_t* stats, size_t n, hipStream_t stream);
 /* one pass in two halves: edk_verify_rlc enqueues the combination and the copy of the group verdicts to rws->host_gok;

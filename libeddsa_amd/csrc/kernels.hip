@@ -1170,6 +1170,17 @@ static hipError_t msg_order(uint32_t* perm, uint32_t* bins, const uint64_t* msg_
   return hipGetLastError();
 }
 
+// the verify workspace's order for a pass of n items, or *perm = nullptr where the pass takes its items as they come
+// (no offset table, or fewer than MSG_ORDER_MIN_N items); rlc.hip's hashing kernel shares it
+hipError_t edk_msg_order(const uint32_t** perm, const edk_verify_ws* ws, const uint64_t* msg_off, const uint64_t* msg_end, size_t n,
+                         hipStream_t stream) {
+  *perm = nullptr;
+  if (!msg_off || n < MSG_ORDER_MIN_N) return hipSuccess;
+  const hipError_t e = msg_order(ws->perm, ws->lenbins, msg_off, msg_end, n, stream);
+  if (e == hipSuccess) *perm = ws->perm;
+  return e;
+}
+
 // Every HIP call below that orders work or moves data is checked (edk_checked.h): the first failure ends the pass with
 // that error.  What has been queued by then still runs; eddsa_amd.c: verify_on waits for it (both streams) before the
 // workspace can be handed out again, and the caller learns that the outputs are unspecified.
@@ -1199,10 +1210,7 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   const bool quad_wide = half_quad && n > QUAD_WIDE_MIN_N;
   // ragged messages: the hashing kernels take their items in order of length
   const uint32_t* perm = nullptr;
-  if (src.msg_off && n >= MSG_ORDER_MIN_N) {
-    EDK_DO(msg_order(ws->perm, ws->lenbins, src.msg_off, src.msg_end, n, stream));
-    perm = ws->perm;
-  }
+  EDK_DO(edk_msg_order(&perm, ws, src.msg_off, src.msg_end, n, stream));
   if (pair_one || quad_wide)
     EDK_LAUNCH(k_verify_prepare_pair<HALF_BITS_SMALL>, dim3(pair_point_blocks + blocks), dim3(BLOCK), 0, stream, src, n,
                ws->digits, ws->hdigits, ws->table, ws->rtable, ws->flags, ws->onlist, ws->offlist, ws->offcount, ws->exact_offcurve == 2,

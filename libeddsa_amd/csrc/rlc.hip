@@ -101,9 +101,10 @@ ED_DEV void load_words8(uint32_t w[8], const uint8_t* p) {
 // R1: per item, t and S mod l (ed25519-sha512.c:162-172) and the item's leaf of the batch hash tree
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(RLC_BLOCK, 2)
-k_rlc_hash(edk_verify_src src, size_t n, uint32_t* ts, uint32_t* leaf) {
-  const size_t i = (size_t)blockIdx.x * RLC_BLOCK + threadIdx.x;
-  if (i >= n) return;
+k_rlc_hash(edk_verify_src src, size_t n, uint32_t* ts, uint32_t* leaf, const uint32_t* perm) {
+  const size_t g = (size_t)blockIdx.x * RLC_BLOCK + threadIdx.x;
+  if (g >= n) return;
+  const size_t i = perm ? perm[g] : g;           // ragged messages: a wave hashes items of one length (edk_msg_order)
   uint32_t rw[8], aw[8], sw[8], tw[8], lf[8];
   load_words8(rw, src.sigs + i * src.sig_stride);
   load_words8(aw, src.pubs + i * src.pub_stride);
@@ -480,7 +481,9 @@ extern "C" hipError_t edk_verify_rlc(uint8_t* ok, uint32_t* stats, const edk_ver
   hipError_t e;
 
   EDK_DO(hipMemsetAsync(gflags, 0, groups * 4, stream));
-  EDK_LAUNCH(k_rlc_hash, dim3(blocks), dim3(RLC_BLOCK), 0, stream, src, n, ts, leaf);
+  const uint32_t* perm = nullptr;
+  EDK_DO(edk_msg_order(&perm, ws, src.msg_off, src.msg_end, n, stream));
+  EDK_LAUNCH(k_rlc_hash, dim3(blocks), dim3(RLC_BLOCK), 0, stream, src, n, ts, leaf, perm);
   // the batch seed: a SHA-512 tree of fan-in 64 over the leaves, on the side stream beside k_rlc_points
   EDK_DO(hipEventRecord(ws->ev_prepared, stream));
   EDK_DO(hipStreamWaitEvent(ws->side, ws->ev_prepared, 0));

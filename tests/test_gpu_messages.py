@@ -100,7 +100,7 @@ def test_ragged_batches_are_hashed_in_order_of_length(engine, oracle, n):
     """passes of 4096 items or more with an offset table take their items through a permutation sorted by message length
     (csrc/kernels.hip: msg_order - a wave ends with its longest message); the verdicts and signatures must not know: lengths from
     0 to 3000 bytes with a few of 40 000, one length repeated a thousand times, on the routes of 4095 (no permutation), 4096, 70 000
-    and 300 000 items, verify and sign and the batch verification, device pointers and - through the chunked pipeline - host
+    and 300 000 items, verify and sign and the batch verification (per-item routing and the combination), device pointers and - through the chunked pipeline - host
     pointers"""
     import torch
     rng = np.random.default_rng(n)
@@ -123,6 +123,15 @@ def test_ragged_batches_are_hashed_in_order_of_length(engine, oracle, n):
     got = engine.ed25519_verify_batch(dev(sig_n), dev(pk_n), dev(blob), msg_off=d_off).cpu().numpy()
     assert np.array_equal(got, want)
     assert np.array_equal(engine.ed25519_verify_batch_rlc(dev(sig_n), dev(pk_n), dev(blob), msg_off=d_off).cpu().numpy(), want)
+    # the combination itself (csrc/rlc.hip: k_rlc_hash takes the same permutation; calls of this size go to the per-item
+    # kernels unless told otherwise): the genuine batch is accepted whole by it, the damaged one falls back group by group
+    engine.set_rlc_min_items(0)
+    try:
+        ok, st = engine.ed25519_verify_batch_rlc(dev(sig[idx]), dev(pk_n), dev(blob), msg_off=d_off, return_stats=True)
+        assert ok.cpu().numpy().all() and st[0] == n and st[2] == 0
+        assert np.array_equal(engine.ed25519_verify_batch_rlc(dev(sig_n), dev(pk_n), dev(blob), msg_off=d_off).cpu().numpy(), want)
+    finally:
+        engine.set_rlc_min_items(3 << 17)
     out = engine.ed25519_sign_batch(dev(sk_n), dev(pk_n), dev(blob), msg_off=d_off).cpu().numpy()
     assert np.array_equal(out, sig[idx])
     if n <= 70000:
