@@ -120,9 +120,9 @@ constexpr int LEN_BINS = EDK_LEN_BINS;           // key = min(length / 128, LEN_
 constexpr size_t MSG_ORDER_MIN_N = (size_t)1 << 12;
 
 ED_DEV uint32_t len_bin(const uint64_t* off, const uint64_t* end, size_t item) {
-  const uint8_t* m; size_t mlen;
-  msg_span(m, mlen, nullptr, off, end, 0, 0, item);            // (the clamped span: what the hashing kernels will read)
-  const size_t blocks = mlen >> 7;
+  uint64_t lo, hi;
+  ragged_span(lo, hi, off, end, item);                         // (the clamped span: what the hashing kernels will read)
+  const size_t blocks = (size_t)(hi - lo) >> 7;
   return (uint32_t)(LEN_BINS - 1) - (uint32_t)(blocks < (size_t)LEN_BINS - 1 ? blocks : (size_t)LEN_BINS - 1);
 }
 

@@ -53,13 +53,17 @@ ED_DEV void shl256(uint32_t w[8]) {
 // the message buffer - and to a length that is not negative: a table that is not non-decreasing (the host-pointer entry
 // points refuse one with hipErrorInvalidValue; a table in device memory cannot be inspected without a pass of its own)
 // never makes a lane read outside [msgs, msgs + *end).  Such an item is hashed over the clamped span.
+ED_DEV void ragged_span(uint64_t& lo, uint64_t& hi, const uint64_t* off, const uint64_t* end, size_t item) {
+  const uint64_t total = *end;
+  lo = off[item]; hi = off[item + 1];
+  lo = lo < total ? lo : total;
+  hi = hi < lo ? lo : hi < total ? hi : total;
+}
 ED_DEV void msg_span(const uint8_t*& m, size_t& mlen, const uint8_t* msgs, const uint64_t* off, const uint64_t* end,
                      size_t len, size_t stride, size_t item) {
   if (off) {
-    const uint64_t total = *end;
-    uint64_t lo = off[item], hi = off[item + 1];
-    lo = lo < total ? lo : total;
-    hi = hi < lo ? lo : hi < total ? hi : total;
+    uint64_t lo, hi;
+    ragged_span(lo, hi, off, end, item);
     m = msgs + lo; mlen = (size_t)(hi - lo);
   } else { m = msgs + item * stride; mlen = len; }
 }
