@@ -231,6 +231,12 @@ def test_device_calls_clamp_an_offset_table_that_lies(engine, oracle, n):
     assert ok[~touched].all() and not ok[touched].all()
     ok = engine.ed25519_verify_batch_rlc(d["sig"], d["pk"], d["blob"], msg_off=d["off"]).cpu().numpy()
     assert ok[~touched].all()
+    engine.set_rlc_min_items(0)                            # ... and through the combination itself (its own hashing kernel)
+    try:
+        ok = engine.ed25519_verify_batch_rlc(d["sig"], d["pk"], d["blob"], msg_off=d["off"]).cpu().numpy()
+    finally:
+        engine.set_rlc_min_items(3 << 17)
+    assert ok[~touched].all() and not ok[touched].all()
     out = engine.ed25519_sign_batch(d["sk"], d["pk"], d["blob"], msg_off=d["off"]).cpu().numpy()
     assert np.array_equal(out[~touched], sig_n[~touched])
     torch.cuda.synchronize()
