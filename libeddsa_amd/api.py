@@ -24,7 +24,9 @@ class EddsaAmdError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "libeddsa_amd.so")
+    """The in-tree build; EDDSA_AMD_LIBRARY names another build of the same sources instead (tools/ab.sh: A/B measurements
+    load their variants this way and never overwrite the product library)."""
+    return os.environ.get("EDDSA_AMD_LIBRARY") or os.path.join(_HERE, "libeddsa_amd.so")
 
 
 def _share_the_hip_runtime_with_torch():

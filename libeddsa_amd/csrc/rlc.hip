@@ -31,12 +31,12 @@
 // may pass although the reference's cofactorless per-item check rejects those items (or fail although all
 // pass; that case only costs time).  tests/test_device_source_on_host.py pins both statements.
 //
-// The multi-scalar multiplication is a bucket method laid out for the wavefront: one workgroup of 128
-// lanes per (group, byte-window), 128 buckets for the signed 8-bit digits: the workgroup counting-sorts
-// the group's digits of that window in LDS (17 KB), hands the buckets to its lanes by size rank (the 64
-// fullest to wave 0: a wave takes as long as its fullest lane), each lane adds the points of its bucket
-// (mixed additions, ed_add_pc's 7 M), and the weighted sum of the 128 buckets is two log-step scans
-// through LDS; k_rlc_final then runs Horner over the 48 window points of each group (four lanes per
+// The multi-scalar multiplication is a bucket method laid out for the wavefront: one wave of 64 lanes
+// per (group, byte-window), 128 buckets for the signed 8-bit digits: the wave counting-sorts the group's
+// digits of that window in LDS (18 KB), hands the buckets to its lanes in pairs by size rank (the fullest
+// with the emptiest ...: a wave takes as long as its busiest lane), each lane adds the points of its two
+// buckets (mixed additions, ed_add_pc's 7 M), and the weighted sum of the 128 buckets is fifteen additions
+// deep through LDS; k_rlc_final then runs Horner over the 48 window points of each group (four lanes per
 // point, quad_lanes.h: 248 dependent doublings are pure latency).
 // -A_i has 32 windows (z_i t_i mod 8 l, centred: |.| <= 4 l), -R_i 16 (z_i), B one entry per group and window: 48 mixed
 // additions per item instead of the per-item kernel's 252 doublings + 80 additions.  Algorithmic HBM
@@ -232,32 +232,33 @@ k_rlc_group_scalar(size_t n, const uint32_t* bsum, int8_t* bdig) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// R5: the buckets.  Block (segment, group); lane b owns bucket b + 1.
+// R5: the buckets.  One wave per (group, window); a lane adds up two buckets, a full and a sparse one.
 // ---------------------------------------------------------------------------------------------
+constexpr int RLC_LANES = 64;
 struct rlc_lds {
   uint32_t hist[RLC_BUCKETS + 4];
   uint32_t cursor[RLC_BUCKETS + 4];
   uint32_t first[RLC_BUCKETS + 4];               // where each bucket's run starts in the sorted list
-  uint32_t perm[RLC_BUCKETS];                    // rank by size -> bucket: lane l serves bucket perm[l]
+  uint32_t perm[RLC_BUCKETS];                    // rank by size -> bucket
   union {
     uint16_t list[RLC_G + 2];                    // entry = item index in the group (or RLC_BASE_IDX) | sign << 15
-    uint32_t pts[RLC_BUCKETS * 40];              // exchange area of the final scans (after the last window)
+    uint32_t pts[RLC_LANES * 40];                // exchange area of the weighted sum (after the list's last use)
   };
 };
 
 ED_DEV void lds_put_at(uint32_t* pts, const ge& p, int slot) {
 #pragma unroll
   for (int j = 0; j < 10; j++) {
-    pts[j * RLC_BUCKETS + slot] = p.X.v[j];        pts[(10 + j) * RLC_BUCKETS + slot] = p.Y.v[j];
-    pts[(20 + j) * RLC_BUCKETS + slot] = p.Z.v[j]; pts[(30 + j) * RLC_BUCKETS + slot] = p.T.v[j];
+    pts[j * RLC_LANES + slot] = p.X.v[j];        pts[(10 + j) * RLC_LANES + slot] = p.Y.v[j];
+    pts[(20 + j) * RLC_LANES + slot] = p.Z.v[j]; pts[(30 + j) * RLC_LANES + slot] = p.T.v[j];
   }
 }
 ED_DEV void lds_put(uint32_t* pts, const ge& p) { lds_put_at(pts, p, (int)threadIdx.x); }
 ED_DEV void lds_get(ge& p, const uint32_t* pts, int lane) {
 #pragma unroll
   for (int j = 0; j < 10; j++) {
-    p.X.v[j] = pts[j * RLC_BUCKETS + lane];        p.Y.v[j] = pts[(10 + j) * RLC_BUCKETS + lane];
-    p.Z.v[j] = pts[(20 + j) * RLC_BUCKETS + lane]; p.T.v[j] = pts[(30 + j) * RLC_BUCKETS + lane];
+    p.X.v[j] = pts[j * RLC_LANES + lane];        p.Y.v[j] = pts[(10 + j) * RLC_LANES + lane];
+    p.Z.v[j] = pts[(20 + j) * RLC_LANES + lane]; p.T.v[j] = pts[(30 + j) * RLC_LANES + lane];
   }
 }
 ED_DEV void ge_add_full(ge& r, const ge& p, const ge& q) {
@@ -265,119 +266,160 @@ ED_DEV void ge_add_full(ge& r, const ge& p, const ge& q) {
   ge_to_cached(c, q);
   ge_add_cached(r, p, c, true);
 }
+ED_DEV void ge_cmov(ge& r, const ge& p, bool flag) {
+  fe_cmov(r.X, p.X, flag); fe_cmov(r.Y, p.Y, flag); fe_cmov(r.Z, p.Z, flag); fe_cmov(r.T, p.T, flag);
+}
 
-__global__ void __launch_bounds__(RLC_BUCKETS, 4)
+__global__ void __launch_bounds__(RLC_LANES, 2)
 k_rlc_bucket(size_t n, const int8_t* dig, const int8_t* bdig, const uint32_t* niels_a, const uint32_t* niels_r,
              const uint32_t* base16, uint32_t* segpts) {
   __shared__ rlc_lds s;
   const size_t groups = (n + RLC_G - 1) / RLC_G;
-  const int seg = (int)(blockIdx.x / groups);    // segment-major: the segments with the longest tails first
+  const int seg = (int)(blockIdx.x / groups);    // window-major
   const size_t g = blockIdx.x % groups;
   const bool is_a = seg < RLC_SEGS_A;
-  // windows of this segment, high to low; segment s of -A and segment s - 4 of -R carry the same weight
-  const int w_hi = (is_a ? RLC_WINDOWS_A - 1 - RLC_SEG_WINDOWS * seg : RLC_WINDOWS_R - 1 - RLC_SEG_WINDOWS * (seg - RLC_SEGS_A));
-  const int w_lo = w_hi - (RLC_SEG_WINDOWS - 1);
+  // window of this block; window s of -A and window s - 16 of -R carry the same weight
+  const int w = (is_a ? RLC_WINDOWS_A - 1 - seg : RLC_WINDOWS_R - 1 - (seg - RLC_SEGS_A));
   const uint32_t* pts = (is_a ? niels_a : niels_r) + g * (size_t)RLC_G * 32;
   const int8_t* drow = dig + (g * RLC_WINDOWS + (is_a ? 0 : RLC_WINDOWS_A)) * (size_t)RLC_G;
-  const int b = (int)threadIdx.x;                // bucket b + 1
-  ge acc;
-  ge_neutral(acc);
+  const int l = (int)threadIdx.x;
+  static_assert(RLC_SEG_WINDOWS == 1 && RLC_BUCKETS == 2 * RLC_LANES, "one window per wave, two buckets per lane");
+
+  // counting sort of the window's digits by magnitude; for the bookkeeping lane l owns buckets l + 1 and l + 65
+  s.hist[l + 1] = 0;
+  s.hist[l + 1 + RLC_LANES] = 0;
+  if (l == 0) s.hist[0] = 0;
+  __syncthreads();
+  // this lane's 128 digits of the window: items 16 (64 j + l) .. + 15, j < 8, one 16-byte load per j
+  // (rows are whole: k_rlc_scalars zeroes the digits of the slots past the end of the batch)
+  const uint4* dw = reinterpret_cast<const uint4*>(drow + (size_t)w * RLC_G);
+  const int bd = (is_a && l == 0) ? (int)bdig[32 * g + w] : 0;               // lane 0 also files the base point
 #pragma unroll 1
-  for (int w = w_hi; w >= w_lo; w--) {
-    if (w != w_hi) {
-#pragma unroll 1
-      for (int k = 0; k < 8; k++) ge_dbl(acc, acc, k == 7);
-    }
-    // counting sort of this window's digits by magnitude
-    s.hist[b + 1] = 0;
-    if (b == 0) s.hist[0] = 0;
-    __syncthreads();
-    // this lane's 64 digits of the window: items 16 (128 j + b) .. + 15, j < 4, one 16-byte load per j
-    // (rows are whole: k_rlc_scalars zeroes the digits of the slots past the end of the batch)
-    const uint4* dw = reinterpret_cast<const uint4*>(drow + (size_t)w * RLC_G);
-    const int bd = (is_a && b == 0) ? (int)bdig[32 * g + w] : 0;             // lane 0 also files the base point
-#pragma unroll 1
-    for (int j = 0; j < 4; j++) {
-      const uint4 v = dw[j * RLC_BUCKETS + b];
-      const uint32_t dd[4] = {v.x, v.y, v.z, v.w};
+  for (int j = 0; j < RLC_G / (16 * RLC_LANES); j++) {
+    const uint4 v = dw[j * RLC_LANES + l];
+    const uint32_t dd[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int t = 0; t < 16; t++) {
-        const int d = (int)(int8_t)(dd[t >> 2] >> (8 * (t & 3)));
-        if (d != 0) atomicAdd(&s.hist[d < 0 ? -d : d], 1u);
-      }
+    for (int t = 0; t < 16; t++) {
+      const int d = (int)(int8_t)(dd[t >> 2] >> (8 * (t & 3)));
+      if (d != 0) atomicAdd(&s.hist[d < 0 ? -d : d], 1u);
     }
-    if (bd != 0) atomicAdd(&s.hist[bd < 0 ? -bd : bd], 1u);
-    __syncthreads();
-    uint32_t start = 0, rank = 0;
-    const uint32_t own = s.hist[b + 1];
-    for (int q = 1; q <= RLC_BUCKETS; q++) {     // prefix sum, and this bucket's rank by size (fullest first)
+  }
+  if (bd != 0) atomicAdd(&s.hist[bd < 0 ? -bd : bd], 1u);
+  __syncthreads();
+  {
+    uint32_t start0 = 0, start1 = 0, rank0 = 0, rank1 = 0;
+    const uint32_t own0 = s.hist[l + 1], own1 = s.hist[l + 1 + RLC_LANES];
+    for (int q = 1; q <= RLC_BUCKETS; q++) {     // prefix sums, and the two buckets' ranks by size (fullest first)
       const uint32_t c = s.hist[q];
-      if (q <= b) start += c;
-      rank += (c > own || (c == own && q < b + 1)) ? 1u : 0u;
+      if (q <= l) start0 += c;
+      if (q <= l + RLC_LANES) start1 += c;
+      rank0 += (c > own0 || (c == own0 && q < l + 1)) ? 1u : 0u;
+      rank1 += (c > own1 || (c == own1 && q < l + 1 + RLC_LANES)) ? 1u : 0u;
     }
-    s.cursor[b + 1] = start;
-    s.first[b + 1] = start;
-    s.perm[rank] = (uint32_t)b;
-    __syncthreads();
+    s.cursor[l + 1] = start0;              s.first[l + 1] = start0;              s.perm[rank0] = (uint32_t)l;
+    s.cursor[l + 1 + RLC_LANES] = start1;  s.first[l + 1 + RLC_LANES] = start1;  s.perm[rank1] = (uint32_t)(l + RLC_LANES);
+  }
+  __syncthreads();
 #pragma unroll 1
-    for (int j = 0; j < 4; j++) {
-      const uint4 v = dw[j * RLC_BUCKETS + b];
-      const uint32_t dd[4] = {v.x, v.y, v.z, v.w};
+  for (int j = 0; j < RLC_G / (16 * RLC_LANES); j++) {
+    const uint4 v = dw[j * RLC_LANES + l];
+    const uint32_t dd[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int t = 0; t < 16; t++) {
-        const int d = (int)(int8_t)(dd[t >> 2] >> (8 * (t & 3)));
-        const int k = 16 * (j * RLC_BUCKETS + b) + t;
-        if (d != 0) s.list[atomicAdd(&s.cursor[d < 0 ? -d : d], 1u)] = (uint16_t)(k | (d < 0 ? 0x8000 : 0));
-      }
+    for (int t = 0; t < 16; t++) {
+      const int d = (int)(int8_t)(dd[t >> 2] >> (8 * (t & 3)));
+      const int k = 16 * (j * RLC_LANES + l) + t;
+      if (d != 0) s.list[atomicAdd(&s.cursor[d < 0 ? -d : d], 1u)] = (uint16_t)(k | (d < 0 ? 0x8000 : 0));
     }
-    if (bd != 0) s.list[atomicAdd(&s.cursor[bd < 0 ? -bd : bd], 1u)] = (uint16_t)(RLC_BASE_IDX | (bd < 0 ? 0x8000 : 0));
-    __syncthreads();
-    // Lane l adds the points of the bucket whose size has rank l: the 64 fullest buckets of the window go to
-    // wave 0, the 64 emptiest to wave 1.  A wave takes as long as its fullest lane (a bucket holds Poisson(64)
-    // points), so in bucket order both waves paid for a near-maximal bucket (~86 additions each); sorted, the
-    // second wave stops at the median (~64).  (Fetching the next entry by hand during the second half of the
-    // current addition measured the same and cost 6 spilled registers: not kept.)
-    const int mb = (int)s.perm[b];
-    const uint32_t lo = s.first[mb + 1], cnt = s.hist[mb + 1];
-#pragma unroll 1
-    for (uint32_t q = lo; q < lo + cnt; q++) {
-      const uint32_t e = s.list[q], idx = e & 0x7fffu;
-      ge_niels nl;
-      niels_load(nl, idx == RLC_BASE_IDX ? base16 + TABLE_ENTRY_WORDS : pts + 32 * (size_t)idx);
-      ge_niels_cneg(nl, (e & 0x8000u) != 0);
-      ge_add_niels(acc, acc, nl, true);
-    }
-    __syncthreads();
-    lds_put_at(s.pts, acc, mb);                  // back to bucket order for the weighted sum
-    __syncthreads();
-    lds_get(acc, s.pts, b);
-    __syncthreads();
   }
-  static_assert(RLC_SEG_WINDOWS == 1, "the size-ranked lane assignment is per window");
-  // sum over buckets of (b + 1) * acc_b = sum over b of the suffix sums T_b = acc_b + acc_(b+1) + ...
+  if (bd != 0) s.list[atomicAdd(&s.cursor[bd < 0 ? -bd : bd], 1u)] = (uint16_t)(RLC_BASE_IDX | (bd < 0 ? 0x8000 : 0));
+  __syncthreads();
+  // Lane l adds up the bucket whose size has rank l and then the bucket of rank 127 - l: a wave takes as long as its
+  // busiest lane, a bucket holds Poisson(64) points (the fullest of 128 about 86), and the fullest plus the emptiest,
+  // the second fullest plus the second emptiest ... all come to about twice the mean: the busiest lane has 130.5
+  // additions where the mean is 127.5.  (Round 5 gave the 64 fullest buckets to one wave of a two-wave block and the
+  // 64 emptiest to the other; the block met at a barrier, so both waves paid for the fullest bucket: 2 x 86.)
+  const int mb1 = (int)s.perm[l], mb2 = (int)s.perm[RLC_BUCKETS - 1 - l];
+  const uint32_t lo1 = s.first[mb1 + 1], cnt1 = s.hist[mb1 + 1];
+  const uint32_t lo2 = s.first[mb2 + 1], total = cnt1 + s.hist[mb2 + 1];
+  ge acc, acc1;
+  ge_neutral(acc);
+  ge_neutral(acc1);
 #pragma unroll 1
-  for (int stride = 1; stride < RLC_BUCKETS; stride <<= 1) {                 // inclusive suffix scan
+  for (uint32_t q = 0; q < total; q++) {
+    const uint32_t e = s.list[q < cnt1 ? lo1 + q : lo2 + (q - cnt1)], idx = e & 0x7fffu;
+    ge_niels nl;
+    niels_load(nl, idx == RLC_BASE_IDX ? base16 + TABLE_ENTRY_WORDS : pts + 32 * (size_t)idx);
+    ge_niels_cneg(nl, (e & 0x8000u) != 0);
+    ge_add_niels(acc, acc, nl, true);
+    if (q + 1 == cnt1) { acc1 = acc; ge_neutral(acc); }     // the first bucket is done (some 18 distinct counts per wave)
+  }
+  // (Fetching the next entry's line during the current addition - two register sets taken in turn, so that the loads
+  // really are in flight - measured the same: the SIMD's other wave covers the wait.)
+  __syncthreads();
+  // Back to bucket order, two buckets per lane again: lane j takes the sums of buckets 2 j + 1 and 2 j + 2 (sa, sb; a
+  // bucket's number is its digit's magnitude = its weight) - in two rounds, the odd-numbered buckets and then the
+  // even-numbered ones, so that the exchange area is 64 points (10 KB) and not 128
+  ge sa, sb;
+  if ((mb1 & 1) == 0) lds_put_at(s.pts, acc1, mb1 >> 1);
+  if ((mb2 & 1) == 0) lds_put_at(s.pts, acc, mb2 >> 1);
+  __syncthreads();
+  lds_get(sa, s.pts, l);
+  __syncthreads();
+  if ((mb1 & 1) != 0) lds_put_at(s.pts, acc1, mb1 >> 1);
+  if ((mb2 & 1) != 0) lds_put_at(s.pts, acc, mb2 >> 1);
+  __syncthreads();
+  lds_get(sb, s.pts, l);
+  __syncthreads();
+  // sum over buckets of weight * sum = sum_j (2 j + 1) sa_j + (2 j + 2) sb_j = 2 sum_j (j + 1) u_j - sum_j sa_j with
+  // u_j = sa_j + sb_j; sum_j (j + 1) u_j is the sum of the suffix sums t_j = u_j + u_(j+1) + ...  Fifteen additions deep
+  // for 128 buckets: one for u, six for the scan, six for the two tree sums (of the t_j in lanes 0..31 and of the sa_j
+  // in lanes 32..63, side by side), a doubling and the last addition.
+  ge_add_full(acc, sa, sb);                      // u
+#pragma unroll 1
+  for (int stride = 1; stride < RLC_LANES; stride <<= 1) {                   // inclusive suffix scan
     lds_put(s.pts, acc);
     __syncthreads();
-    if (b + stride < RLC_BUCKETS) {
+    if (l + stride < RLC_LANES) {
       ge o;
-      lds_get(o, s.pts, b + stride);
+      lds_get(o, s.pts, l + stride);
       ge_add_full(acc, acc, o);
     }
     __syncthreads();
   }
-#pragma unroll 1
-  for (int stride = RLC_BUCKETS / 2; stride >= 1; stride >>= 1) {            // tree sum of the T_b
+  {                                              // first step of both trees: lanes 0..31 t_l + t_(l+32), lanes 32..63 sa_(l-32) + sa_l
+    ge o, o2;
     lds_put(s.pts, acc);
     __syncthreads();
-    if (b < stride) {
+    lds_get(o, s.pts, l ^ 32);
+    __syncthreads();
+    lds_put(s.pts, sa);
+    __syncthreads();
+    lds_get(o2, s.pts, l ^ 32);
+    __syncthreads();
+    ge_cmov(acc, sa, l >= 32);
+    ge_cmov(o, o2, l >= 32);
+    ge_add_full(acc, acc, o);
+  }
+#pragma unroll 1
+  for (int stride = RLC_LANES / 4; stride >= 1; stride >>= 1) {
+    lds_put(s.pts, acc);
+    __syncthreads();
+    if ((l & 31) < stride) {
       ge o;
-      lds_get(o, s.pts, b + stride);
+      lds_get(o, s.pts, l + stride);
       ge_add_full(acc, acc, o);
     }
     __syncthreads();
   }
-  if (b == 0) {                                  // the window's weight 2^(8 w_lo) is applied by k_rlc_final
+  lds_put(s.pts, acc);
+  __syncthreads();
+  if (l == 0) {                                  // the window's weight 2^(8 w) is applied by k_rlc_final
+    ge o;
+    lds_get(o, s.pts, 32);                       // sum of the sa_j: subtracted
+    fe_neg(o.X, o.X); fe_carry(o.X);
+    fe_neg(o.T, o.T); fe_carry(o.T);
+    ge_dbl(acc, acc, true);
+    ge_add_full(acc, acc, o);
     ge_cached c;                                 // stored in cached form (Y-X | Y+X | 2dT | 2Z): what quad_add_entry reads
     ge_to_cached(c, acc);
     cached_store(segpts + (g * RLC_SEGS + seg) * VERIFY_ENTRY_WORDS, 0, c);
@@ -504,7 +546,7 @@ extern "C" hipError_t edk_verify_rlc(uint8_t* ok, uint32_t* stats, const edk_ver
   EDK_DO(hipStreamWaitEvent(stream, ws->ev_exact, 0));
   EDK_LAUNCH(k_rlc_scalars, dim3((unsigned)(groups * (RLC_G / RLC_BLOCK))), dim3(RLC_BLOCK), 0, stream, n, ts, seed, flags, dig, bsum);
   EDK_LAUNCH(k_rlc_group_scalar, dim3((unsigned)((groups + 63) / 64)), dim3(64), 0, stream, n, bsum, bdig);
-  EDK_LAUNCH(k_rlc_bucket, dim3((unsigned)(groups * RLC_SEGS)), dim3(RLC_BUCKETS), 0, stream, n, dig, bdig,
+  EDK_LAUNCH(k_rlc_bucket, dim3((unsigned)(groups * RLC_SEGS)), dim3(RLC_LANES), 0, stream, n, dig, bdig,
                      niels_a, niels_r, base16, segpts);
   EDK_LAUNCH(k_rlc_final, dim3((unsigned)((4 * groups + 255) / 256)), dim3(256), 0, stream, n, segpts, gflags, gok, stats);
   EDK_LAUNCH(k_rlc_verdicts, dim3(blocks), dim3(RLC_BLOCK), 0, stream, n, gok, flags, ok);

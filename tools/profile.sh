@@ -30,6 +30,9 @@ rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_exact -- python3 $REPO/tools/exact_lane_probe.py 20 3 > $OUT/bench_stats_exact.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq_exact -- python3 $REPO/tools/exact_lane_probe.py 20 3 alone > $OUT/bench_sq_exact.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_exact -- python3 $REPO/tools/exact_lane_probe.py 20 3 alone > $OUT/bench_fetch_exact.log 2>&1
-# the opt-in batch verification (tools/rlc_rate.py): kernel stats
+# the opt-in batch verification (tools/rlc_rate.py): kernel stats, then its counters (the k_rlc_* kernels' rows of the summary)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_rlc -- python3 $REPO/tools/rlc_rate.py 5 > $OUT/bench_stats_rlc.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq_rlc -- python3 $REPO/tools/rlc_rate.py 3 > $OUT/bench_sq_rlc.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_rlc -- python3 $REPO/tools/rlc_rate.py 3 > $OUT/bench_fetch_rlc.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_rlc -- python3 $REPO/tools/rlc_rate.py 3 > $OUT/bench_write_rlc.log 2>&1
 python3 $REPO/tools/summarize_profile.py $TAG

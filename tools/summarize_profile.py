@@ -43,7 +43,8 @@ if rows:
 
 out = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc", "pmc_fetch_x25519", "pmc_write_x25519",
-            "pmc_fetch_sign", "pmc_write_sign", "pmc_sq_x25519", "pmc_sq_sign", "pmc_sq_exact", "pmc_fetch_exact"):
+            "pmc_fetch_sign", "pmc_write_sign", "pmc_sq_x25519", "pmc_sq_sign", "pmc_sq_exact", "pmc_fetch_exact",
+            "pmc_sq_rlc", "pmc_fetch_rlc", "pmc_write_rlc"):
     for f in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         meta = {}
@@ -57,6 +58,8 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc", "pmc_fetch_x25519", 
         for k, cs in agg.items():
             if sub.endswith("_exact") and "exact_lane" not in k:
                 continue                       # (that workload's other kernels ran over mixed list lengths: the bench passes speak for them)
+            if sub.endswith("_rlc") and "k_rlc_" not in k:
+                continue                       # (tools/rlc_rate.py also times the per-item kernels: their rows come from the bench passes)
             if k.startswith("ed::"):
                 # the verify workload builder also runs sign/genpub once; prefer the op's own pass
                 if "_" in sub.replace("pmc_", "", 1) or not any(c in out.get(k, {}) for c in cs):
