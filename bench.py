@@ -582,6 +582,10 @@ def spawn_ranks(n, argv):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    # HSA_ENABLE_IPC_MODE_LEGACY: this pool's host driver supports dmabuf IPC only - with the legacy mode RCCL's buffer
+    # exchange between the ranks fails in hipIpcGetMemHandle ("invalid argument").  The image and the GPU boxes export 0;
+    # the ranks inherit whatever the caller's environment says, and 0 only when it says nothing (ROCm 7.2.0 / RCCL 2.2x of
+    # this image; nothing else in the repository touches the variable).
     return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
 
 
@@ -621,6 +625,13 @@ def main():
         else:
             dist.init_process_group(backend)
         HOST_GROUP[0] = dist.new_group(backend="gloo")     # host-side barriers and small host gathers
+        # a misconfigured node fails here, in seconds, before a 2^24-item workload is generated: every rank on a device
+        # of its own (exits otherwise), the ranks the launcher was asked for, and a collective library that answers
+        facts = collective_facts(world, backend, os.environ.get("EDDSA_BENCH_SHARE_GPU") == "1")
+        if facts["world"] != args.gpus:
+            raise SystemExit(f"bench.py: the process group has {facts['world']} ranks, --gpus says {args.gpus}")
+        if backend == "nccl" and not facts["version"]:
+            raise SystemExit("bench.py: torch.cuda.nccl.version() gives nothing: no RCCL behind torch.distributed")
     ed.init(local)
 
     # sizes: config 2 at N = 1, config 4 (2^24 in total) at N > 1, unless --log2n says otherwise
