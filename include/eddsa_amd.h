@@ -33,8 +33,11 @@
  *                and returns without synchronising.
  *
  * Return value: 0 on success, otherwise the negated hipError_t of the failing HIP call (the
- * reference has no error channel; a loop over it cannot fail).  On error the outputs are
- * unspecified.  Ownership: the caller owns every buffer; the library keeps no pointer after a
+ * reference has no error channel; a loop over it cannot fail), or EDDSA_AMD_STALLED: a kernel gave up
+ * waiting for a hand-off between its own waves (seconds, where the hand-off takes a millisecond: a
+ * fault on the device) - the pass's outputs are incomplete.  A host-pointer call reports it itself; a
+ * device-pointer call has returned by then, and the next verify call on that device reports it instead
+ * (and is not run).  On error the outputs are unspecified.  Ownership: the caller owns every buffer; the library keeps no pointer after a
  * host-pointer call returns / after the stream work of a device-pointer call completes.
  * Devices: the library keeps one engine (tables, workspaces, staging pipeline) per HIP device,
  * created on first use.  A device-pointer call runs on the device that holds its output buffer; a
@@ -119,6 +122,7 @@ EDDSA_AMD_DECL void eddsa_amd_host_free(void *p);
 /* helper threads that copy ordinary caller memory into the staging buffers beside the calling thread (default 6, at
  * most 16; 0 = the caller copies alone) */
 EDDSA_AMD_DECL void eddsa_amd_set_host_threads(int n);
+#define EDDSA_AMD_STALLED (-100003)
 /* human-readable text for a negative return value */
 EDDSA_AMD_DECL const char *eddsa_amd_strerror(int err);
 /* How ed25519_verify* treats a public key that does not decode to a curve point (the reference's

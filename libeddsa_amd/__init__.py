@@ -11,6 +11,8 @@ from .api import (  # noqa: F401
     EddsaAmdError,
     DH,
     HOOKS_OFF,
+    STALLED,
+    debug_withhold_handoff,
     debug_fail_hip_call,
     debug_fail_next_host_call,
     debug_halve,

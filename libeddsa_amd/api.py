@@ -120,6 +120,15 @@ def debug_hip_calls():
     return int(library().eddsa_amd_debug_hip_calls())
 
 
+STALLED = -100003
+
+
+def debug_withhold_handoff(tile_plus_1):
+    """the first hand-off of that tile of k_verify_exact_lane_chain is never published in the passes that follow (0: off);
+    HOOKS_OFF when not armed"""
+    return int(library().eddsa_amd_debug_withhold_handoff(int(tile_plus_1)))
+
+
 def debug_teardown_errors():
     """(count, first hipError_t) of the HIP calls that failed on teardown / clean-up paths since the library was loaded"""
     first = ctypes.c_int(0)

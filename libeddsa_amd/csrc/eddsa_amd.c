@@ -37,6 +37,7 @@ const char *eddsa_amd_strerror(int err)
     if (err == ERR_NOT_GFX950) return "eddsa_amd: device is not gfx950 (MI355X); no code object for it";
     if (err == ERR_RCCL_MISSING) return "eddsa_amd: librccl.so.1 could not be loaded (needed for the multi-device result gather)";
     if (err == EDDSA_AMD_HOOKS_OFF) return "eddsa_amd: test hooks not armed (eddsa_amd_debug_init)";
+    if (err == EDDSA_AMD_STALLED) return "eddsa_amd: a verify kernel gave up waiting for a hand-off between its waves; the pass's outputs are incomplete";
     if (err <= ERR_RCCL_BASE) {
         if (g_multi.GetErrorString) return g_multi.GetErrorString(ERR_RCCL_BASE - err);
         return "eddsa_amd: RCCL error";
@@ -237,6 +238,7 @@ static void engine_destroy(struct engine *e)
     if (e->base16) HIP_NOTE(hipFree(e->base16));
     if (e->comb) HIP_NOTE(hipFree(e->comb));
     if (e->comb_img) HIP_NOTE(hipFree(e->comb_img));
+    if (e->status) HIP_NOTE(hipHostFree(e->status));
     for (int s = 0; s < MARK_SLOTS; s++)
         for (int i = 0; i < 4; i++) if (e->marks[s][i]) HIP_NOTE(hipEventDestroy(e->marks[s][i]));
     pthread_mutex_destroy(&e->lk);
@@ -268,11 +270,14 @@ static int engine_create(int device)
     TRY(hipMalloc((void **)&e->base16, (size_t)2 * TABLE_BASE16_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&e->comb, TABLE_COMB_ENTRIES * TABLE_ENTRY_WORDS * sizeof(uint32_t)));
     TRY(hipMalloc((void **)&e->comb_img, COMB_IMG_WORDS * sizeof(uint32_t)));
+    TRY(hipHostMalloc((void **)&e->status, 64, hipHostMallocDefault));
+    memset(e->status, 0, 64);
     for (int i = 0; i < VERIFY_SLOTS; i++) {
         /* highest queue priority for the side streams: their few workgroups must be dispatched while
          * k_verify_main still has thousands waiting, not after them */
         int lo = 0, hi = 0;
         struct vslot *v = &e->vs[i];
+        v->ws.status = e->status;
         TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
         TRY(hipStreamCreateWithPriority(&v->ws.side, hipStreamNonBlocking, hi));
         TRY(hipEventCreateWithFlags(&v->ws.ev_prepared, hipEventDisableTiming));
@@ -414,6 +419,25 @@ int eddsa_amd_debug_hip_calls(void)
     return edk_debug_fail_in(-1);
 }
 
+int eddsa_amd_debug_withhold_handoff(int tile_plus_1)
+{
+    struct call c;
+    int rc;
+    if (!__atomic_load_n(&g_hooks_armed, __ATOMIC_ACQUIRE)) return EDDSA_AMD_HOOKS_OFF;
+    if ((rc = enter(&c, -1))) return rc;
+    pthread_mutex_lock(&c.e->lk);
+    TRY(hipDeviceSynchronize());
+    for (int i = 0; i < VERIFY_SLOTS; i++) {
+        const uint32_t w = tile_plus_1 > 0 ? (uint32_t)tile_plus_1 : 0u;
+        if (!c.e->vs[i].ws.offcount) continue;
+        TRY(hipMemcpy(c.e->vs[i].ws.offcount + EDK_WITHHOLD_WORD, &w, sizeof(w), hipMemcpyHostToDevice));
+    }
+out:
+    pthread_mutex_unlock(&c.e->lk);
+    leave(&c);
+    return rc;
+}
+
 int eddsa_amd_dump_tables(uint32_t *base16_words, uint32_t *comb_words)
 {
     struct call c;
@@ -529,11 +553,17 @@ static void slot_quiesce(struct vslot *v, hipStream_t st)
     HIP_NOTE(hipEventRecord(v->free, st));
 }
 
+int take_async_error(struct engine *e)
+{
+    return __atomic_exchange_n(e->status, 0u, __ATOMIC_ACQ_REL) == EDK_STATUS_STALLED ? EDDSA_AMD_STALLED : 0;
+}
+
 /* both verify forms: chunks of at most CHUNK_MAX items through the workspace */
 int verify_on(struct engine *e, uint8_t *ok, const edk_verify_src *all, size_t n, hipStream_t st, hipEvent_t bulk_done, int bulk_early)
 {
     int rc = 0;
     if (n == 0) return 0;
+    if ((rc = take_async_error(e))) return rc;   /* an earlier pass's kernels gave up: see engine.h */
     pthread_mutex_lock(&e->lk);
     struct vslot *v = ws_pick(e, st);
     rc = ws_reserve(v, n < CHUNK_MAX ? n : CHUNK_MAX);
@@ -670,6 +700,7 @@ int rlc_on(struct engine *e, uint8_t *ok, uint32_t *stats, const edk_verify_src 
         if (!rc) { hipError_t er = edk_rlc_note_per_item(stats, n, st); if (er != hipSuccess) rc = -(int)er; }
         return rc;
     }
+    if ((rc = take_async_error(e))) return rc;
     /* The combination's group verdicts are read by the host, once per pass.  The wait for the stream happens OUTSIDE
      * e->lk (other threads keep enqueueing on this engine meanwhile); the workspace slot stays reserved through its
      * busy mark, which ws_pick honours. */

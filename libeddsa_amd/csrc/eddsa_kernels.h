@@ -26,6 +26,10 @@
 #define EDK_REFUSED_WORD 8
 #define EDK_ONLIST_WORD 1           /* word of edk_verify_ws.offcount: the length of onlist */
 #define EDK_EXACT_UNIT_WORD 2        /* word of edk_verify_ws.offcount: the next unit of work of k_verify_exact_lane_chain */
+#define EDK_STALL_WORD 3             /* ... set by a wave of that kernel that gave up waiting for a hand-off: the others then leave too */
+#define EDK_PASS_WORDS 4             /* words 0..3 are zeroed by every pass */
+#define EDK_WITHHOLD_WORD 9          /* test hook (eddsa_amd_debug_withhold_handoff): tile + 1 whose first hand-off is never published; 0: none */
+#define EDK_EXACT_PATIENCE (1u << 21) /* polls (a microsecond or two each) a wave of k_verify_exact_lane_chain spends on one hand-off */
 #define EDK_BENTRY_WORD 32          /* words 32..63 of edk_verify_ws.offcount: the base point as a packed cached entry (lanes.h: exact_bentry_store) */
 #define ACC_WORDS 40               /* point workspace per item: X, Y, Z and one slot for the finish kernels' prefix products */
 
@@ -37,6 +41,7 @@ hipError_t edk_init_tables(uint32_t* base16, uint32_t* comb, uint32_t* comb_img,
 
 #define EDK_SUMS_MAX_ITEMS ((size_t)1 << 11)          /* passes of up to this many items add their windows' sums first (kernels.hip: k_verify_window_sums) */
 #define EDK_SUMS_BYTES (EDK_SUMS_MAX_ITEMS * 64 * 40 * sizeof(uint32_t))   /* 64 windows x four multipliers of ten limbs per item */
+#define EDK_STATUS_STALLED 1u
 #define EDK_EXACT_SLOTS 65536                        /* items k_verify_exact_quad has in flight at once (4096 waves of 16); a longer work list is walked in strides of this */
 #define EDK_EXACT_PAD_BYTES ((size_t)EDK_EXACT_SLOTS * 960)   /* per slot: four addends x five factors x 12 words (quad_lanes.h: QUAD_ITEM_WORDS) */
 
@@ -54,11 +59,14 @@ typedef struct edk_verify_ws {
                          k_verify_halve / k_verify_main_half run over this list */
   uint32_t* perm;     /* capacity words: ragged passes: the items in order of message length (kernels.hip: msg_order) */
   uint32_t* lenbins;  /* 2 * EDK_LEN_BINS words: that sort's counts and cursors */
-  uint32_t* offcount; /* 64 words, zeroed at allocation: [0] the length of offlist, [EDK_ONLIST_WORD] the length of onlist, [EDK_EXACT_UNIT_WORD]
-                         (all three zeroed by every pass), [EDK_REFUSED_WORD] half-length pairs that the exact check of lanes.h: verify_half_scalars_lane
-                         refused since allocation (diagnostic), [EDK_BENTRY_WORD..] the shared entry of the one-lane exact path */
+  uint32_t* offcount; /* 64 words, zeroed at allocation: [0] the length of offlist, [EDK_ONLIST_WORD] the length of onlist, [EDK_EXACT_UNIT_WORD],
+                         [EDK_STALL_WORD] (all four zeroed by every pass), [EDK_REFUSED_WORD] half-length pairs that the exact check of lanes.h:
+                         verify_half_scalars_lane refused since allocation (diagnostic), [EDK_WITHHOLD_WORD] (test hook), [EDK_BENTRY_WORD..] the
+                         shared entry of the one-lane exact path */
   uint32_t* exact_pad;/* EDK_EXACT_PAD_BYTES: scratchpad of k_verify_exact_quad: the addends of the items in flight, one slot per quad */
   uint32_t* sums;     /* EDK_SUMS_BYTES: the windows' sums of a small pass */
+  uint32_t* status;   /* one word of page-locked host memory shared by the engine's workspaces (or NULL): a kernel that had to give up
+                         stores EDK_STATUS_STALLED there; the host side turns it into EDDSA_AMD_STALLED (eddsa_amd.c: take_async_error) */
   hipStream_t side;   /* the exact path runs here, beside the main kernel */
   hipEvent_t ev_prepared, ev_exact;
   int algo;           /* 0: half-length scalars (four lanes per item up to 24 576 items, one above); 1: always full-length; 2: half-length, one lane per item; 3: the mid-size arrangement below 2^18 items */

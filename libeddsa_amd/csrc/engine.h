@@ -123,6 +123,7 @@ struct engine {
     pthread_cond_t slot_cv;            /* signalled (under lk) when a busy workspace slot is released */
     uint32_t *base16, *comb;           /* generated base-point tables (HBM) */
     uint32_t *comb_img;                /* the comb as the point kernels stage it in LDS (lanes.h: comb_select) */
+    uint32_t *status;                  /* page-locked host word the kernels report through (edk_verify_ws.status); read with take_async_error */
     struct vslot vs[VERIFY_SLOTS];
     unsigned long clock;
     int marks_used;                   /* passes recorded since profiling was switched on */
@@ -161,6 +162,11 @@ void leave(struct call *c);
 
 /* device buffers that held secrets (or may have) are zeroed before they go back to the allocator */
 void wipe_free(void *p, size_t bytes);
+/* What a kernel of an earlier or (after the stream was waited for) of this pass reported through e->status: 0, or
+ * EDDSA_AMD_STALLED once per report.  Host-pointer calls ask after their last wait, so the call that stalled is the one that
+ * fails; device-pointer calls return before their kernels run, so there the NEXT verify call on the engine fails in
+ * its place (it is not run), as a sticky HIP error would surface. */
+int take_async_error(struct engine *e);
 
 /* device-pointer work on one engine (the engine's device is current); all asynchronous on `st` except rlc_on,
  * which waits for the stream once per pass */

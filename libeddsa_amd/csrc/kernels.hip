@@ -333,7 +333,7 @@ k_verify_exact_lane_setup(const uint32_t* digits, uint32_t* table, uint32_t* rta
 __global__ void __launch_bounds__(BLOCK, 2)
 k_verify_exact_lane_chain(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const uint32_t* table, uint32_t* rtable,
                           const uint32_t* offlist, uint32_t* offcount, uint32_t* tile_done, uint32_t min_listed, size_t n,
-                          uint32_t main_cost, int main_all) {
+                          uint32_t main_cost, int main_all, uint32_t* status) {
   const size_t listed = *offcount;
   if (listed < min_listed) return;
   // a tile is 128 entries of the list: a lane walks TWO chains, entries L and 64 + L of the tile (lanes.h: exact_pair_iterations)
@@ -363,15 +363,38 @@ k_verify_exact_lane_chain(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, c
   if ((blockIdx.x * (unsigned)BLOCK + threadIdx.x) / 64u >= waves) return;
   for (;;) {
     unsigned u = 0;
-    if (lane == 0) u = atomicAdd(offcount + EDK_EXACT_UNIT_WORD, 1u);
+    if (lane == 0)
+      u = __hip_atomic_load(offcount + EDK_STALL_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? units
+                                                                                                        : atomicAdd(offcount + EDK_EXACT_UNIT_WORD, 1u);
     u = (unsigned)__builtin_amdgcn_readfirstlane((int)u);
     if (u >= units) break;
     const unsigned seg = u / tiles, tile = u - seg * tiles;
     if (seg > 0) {
       // the tile's previous stretch, possibly on another CU: its stores are in L2 once its count is; the acquire drops this
-      // CU's stale lines
-      if (lane == 0)
-        while (__hip_atomic_load(tile_done + tile, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seg) __builtin_amdgcn_s_sleep(16);
+      // CU's stale lines.
+      // Why the wait ends: units are drawn in order from ONE counter - stretch s - 1 of every tile before stretch s of any -
+      // so the unit waited for was drawn earlier, by a wave that is resident (a wave draws only while it runs) and that
+      // itself waits, if at all, for a unit drawn earlier still: the oldest unit in flight waits for nothing.
+      // Why it is bounded all the same: if that wave never publishes (a fault in it; the test hook below), spinning for
+      // ever would turn one lost hand-off into a hung queue.  After EDK_EXACT_PATIENCE polls - seconds, where a stretch
+      // takes a millisecond - the wave raises EDK_STALL_WORD and leaves; every wave looks at that word before it draws or
+      // while it waits, so the launch drains, and the host side returns EDDSA_AMD_STALLED for the pass.
+      uint32_t stalled = 0;
+      if (lane == 0) {
+        uint32_t polls = 0;
+        while (__hip_atomic_load(tile_done + tile, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seg) {
+          if (++polls == EDK_EXACT_PATIENCE || __hip_atomic_load(offcount + EDK_STALL_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            stalled = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(16);
+        }
+        if (stalled) {
+          __hip_atomic_store(offcount + EDK_STALL_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (status) __hip_atomic_store(status, EDK_STATUS_STALLED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+      if (__builtin_amdgcn_readfirstlane((int)stalled)) break;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     const size_t ga = (size_t)tile * 128 + lane, gb = ga + 64;
@@ -404,7 +427,9 @@ k_verify_exact_lane_chain(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, c
       if (live_a) exact_walk_store(rtable + (size_t)ia * SLOT + EXACT_STATE_AT, ra, wa);
       if (live_b) exact_walk_store(rtable + (size_t)ib * SLOT + EXACT_STATE_AT, rb, wb);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");         // every lane's accumulators are out before the count says so
-      if (lane == 0) __hip_atomic_fetch_add(tile_done + tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      // (test hook: the first hand-off of tile EDK_WITHHOLD_WORD - 1 is never published; the word is 0 unless a test set it)
+      if (lane == 0 && !(seg == 0 && offcount[EDK_WITHHOLD_WORD] == tile + 1u))
+        __hip_atomic_fetch_add(tile_done + tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -1189,7 +1214,7 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
   const edk_verify_src src = *srcp;
   if (n == 0) return hipSuccess;
   const unsigned blocks = (unsigned)((n + BLOCK - 1) / BLOCK);
-  EDK_DO(hipMemsetAsync(ws->offcount, 0, 3 * sizeof(uint32_t), stream));   // both work lists' lengths and the one-lane exact path's unit counter
+  EDK_DO(hipMemsetAsync(ws->offcount, 0, EDK_PASS_WORDS * sizeof(uint32_t), stream));   // both work lists' lengths, the one-lane exact path's unit counter and its stall flag
   if (marks) EDK_DO(hipEventRecord(marks[0], stream));
   // algo 0: half-length scalars - the three-lane preparation and four lanes per item up to 24 576 items, the same preparation and one lane per item up to 2^18, one lane per item above;
   // 3: the mid-size arrangement at any size below 2^18;
@@ -1254,7 +1279,7 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
       // full-length one over the whole pass, 323 k: profiles/pmc_summary.json)
       const bool half_main = half || pair_one;
       EDK_LAUNCH(k_verify_exact_lane_chain, dim3(lane_blocks), dim3(BLOCK), 0, ws->side, ok, src.sigs, src.sig_stride, ws->table, ws->rtable,
-                 ws->offlist, ws->offcount, ws->exact_pad, lane_min, n, half_main ? 226u : 323u, half_main ? 0 : 1);
+                 ws->offlist, ws->offcount, ws->exact_pad, lane_min, n, half_main ? 226u : 323u, half_main ? 0 : 1, ws->status);
     }
     {
       // one launch: a list it would serve has fewer entries than the scratchpad has slots (lane_min != 0: fewer than lane_min;

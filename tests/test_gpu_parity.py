@@ -252,6 +252,77 @@ def test_every_route_with_two_thirds_of_the_keys_random(engine, oracle):
         engine.set_verify_algo(0)
 
 
+def test_a_lost_hand_off_between_the_chain_s_waves_is_an_error_not_a_hang(engine, oracle):
+    """The waves of k_verify_exact_lane_chain hand a tile's accumulators to one another through memory, and a wave that drew
+    stretch s waits for stretch s - 1.  The wait is bounded: with the test hook withholding the first hand-off of tile 0, the
+    wave that waits for it gives up after its bound (seconds), the launch drains, and the pass comes back as
+    EDDSA_AMD_STALLED - through the host-pointer call that ran it, and through the NEXT device-pointer call after one whose
+    kernels stalled (that call had returned before its kernels ran).  Afterwards the engine serves the same pass correctly."""
+    import torch
+    import workload
+    n = 1 << 16
+    sk, msg = workload.sign_inputs(n, seed=21, config=2)
+    pk = engine.ed25519_genpub_batch(dev(sk))
+    sig = engine.ed25519_sign_batch(dev(sk), pk, dev(msg)).cpu().numpy()
+    keys = pk.cpu().numpy().copy()
+    keys[::2] = np.random.default_rng(21).integers(0, 256, (n // 2, 32), dtype=np.uint8)     # ~15 000 keys off the curve: the one-lane form
+    want = oracle.verify_batch(sig, keys, msg, 32)
+    assert np.array_equal(engine.ed25519_verify_batch(dev(sig), dev(keys), dev(msg)).cpu().numpy(), want)   # (allocates the workspace)
+    assert engine.debug_withhold_handoff(1) == engine.HOOKS_OFF                                # inert until armed
+    engine.debug_init(0, True)
+    try:
+        assert engine.debug_withhold_handoff(1) == 0
+        with pytest.raises(engine.EddsaAmdError) as err:
+            engine.ed25519_verify_batch(sig, keys, msg)                                          # host pointers: this call reports it
+        assert f"rc={engine.STALLED}" in str(err.value)
+        engine.ed25519_verify_batch(dev(sig), dev(keys), dev(msg))                              # device pointers: returns before its kernels give up
+        torch.cuda.synchronize()
+        assert engine.debug_withhold_handoff(0) == 0
+        with pytest.raises(engine.EddsaAmdError) as err:
+            engine.ed25519_verify_batch(dev(sig), dev(keys), dev(msg))                          # ... so the next call carries the report
+        assert f"rc={engine.STALLED}" in str(err.value)
+    finally:
+        engine.debug_withhold_handoff(0)
+        engine.debug_init(0, False)
+    assert np.array_equal(engine.ed25519_verify_batch(dev(sig), dev(keys), dev(msg)).cpu().numpy(), want)
+    assert np.array_equal(engine.ed25519_verify_batch(sig, keys, msg), want)
+
+
+def test_the_hand_off_under_concurrency(engine, oracle):
+    """a short run of tools/exact_soak.py inside the suite: the passes "every second key random" and "just above the
+    threshold of the one-lane form" from two host threads on two streams at once, 12 times each - every verdict vector
+    equal to the oracle's"""
+    import threading
+    import torch
+    import workload
+    n = 1 << 18
+    sk, msg = workload.sign_inputs(n, seed=22, config=2)
+    pk = engine.ed25519_genpub_batch(dev(sk))
+    sig = engine.ed25519_sign_batch(dev(sk), pk, dev(msg))
+    dm = dev(msg)
+    garbage = np.random.default_rng(22).integers(0, 256, (n, 32), dtype=np.uint8)
+    cases = {}
+    for tag, sel in (("every second", slice(0, n, 2)), ("just above the threshold", slice(0, 20000))):
+        keys = pk.cpu().numpy().copy()
+        keys[sel] = garbage[sel]
+        cases[tag] = (dev(keys), torch.from_numpy(oracle.verify_batch(sig.cpu().numpy(), keys, msg, 32)).cuda())
+    errs = []
+
+    def worker(tag):
+        keys, want = cases[tag]
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            for r in range(12):
+                ok = engine.ed25519_verify_batch(sig, keys, dm)
+                s.synchronize()
+                if not torch.equal(ok, want):
+                    errs.append((tag, r, int((ok != want).sum())))
+    ts = [threading.Thread(target=worker, args=(t,)) for t in cases]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not errs, errs[:5]
+
+
 def test_every_item_through_the_reference_order_kernels(engine):
     """self-check mode 2: all 70 000 items (more than the 65 536 the setup/chain kernels take, so the
     strided k_verify_exact runs too) are decided by the replay of the reference's JSF/Shamir chain;

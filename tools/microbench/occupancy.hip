@@ -10,11 +10,11 @@ template <int LDS, int VG> __global__ void __launch_bounds__(64, 2) k(int* out) 
 }
 template <int LDS, int VG> void probe() {
   int n = 0;
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k<LDS, VG>, 64, 0);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k<LDS, VG>, 64, 0);
   printf("LDS %6d B  vgpr %s  -> %d blocks per CU\n", LDS, VG > 128 ? ">128" : "small", n);
 }
 int main() {
-  hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+  hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0);
   printf("%s: sharedMemPerMultiprocessor %zu, maxSharedMemoryPerBlock %zu, regsPerMultiprocessor %d\n", p.gcnArchName, p.maxSharedMemoryPerMultiProcessor, p.sharedMemPerBlock, p.regsPerMultiprocessor);
   probe<16384, 189>(); probe<17408, 189>(); probe<18176, 189>(); probe<18484, 189>(); probe<19456, 189>(); probe<20480, 189>(); probe<18484, 64>(); probe<8192, 189>(); probe<8192, 64>();
   return 0;

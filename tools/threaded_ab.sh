@@ -11,8 +11,10 @@ def golden_msg(i):
     return out[:i]
 open("/tmp/msgs.bin","wb").write(b"".join(golden_msg(i) for i in range(1024)))
 PY
-gcc -std=c11 -O1 -pthread -Iinclude tests/c/threaded_callers.c -Llibeddsa_amd -leddsa_amd -Wl,-rpath,$PWD/libeddsa_amd -o /tmp/threaded_callers
+# the program binds libeddsa.so.0 (the SONAME); each variant gets a directory of its own with that name in it - the product library is not touched
+gcc -std=c11 -O1 -pthread -Iinclude tests/c/threaded_callers.c -Llibeddsa_amd -leddsa_amd -o /tmp/threaded_callers
 for rep in 1 2; do for so in "$@"; do
-  cp $so libeddsa_amd/libeddsa_amd.so; echo "== $so"
-  for t in 8 32 64 128 256 512; do /tmp/threaded_callers tests/golden/ed25519_table.bin /tmp/msgs.bin tests/golden/x25519_table.bin $t 200 48 | grep -v "one caller\|: ok"; done
+  d=$(mktemp -d); cp "$so" "$d/libeddsa.so.0"; echo "== $so"
+  for t in 8 32 64 128 256 512; do LD_LIBRARY_PATH="$d" /tmp/threaded_callers tests/golden/ed25519_table.bin /tmp/msgs.bin tests/golden/x25519_table.bin $t 200 48 | grep -v "one caller\|: ok"; done
+  rm -rf "$d"
 done; done
