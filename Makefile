@@ -14,8 +14,12 @@ HIPFLAGS := -O3 --offload-arch=$(ARCH) -fPIC -fvisibility=hidden -DEDDSA_BUILD -
 CFLAGS   := -std=c11 -O2 -fPIC -fvisibility=hidden -Wall -Wextra -DEDDSA_BUILD -Iinclude -I$(CSRC) -I$(ROCM)/include
 
 PROBE   := libeddsa_amd/libeddsa_amd_probe.so
+# The same objects plus the test and measurement hooks of include/eddsa_amd_debug.h (-DEDDSA_AMD_DEBUG_BUILD compiles them into
+# the two host files; the kernels are the SAME object files): what the tests, bench.py and tools/ load.  $(LIB) exports the
+# reference's 13 names and the batched set of include/eddsa_amd.h, nothing else (tests/test_abi_and_host.py).
+DEBUGLIB := libeddsa_amd/libeddsa_amd_debug.so
 
-all: $(LIB) $(PROBE) oracle
+all: $(LIB) $(DEBUGLIB) $(PROBE) oracle
 
 $(BUILD)/kernels.o: $(CSRC)/kernels.hip $(wildcard $(CSRC)/*.h)
 	@mkdir -p $(BUILD)
@@ -24,6 +28,13 @@ $(BUILD)/kernels.o: $(CSRC)/kernels.hip $(wildcard $(CSRC)/*.h)
 $(BUILD)/%.o: $(CSRC)/%.c $(CSRC)/engine.h $(CSRC)/eddsa_kernels.h include/eddsa.h include/eddsa_amd.h
 	@mkdir -p $(BUILD)
 	$(CC) $(CFLAGS) -c $< -o $@
+
+$(BUILD)/%.dbg.o: $(CSRC)/%.c $(CSRC)/engine.h $(CSRC)/eddsa_kernels.h include/eddsa.h include/eddsa_amd.h include/eddsa_amd_debug.h
+	@mkdir -p $(BUILD)
+	$(CC) $(CFLAGS) -DEDDSA_AMD_DEBUG_BUILD -c $< -o $@
+
+$(DEBUGLIB): $(BUILD)/kernels.o $(BUILD)/rlc.o $(BUILD)/eddsa_amd.dbg.o $(BUILD)/host_pipe.dbg.o
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -Wl,-soname,libeddsa_amd_debug.so -o $@ $^ -lpthread -ldl
 
 # SONAME = the reference's (libeddsa.so.0, reference lib/CMakeLists.txt:43-44): a program linked against
 # the reference loads this library through the libeddsa.so.0 link without being relinked.
@@ -49,7 +60,7 @@ microbench:
 	$(HIPCC) -O3 --offload-arch=$(ARCH) -I$(CSRC) tools/microbench/fe_rates.hip -o tools/microbench/fe_rates.bin
 
 clean:
-	rm -rf $(BUILD) $(LIB) $(PROBE) libeddsa_amd/libeddsa.so.0
+	rm -rf $(BUILD) $(LIB) $(DEBUGLIB) $(PROBE) libeddsa_amd/libeddsa.so.0
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle probe microbench clean

@@ -53,6 +53,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import libeddsa_amd as ed  # noqa: E402
 import workload  # noqa: E402
+ed.use_debug_library()   # libeddsa_amd_debug.so = the product's object files (the same kernels) plus the hooks this harness reads: phase timings, route selection
 
 # canonical 32x32->64 multiply counts per item (BASELINE.md "Work per item")
 MUL32_VERIFY = 312370

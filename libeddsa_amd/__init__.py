@@ -48,6 +48,7 @@ from .api import (  # noqa: F401
     init,
     library,
     library_path,
+    use_debug_library,
     pk_ed25519_to_x25519,
     pk_ed25519_to_x25519_batch,
     sk_ed25519_to_x25519,

@@ -23,10 +23,26 @@ class EddsaAmdError(RuntimeError):
     """A HIP call behind the engine failed (or the engine library is missing)."""
 
 
+_PATH = None
+
+
 def library_path():
-    """The in-tree build; EDDSA_AMD_LIBRARY names another build of the same sources instead (tools/ab.sh: A/B measurements
-    load their variants this way and never overwrite the product library)."""
-    return os.environ.get("EDDSA_AMD_LIBRARY") or os.path.join(_HERE, "libeddsa_amd.so")
+    """The in-tree product build, libeddsa_amd.so - unless use_debug_library() chose the debug build, or EDDSA_AMD_LIBRARY
+    names another build of the same sources (tools/ab.sh: A/B measurements load their variants this way and never
+    overwrite the product library)."""
+    return os.environ.get("EDDSA_AMD_LIBRARY") or _PATH or os.path.join(_HERE, "libeddsa_amd.so")
+
+
+def use_debug_library():
+    """Bind libeddsa_amd_debug.so instead: the product's object files plus the test and measurement hooks of
+    include/eddsa_amd_debug.h (route selection, phase timings, fault injectors, traces), which the shipped library does not
+    export.  The tests, bench.py and the scripts under tools/ call this before their first call; a process holds ONE engine
+    library, so it must come before anything has loaded the product build."""
+    global _PATH
+    path = os.path.join(_HERE, "libeddsa_amd_debug.so")
+    if _LIB is not None and library_path() != path:
+        raise EddsaAmdError(f"use_debug_library(): {library_path()} is already loaded in this process")
+    _PATH = path
 
 
 def _share_the_hip_runtime_with_torch():
@@ -63,6 +79,8 @@ def library():
                 "there is no CPU fallback")
         _share_the_hip_runtime_with_torch()
         lib = ctypes.CDLL(path)
+        global _PATH
+        _PATH = _PATH or path                                          # (what is loaded stays loaded)
         lib.eddsa_amd_strerror.restype = ctypes.c_char_p
         lib.ed25519_verify.restype = ctypes.c_bool
         lib.eddsa_verify.restype = ctypes.c_bool
@@ -101,23 +119,32 @@ LAYER_OPS = {"fe_mul": 1, "fe_sq": 2, "fe_inv": 3, "fe_pow2523": 4, "fe_mul_loos
              "sc_muladd": 8, "sha512": 9, "ed_import_export": 10, "ed_scale_base": 11, "ed_dual_scale": 12, "ge_dbl_add": 13}
 
 
+def _hooks():
+    """the loaded library, which must be the debug build (use_debug_library): the shipped one exports no hook"""
+    lib = library()
+    if not hasattr(lib, "eddsa_amd_debug_init"):
+        raise EddsaAmdError(f"{library_path()} has no test hooks: call libeddsa_amd.use_debug_library() before the first "
+                            "call (or point EDDSA_AMD_LIBRARY at libeddsa_amd_debug.so)")
+    return lib
+
+
 def debug_init(device=0, hooks=True):
     """eddsa_amd_init(device), then arm (or disarm) the fault injectors"""
-    _check(library().eddsa_amd_debug_init(int(device), ctypes.c_uint(1 if hooks else 0)), "eddsa_amd_debug_init")
+    _check(_hooks().eddsa_amd_debug_init(int(device), ctypes.c_uint(1 if hooks else 0)), "eddsa_amd_debug_init")
 
 
 def debug_fail_next_host_call():
     """the next host-pointer call fails after its kernels were launched; returns HOOKS_OFF when the hooks are not armed"""
-    return int(library().eddsa_amd_debug_fail_next_host_call())
+    return int(_hooks().eddsa_amd_debug_fail_next_host_call())
 
 
 def debug_fail_hip_call(nth):
     """the nth checked HIP call of the verify passes from now on fails (0 disarms); HOOKS_OFF when not armed"""
-    return int(library().eddsa_amd_debug_fail_hip_call(int(nth)))
+    return int(_hooks().eddsa_amd_debug_fail_hip_call(int(nth)))
 
 
 def debug_hip_calls():
-    return int(library().eddsa_amd_debug_hip_calls())
+    return int(_hooks().eddsa_amd_debug_hip_calls())
 
 
 STALLED = -100003
@@ -126,13 +153,13 @@ STALLED = -100003
 def debug_withhold_handoff(tile_plus_1):
     """the first hand-off of that tile of k_verify_exact_lane_chain is never published in the passes that follow (0: off);
     HOOKS_OFF when not armed"""
-    return int(library().eddsa_amd_debug_withhold_handoff(int(tile_plus_1)))
+    return int(_hooks().eddsa_amd_debug_withhold_handoff(int(tile_plus_1)))
 
 
 def debug_teardown_errors():
     """(count, first hipError_t) of the HIP calls that failed on teardown / clean-up paths since the library was loaded"""
     first = ctypes.c_int(0)
-    return int(library().eddsa_amd_debug_teardown_errors(ctypes.byref(first))), int(first.value)
+    return int(_hooks().eddsa_amd_debug_teardown_errors(ctypes.byref(first))), int(first.value)
 
 
 _PROBE = None
@@ -169,7 +196,7 @@ def verify_phase_ms():
     """(prepare, main, finish) kernel durations in ms of the last profiled verify pass, measured
     with HIP events on the launch stream (enable with set_profiling(True))."""
     out = (ctypes.c_float * 3)()
-    _check(library().eddsa_amd_verify_phase_ms(out), "eddsa_amd_verify_phase_ms")
+    _check(_hooks().eddsa_amd_verify_phase_ms(out), "eddsa_amd_verify_phase_ms")
     return tuple(out)
 
 
@@ -184,7 +211,7 @@ def set_verify_algo(algo=0):
     """0 (default): half-length scalars (four lanes per item up to 24 576 items, one above); 1: always full-length;
     2: half-length with one lane per item whatever the size; 3: the arrangement of 24 577 .. 2^18 items (three-lane
     preparation, one-lane evaluation) at any size below 2^18.  Same verdicts; a measurement and test aid."""
-    library().eddsa_amd_set_verify_algo(int(algo))
+    _hooks().eddsa_amd_set_verify_algo(int(algo))
 
 
 def debug_halve(ts, wide=False):
@@ -205,7 +232,7 @@ def debug_halve(ts, wide=False):
 def halve_rejected():
     """diagnostic: half-length pairs refused by the exact integer check on the default device (expected 0)"""
     out = ctypes.c_uint64(0)
-    _check(library().eddsa_amd_halve_rejected(ctypes.byref(out)), "eddsa_amd_halve_rejected")
+    _check(_hooks().eddsa_amd_halve_rejected(ctypes.byref(out)), "eddsa_amd_halve_rejected")
     return int(out.value)
 
 
@@ -223,7 +250,7 @@ def set_host_threads(n):
 def combiner_stats():
     """(launches, calls they carried) of the combiner of small host-pointer calls on the default device"""
     out = (ctypes.c_uint64 * 2)()
-    _check(library().eddsa_amd_combiner_stats(out), "eddsa_amd_combiner_stats")
+    _check(_hooks().eddsa_amd_combiner_stats(out), "eddsa_amd_combiner_stats")
     return int(out[0]), int(out[1])
 
 
@@ -253,14 +280,14 @@ def host_free(a):
 
 
 def set_profiling(on):
-    library().eddsa_amd_set_profiling(int(bool(on)))
+    _hooks().eddsa_amd_set_profiling(int(bool(on)))
 
 
 def secret_residue():
     """(aux, acc, staging-in, staging-out): non-zero bytes left in the engine's secret-bearing HBM
     buffers on the default device (diagnostic for the hygiene tests; waits for the device)."""
     out = (ctypes.c_uint64 * 4)()
-    _check(library().eddsa_amd_secret_residue(out), "eddsa_amd_secret_residue")
+    _check(_hooks().eddsa_amd_secret_residue(out), "eddsa_amd_secret_residue")
     return tuple(int(x) for x in out)
 
 

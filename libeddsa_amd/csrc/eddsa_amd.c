@@ -62,11 +62,13 @@ void hip_forget_error(void)
     (void)hipGetLastError();               /* the caller has handled the answer it stands for */
 }
 
+#ifdef EDDSA_AMD_DEBUG_BUILD   /* include/eddsa_amd_debug.h: only libeddsa_amd_debug.so has it */
 int eddsa_amd_debug_teardown_errors(int *first_hip_error)
 {
     if (first_hip_error) *first_hip_error = __atomic_load_n(&g_teardown.first, __ATOMIC_ACQUIRE);
     return __atomic_load_n(&g_teardown.count, __ATOMIC_ACQUIRE);
 }
+#endif
 
 /* ------------------------------------------------------------------------------------------
  * engines
@@ -397,6 +399,7 @@ void eddsa_amd_shutdown(void)
  * the test surface (include/eddsa_amd_debug.h): inert unless armed
  * ---------------------------------------------------------------------------------------- */
 
+#ifdef EDDSA_AMD_DEBUG_BUILD   /* include/eddsa_amd_debug.h: only libeddsa_amd_debug.so has it */
 int eddsa_amd_debug_init(int device, unsigned flags)
 {
     const int rc = eddsa_amd_init(device);
@@ -406,19 +409,25 @@ int eddsa_amd_debug_init(int device, unsigned flags)
     if (!(flags & EDDSA_AMD_TEST_HOOKS)) (void)edk_debug_fail_in(0);
     return 0;
 }
+#endif
 
+#ifdef EDDSA_AMD_DEBUG_BUILD   /* include/eddsa_amd_debug.h: only libeddsa_amd_debug.so has it */
 int eddsa_amd_debug_fail_hip_call(int nth)
 {
     if (!__atomic_load_n(&g_hooks_armed, __ATOMIC_ACQUIRE)) return EDDSA_AMD_HOOKS_OFF;
     (void)edk_debug_fail_in(nth < 0 ? 0 : nth);
     return 0;
 }
+#endif
 
+#ifdef EDDSA_AMD_DEBUG_BUILD   /* include/eddsa_amd_debug.h: only libeddsa_amd_debug.so has it */
 int eddsa_amd_debug_hip_calls(void)
 {
     return edk_debug_fail_in(-1);
 }
+#endif
 
+#ifdef EDDSA_AMD_DEBUG_BUILD   /* include/eddsa_amd_debug.h: only libeddsa_amd_debug.so has it */
 int eddsa_amd_debug_withhold_handoff(int tile_plus_1)
 {
     struct call c;
@@ -437,7 +446,9 @@ out:
     leave(&c);
     return rc;
 }
+#endif
 
+#ifdef EDDSA_AMD_DEBUG_BUILD   /* include/eddsa_amd_debug.h: only libeddsa_amd_debug.so has it */
 int eddsa_amd_dump_tables(uint32_t *base16_words, uint32_t *comb_words)
 {
     struct call c;
@@ -449,19 +460,23 @@ out:
     leave(&c);
     return rc;
 }
+#endif
 
 /* Which evaluation ed25519_verify* uses (same verdicts; a measurement and test aid).  0 (default): half-length
  * scalars (csrc/halve.h), four lanes per item up to 2^15 items and one above; 1: full-length windows always;
  * 2: half-length scalars with one lane per item always. */
+#ifdef EDDSA_AMD_DEBUG_BUILD   /* include/eddsa_amd_debug.h: only libeddsa_amd_debug.so has it */
 void eddsa_amd_set_verify_algo(int algo)
 {
     pthread_rwlock_wrlock(&g_table);
     g_verify_algo = algo >= 1 && algo <= 3 ? algo : 0;
     pthread_rwlock_unlock(&g_table);
 }
+#endif
 
 /* diagnostic for the tests: how many half-length pairs the exact integer check (csrc/lanes.h: verify_half_scalars_lane)
  * has refused on the default device since its workspaces were allocated.  Waits for the device.  Expected: 0. */
+#ifdef EDDSA_AMD_DEBUG_BUILD   /* include/eddsa_amd_debug.h: only libeddsa_amd_debug.so has it */
 int eddsa_amd_halve_rejected(uint64_t *count)
 {
     struct call c;
@@ -481,6 +496,7 @@ out:
     leave(&c);
     return rc;
 }
+#endif
 
 /* How verify treats a public key that does not decode to a curve point (ed_import never fails,
  * reference lib/ed.c:100-149).  EXACT (default): such items are evaluated in the reference's own
@@ -507,6 +523,7 @@ void eddsa_amd_set_rlc_min_items(size_t items)
 
 /* per-kernel timing of the verify pass, for bench.py's roofline line: HIP events recorded on the
  * launch stream around k_verify_prepare / k_verify_main / k_verify_finish of every chunk */
+#ifdef EDDSA_AMD_DEBUG_BUILD   /* include/eddsa_amd_debug.h: only libeddsa_amd_debug.so has it */
 void eddsa_amd_set_profiling(int on)
 {
     pthread_rwlock_wrlock(&g_table);       /* no call in flight: nobody is bumping marks_used */
@@ -514,9 +531,11 @@ void eddsa_amd_set_profiling(int on)
     for (int d = 0; d < MAX_DEVICES; d++) if (g_eng[d]) g_eng[d]->marks_used = 0;
     pthread_rwlock_unlock(&g_table);
 }
+#endif
 
 /* average duration (ms) of each of the three kernels over the passes recorded on the default device
  * since profiling was switched on (at most MARK_SLOTS; later passes are not recorded) */
+#ifdef EDDSA_AMD_DEBUG_BUILD   /* include/eddsa_amd_debug.h: only libeddsa_amd_debug.so has it */
 int eddsa_amd_verify_phase_ms(float out[3])
 {
     struct call c;
@@ -539,6 +558,7 @@ out:
     leave(&c);
     return rc;
 }
+#endif
 
 /* ------------------------------------------------------------------------------------------
  * device-pointer work on one engine (the engine's device is current)
@@ -999,6 +1019,7 @@ out:
  * workspace `aux` (sign's a and r), out[1] the point workspace `acc` (x25519's (x2 : z2); public for
  * the other operations), out[2] the host pipeline's first input staging buffers (secret keys /
  * scalars), out[3] its output staging buffer.  Waits for the device to go idle first. */
+#ifdef EDDSA_AMD_DEBUG_BUILD   /* include/eddsa_amd_debug.h: only libeddsa_amd_debug.so has it */
 int eddsa_amd_secret_residue(uint64_t out[4])
 {
     struct call c;
@@ -1018,3 +1039,4 @@ out:
     leave(&c);
     return rc;
 }
+#endif

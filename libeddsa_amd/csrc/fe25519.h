@@ -37,11 +37,7 @@ namespace ed { static const uint64_t ed_opaque_zero = 0; }
 // Each fe_mul / fe_sq ends with a scheduling fence: without it hipcc interleaves independent
 // multiplications for ILP, which pushes the big kernels past 256 VGPRs into scratch spills;
 // two to four waves per SIMD already hide the dependent-issue latency (profiles/r01_fe_rates.txt).
-#ifdef ED_NO_FENCE
-#define ED_SCHED_FENCE() ((void)0)
-#else
 #define ED_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
 #define ED_CHECK(cond) ((void)0)
 #define ED_CONSTANT_MEM __device__ __constant__
 #define ED_ASSUME(cond) __builtin_assume(cond)

@@ -216,14 +216,17 @@ static int is_pinned(const void *p, size_t bytes)
 static size_t g_pipe_first, g_pipe_stage;   /* eddsa_amd_set_pipeline: 0 = the defaults above / the job's own stage size */
 static int g_pipe_chain = -1;               /* -1: the job's own; 0: the lanes' kernels run side by side; 1: in chunk order; 2: verify's next chunk starts beside the main kernel */
 
+#ifdef EDDSA_AMD_DEBUG_BUILD   /* include/eddsa_amd_debug.h: only libeddsa_amd_debug.so has it */
 void eddsa_amd_set_pipeline_chain(int mode)
 {
     pthread_rwlock_wrlock(&g_table);
     g_pipe_chain = mode;
     pthread_rwlock_unlock(&g_table);
 }
+#endif
 
 /* tuning: items of the first chunk of a host-pointer call and of its later stages (0 = default).  A measurement aid. */
+#ifdef EDDSA_AMD_DEBUG_BUILD   /* include/eddsa_amd_debug.h: only libeddsa_amd_debug.so has it */
 void eddsa_amd_set_pipeline(size_t first_chunk, size_t stage_chunk)
 {
     pthread_rwlock_wrlock(&g_table);
@@ -231,6 +234,7 @@ void eddsa_amd_set_pipeline(size_t first_chunk, size_t stage_chunk)
     g_pipe_stage = stage_chunk;
     pthread_rwlock_unlock(&g_table);
 }
+#endif
 
 enum { WIPE_NONE = 0, WIPE_IN0 = 1, WIPE_OUT = 2 };   /* which staging buffers held secrets */
 
@@ -448,6 +452,7 @@ static int64_t trace_now(void)
  * 4 download queued, 5 all lanes drained, 6 call end; of a combined launch also 7 leader elected, 8 callers gathered,
  * 9 requests packed, 10 results handed back), chunk index, milliseconds since the call started.  on = 2: recording stops
  * by itself after the 20th combined launch of 32 calls or more, so that a typical launch under load can be read */
+#ifdef EDDSA_AMD_DEBUG_BUILD   /* include/eddsa_amd_debug.h: only libeddsa_amd_debug.so has it */
 int eddsa_amd_debug_pipe_trace(int on, int *tags, unsigned *chunks, double *ms, int max)
 {
     pthread_rwlock_wrlock(&g_table);       /* no call in flight: nobody is stamping */
@@ -463,16 +468,19 @@ int eddsa_amd_debug_pipe_trace(int on, int *tags, unsigned *chunks, double *ms, 
     pthread_rwlock_unlock(&g_table);
     return n;
 }
+#endif
 
 /* test hook (inert unless armed, include/eddsa_amd_debug.h): the next host-pointer call fails (hipErrorUnknown) after its
  * inputs were staged and its kernels launched, so that the error path's clean-up (the staging copies of secrets are wiped
  * there too) can be exercised */
+#ifdef EDDSA_AMD_DEBUG_BUILD   /* include/eddsa_amd_debug.h: only libeddsa_amd_debug.so has it */
 int eddsa_amd_debug_fail_next_host_call(void)
 {
     if (!__atomic_load_n(&g_hooks_armed, __ATOMIC_ACQUIRE)) return EDDSA_AMD_HOOKS_OFF;
     __atomic_store_n(&g_fail_next_host_call, 1, __ATOMIC_RELEASE);
     return 0;
 }
+#endif
 
 /* One host-pointer job on engine e (its device is current).
  * Chunk k travels on lane k mod 3: [wait for the lane's previous chunk, fetch and deliver its results] - stage and
@@ -660,6 +668,7 @@ void combiner_release(struct combiner *q)
 }
 
 /* diagnostic: combined launches and the items they carried on the default device since its engine was built */
+#ifdef EDDSA_AMD_DEBUG_BUILD   /* include/eddsa_amd_debug.h: only libeddsa_amd_debug.so has it */
 int eddsa_amd_combiner_stats(uint64_t out[2])
 {
     struct call c;
@@ -671,6 +680,7 @@ int eddsa_amd_combiner_stats(uint64_t out[2])
     leave(&c);
     return 0;
 }
+#endif
 
 static int64_t now_ns(void)
 {

@@ -239,18 +239,9 @@ constexpr int QUAD_BLOCK = 256;                  // k_verify_main_quad
 constexpr int QUAD_CHAIN_BLOCK = 64;             // k_verify_exact_quad: one wave, up to 16 items
 constexpr int QUAD_CHAIN_ITEMS = QUAD_CHAIN_BLOCK / 4;
 constexpr int QUAD_SPREAD_WAVES = 256;           // a short work list is spread over this many waves, a long one packed 16 items to the wave
-#ifndef EXACT_DENSE_LOG2
-#define EXACT_DENSE_LOG2 16
-#endif
-constexpr size_t EXACT_DENSE_MIN_N = (size_t)1 << EXACT_DENSE_LOG2;   // passes from this size on pack the chain's items 16 to the wave whatever their number
-#ifndef EXACT_LANE_MIN_LOG2
-#define EXACT_LANE_MIN_LOG2 13
-#endif
-constexpr size_t EXACT_LANE_MIN_LISTED = (size_t)1 << EXACT_LANE_MIN_LOG2;   // work lists from this length on go to k_verify_exact_lane_* ...
-#ifndef EXACT_LANE_MIN_N_LOG2
-#define EXACT_LANE_MIN_N_LOG2 16
-#endif
-constexpr size_t EXACT_LANE_MIN_N = (size_t)1 << EXACT_LANE_MIN_N_LOG2;      // ... in passes of at least this many items
+constexpr size_t EXACT_DENSE_MIN_N = (size_t)1 << 16;   // passes from this size on pack the chain's items 16 to the wave whatever their number
+constexpr size_t EXACT_LANE_MIN_LISTED = (size_t)1 << 13;   // (the threshold's table: profiles/r05_exact_lane.txt, 5.) work lists from this length on go to k_verify_exact_lane_* ...
+constexpr size_t EXACT_LANE_MIN_N = (size_t)1 << 16;      // ... in passes of at least this many items
 static_assert((size_t)EDK_EXACT_SLOTS * QUAD_ITEM_WORDS * 4 <= EDK_EXACT_PAD_BYTES, "scratchpad too small");
 static_assert(EDK_EXACT_SLOTS % QUAD_CHAIN_ITEMS == 0, "whole waves");
 
@@ -310,9 +301,6 @@ k_verify_exact_quad(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, const u
 // every tile, stretch 1 of every tile, ..., so the wait is over before it starts unless the list is shorter than the chip).
 // Why not one chain per lane per launch slot: beside k_verify_main_half half of these blocks become resident late, and with a
 // fixed share of 4 chains of 2.5 ms each per lane the kernel's tail was 3 ms of a 17 ms pass (profiles/r05_exact_lane.txt).
-#ifndef EXACT_LANE_SHARE
-#define EXACT_LANE_SHARE 1
-#endif
 constexpr uint32_t EXACT_CHAIN_COST = 594;       // executed instructions per item of k_verify_exact_lane_chain, thousands
 constexpr unsigned EXACT_LANE_BLOCKS = 512;      // two resident blocks per CU
 constexpr int EXACT_DIGITS_AT = 0, EXACT_STATE_AT = 64;   // words of the item's rtable slot: the digit string; the accumulator between stretches (lines of its own)
@@ -342,7 +330,6 @@ k_verify_exact_lane_chain(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, c
   // no more waves than tiles: one that drew a later stretch of a tile still in its first would only hold, waiting, a slot
   // that a wave of k_verify_main_half could use
   unsigned waves = tiles;
-#if EXACT_LANE_SHARE
   // ... and no more than this kernel's SHARE of the wave slots: its persistent waves keep what they take until the list is
   // done, the main kernel beside it fills what is left, and whichever ends first leaves the other to its own tail.  With the
   // slots split like the work (main_cost: the main kernel's instructions per item in thousands, over the on-curve list or -
@@ -359,7 +346,6 @@ k_verify_exact_lane_chain(uint8_t* ok, const uint8_t* sigs, size_t sig_stride, c
     // - all keys random, a share of 0.70: 14.3 ms with all slots, 14.7 with its share)
     if (share * 5 < slots * 3 && share < waves) waves = (unsigned)(share < least ? least : share);
   }
-#endif
   if ((blockIdx.x * (unsigned)BLOCK + threadIdx.x) / 64u >= waves) return;
   for (;;) {
     unsigned u = 0;
@@ -495,14 +481,9 @@ k_verify_halve(const uint8_t* sigs, size_t sig_stride, const uint32_t* digits, u
 
 // dynamic LDS the main kernels are launched with: what keeps a third block off the CU, and where k_verify_main_half keeps its digit words
 constexpr unsigned MAIN_LDS_RESERVE = 74 * 1024;   // (2 x 74 of the CU's 160 KB: a third block does not fit, four waves of k_verify_exact_quad do)
-// (A/B builds only: -DMAIN_HALF_BLOCK=128 -DMAIN_HALF_LDS_KB=50 gives three blocks of 128 lanes per CU, 1.5 waves per
-// SIMD, a resident set of 226 MB that fits the 256 MB Infinity Cache: profiles/r03_verify_ab.txt)
-#ifndef MAIN_HALF_BLOCK
-#define MAIN_HALF_BLOCK BLOCK
-#endif
-#ifndef MAIN_HALF_BLOCKS_PER_CU
-#define MAIN_HALF_BLOCKS_PER_CU 2
-#endif
+// (measured and dropped: three blocks of 128 lanes with 50 KB each, 1.5 waves per SIMD - a resident set of 226 MB, which fits the
+// 256 MB Infinity Cache: profiles/r03_verify_ab.txt)
+constexpr int MAIN_HALF_BLOCK = BLOCK, MAIN_HALF_BLOCKS_PER_CU = 2;
 // WITH_LONG: after k_verify_prepare_pair (mid-size passes), which leaves the items without a short pair to this kernel:
 // the wave of such an item (2 in 10^7 with the wide search) runs the long loop
 template <int WINDOWS, bool WITH_LONG = false>
@@ -666,12 +647,9 @@ struct verify_finish_policy {
 
 // small passes: four lanes per item (quad_lanes.h: verify_main_quad); writes the same workspace
 constexpr size_t QUAD_MAIN_MAX_N = (size_t)1 << 14;   // measured: 0.57 vs 0.86 ms at 2^14, equal at 2^15 (tools/verify_sizes.py)
-#ifndef HALF_QUAD_LOG2
-#define HALF_QUAD_LOG2 15
-#endif
 // the upper bound of k_verify_prepare_pair + k_verify_main_half_quad when the mid-size arrangement below is switched off
 // (algo 0 takes that one above PAIR_ONE_MIN_N items, so the four-lane evaluation serves passes of up to 24 576 items)
-constexpr size_t HALF_QUAD_MAX_N = (size_t)1 << HALF_QUAD_LOG2;
+constexpr size_t HALF_QUAD_MAX_N = (size_t)1 << 15;
 // Between 24 576 and 2^18 items: k_verify_prepare_pair, then the ONE-lane evaluation with the long loop in place.  Measured
 // (tools/verify_mid.py, valid signatures, ms): 2^15 0.68 (four-lane evaluation) / 0.70 (one lane per item throughout) -> 0.58,
 // 2^16 0.71-0.76 -> 0.66, 2^17 1.30 -> 1.28; the config-2 mix, whose floor is the exact path: 2^16 1.16 -> 1.11, else equal.
@@ -759,9 +737,6 @@ constexpr int POINT_SPLIT = 4, POINT_SPLIT_ITEMS = 64;
 // VERDICT r03 #8; not the staging, not LDS latency, not the instruction cache: profiles/r04_sign_ab.txt).  Handed out one by
 // one, the tiles go to whichever wave is ahead and all waves finish together.  Small passes (no more blocks than CUs, or four
 // lanes per item) keep the fixed mapping: block b takes tile b.
-#ifndef POINT_DYNAMIC
-#define POINT_DYNAMIC 1
-#endif
 constexpr unsigned POINT_MAX_BLOCKS = 256u * (512 / POINT_BLOCK);   // as many as are resident at once
 
 // the next item of this lane, or false when the pass is done.  `it` = the lane's iteration count so far (0 at the start).
@@ -769,7 +744,7 @@ constexpr unsigned POINT_MAX_BLOCKS = 256u * (512 / POINT_BLOCK);   // as many a
 // the end (the launcher zeroes it on the pass's stream before every such launch).
 template <int PARTS>
 ED_DEV bool point_tile(size_t& i, unsigned it, size_t n, uint32_t* tiles) {
-  if (PARTS == 1 && POINT_DYNAMIC && tiles != nullptr) {
+  if (PARTS == 1 && tiles != nullptr) {
     unsigned t = 0;
     if ((threadIdx.x & 63u) == 0) t = atomicAdd(tiles, 1u);
     t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
@@ -1314,11 +1289,7 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* srcp, size_t n, const u
                  ok, ws->hdigits, ws->table, ws->rtable, base16, ws->flags, n, ws->exact_offcurve);
     if (marks) { EDK_DO(hipEventRecord(marks[2], stream)); EDK_DO(hipEventRecord(marks[3], stream)); }
   } else if (half || pair_one) {
-#ifdef MAIN_HALF_LDS_KB
-    constexpr unsigned half_lds = MAIN_HALF_LDS_KB * 1024;
-#else
     constexpr unsigned half_lds = MAIN_LDS_RESERVE;
-#endif
     static_assert(HALF_DIGIT_WORDS * MAIN_HALF_BLOCK * 4 <= half_lds, "k_verify_main_half keeps its digit words in the block's LDS");
     const unsigned hblocks = (blocks * BLOCK + MAIN_HALF_BLOCK - 1) / MAIN_HALF_BLOCK;
     if (pair_one)

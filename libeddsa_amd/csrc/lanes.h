@@ -1318,7 +1318,6 @@ ED_DEV void scale_base_lane(ge& out, const uint32_t xw[8], const uint32_t* comb,
       for (int k = 0; k < 8; k++) y[k] = (y[k] >> (2 * COMB_W)) | (y[k + 1] << (32 - 2 * COMB_W));
       y[8] >>= 2 * COMB_W;
     }
-#ifndef COMB_LOOKUP_LATE
     // both lookups of the row are issued ahead of its two additions: the second one's 30 shuffles and their latency run on
     // the LDS pipe beside the first addition's multiplications instead of between the two additions (fe_mul ends in a
     // scheduling barrier, so the compiler does not move them there by itself).  Measured, profiles/r04_sign_ab.txt:
@@ -1328,13 +1327,6 @@ ED_DEV void scale_base_lane(ge& out, const uint32_t xw[8], const uint32_t* comb,
     comb_select(e2, comb, valid ? row : 0, valid ? two >> COMB_W : (uint32_t)COMB_HALF);
     if (i == 0) ge_from_niels(r0, e); else ge_add_niels(r0, r0, e, true);      // (the first entry IS the sum so far: one multiplication instead of seven)
     if (i == 0) ge_from_niels(r1, e2); else ge_add_niels(r1, r1, e2, true);
-#else                    /* the A/B build: each lookup right before its addition */
-    ge_niels e;
-    comb_select(e, comb, valid ? row : 0, valid ? two & ((1u << COMB_W) - 1u) : (uint32_t)COMB_HALF);
-    if (i == 0) ge_from_niels(r0, e); else ge_add_niels(r0, r0, e, true);
-    comb_select(e, comb, valid ? row : 0, valid ? two >> COMB_W : (uint32_t)COMB_HALF);
-    if (i == 0) ge_from_niels(r1, e); else ge_add_niels(r1, r1, e, true);
-#endif
   }
 #pragma unroll 1
   for (int k = 0; k < COMB_W; k++) ge_dbl(r1, r1, k == COMB_W - 1);

@@ -11,6 +11,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+import libeddsa_amd  # noqa: E402
+# the suite drives the hooks of include/eddsa_amd_debug.h (route selection, fault injectors, counters): it binds the debug build -
+# the product's object files plus those functions.  The shipped library is what the C programs under tests/c link and what
+# test_abi_and_host.py inspects.
+libeddsa_amd.use_debug_library()
 
 
 def pytest_configure(config):

@@ -493,7 +493,8 @@ def test_small_batch_digests(engine, golden):
 
 def test_c_program_against_eddsa_h(engine, golden, tmp_path):
     """a plain C program written against eddsa.h / eddsa_amd.h (tests/c/selftest_dropin.c: the checks
-    of the reference's four selftests on the golden tables) linked against libeddsa_amd.so"""
+    of the reference's four selftests on the golden tables) linked against libeddsa_amd.so - the SHIPPED library, which
+    exports no hook (the two programs below use the measurement surface and link libeddsa_amd_debug.so)"""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -522,7 +523,7 @@ def test_host_side_stress_program_on_the_real_runtime(engine, golden, tmp_path):
     exe = tmp_path / "host_side_stress"
     subprocess.check_call(["gcc", "-std=c11", "-O1", "-pthread", "-I" + os.path.join(root, "include"),
                            os.path.join(root, "tests", "c", "host_side_stress.c"), "-L" + os.path.join(root, "libeddsa_amd"),
-                           "-leddsa_amd", "-Wl,-rpath," + os.path.join(root, "libeddsa_amd"), "-ldl", "-o", str(exe)])
+                           "-leddsa_amd_debug", "-Wl,-rpath," + os.path.join(root, "libeddsa_amd"), "-ldl", "-o", str(exe)])
     msgs = tmp_path / "msgs.bin"
     msgs.write_bytes(b"".join(golden_msg(i) for i in range(1024)))
     r = subprocess.run([str(exe), os.path.join(root, "tests", "golden", "ed25519_table.bin"), str(msgs),
@@ -544,7 +545,7 @@ def test_threaded_c_application_on_the_single_item_functions(engine, golden, tmp
     exe = tmp_path / "threaded_callers"
     subprocess.check_call(["gcc", "-std=c11", "-O1", "-pthread", "-I" + os.path.join(root, "include"),
                            os.path.join(root, "tests", "c", "threaded_callers.c"), "-L" + os.path.join(root, "libeddsa_amd"),
-                           "-leddsa_amd", "-Wl,-rpath," + os.path.join(root, "libeddsa_amd"), "-o", str(exe)])
+                           "-leddsa_amd_debug", "-Wl,-rpath," + os.path.join(root, "libeddsa_amd"), "-o", str(exe)])
     msgs = tmp_path / "msgs.bin"
     msgs.write_bytes(b"".join(golden_msg(i) for i in range(1024)))
     r = subprocess.run([str(exe), os.path.join(root, "tests", "golden", "ed25519_table.bin"), str(msgs),

@@ -11,6 +11,7 @@ import torch
 
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 import libeddsa_amd as ed
+ed.use_debug_library()   # the hooks (route selection, phase timings, traces) live in libeddsa_amd_debug.so
 
 cls = sys.argv[1] if len(sys.argv) > 1 else "random"
 n = 1 << 16

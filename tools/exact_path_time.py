@@ -5,6 +5,7 @@ import torch, time, numpy as np, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import libeddsa_amd as ed, workload
+ed.use_debug_library()   # the hooks (route selection, phase timings, traces) live in libeddsa_amd_debug.so
 ed.init(0)
 n = 1 << 20
 sk, msg = workload.sign_inputs(n)

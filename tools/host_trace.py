@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch  # noqa: F401
 import libeddsa_amd as ed
+ed.use_debug_library()   # the hooks (route selection, phase timings, traces) live in libeddsa_amd_debug.so
 import workload
 ed.init(0)
 op = sys.argv[1] if len(sys.argv) > 1 else "verify"

@@ -4,6 +4,7 @@ block on the GPU (about 10 us), so its latency is the host path's fixed cost (co
 import time, sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import libeddsa_amd as ed
+ed.use_debug_library()   # the hooks (route selection, phase timings, traces) live in libeddsa_amd_debug.so
 ed.init(0)
 sk = bytes(range(32)); pk = ed.ed25519_genpub(sk); msg = b"x" * 32; sig = ed.ed25519_sign(sk, pk, msg)
 for name, f in (("sk_ed25519_to_x25519 (fixed cost)", lambda: ed.sk_ed25519_to_x25519(sk)),

@@ -7,6 +7,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import libeddsa_amd as ed
+ed.use_debug_library()   # the hooks (route selection, phase timings, traces) live in libeddsa_amd_debug.so
 ed.init(0)
 n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 16)
 g = torch.Generator(device="cuda").manual_seed(7)

@@ -7,6 +7,7 @@ ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import libeddsa_amd as ed, workload
+ed.use_debug_library()   # the hooks (route selection, phase timings, traces) live in libeddsa_amd_debug.so
 ed.init(0)
 n = 1 << 20
 sk, msg = workload.sign_inputs(n, seed=1, config=2)

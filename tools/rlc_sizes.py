@@ -4,6 +4,7 @@ import sys, time
 import numpy as np, torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0]); sys.path.insert(0, __file__.rsplit("/", 1)[0])
 import libeddsa_amd as ed, workload
+ed.use_debug_library()   # the hooks (route selection, phase timings, traces) live in libeddsa_amd_debug.so
 ed.init(0)
 N = 1 << 21
 sk, msg = workload.sign_inputs(N, seed=1, config=2)

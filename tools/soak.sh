@@ -15,8 +15,8 @@ def golden_msg(i):
     return out[:i]
 open("/tmp/msgs.bin", "wb").write(b"".join(golden_msg(i) for i in range(1024)))
 PY
-gcc -std=c11 -O1 -pthread -Iinclude tests/c/host_side_stress.c -Llibeddsa_amd -leddsa_amd -Wl,-rpath,$PWD/libeddsa_amd -ldl -o /tmp/host_side_stress || exit 1
-gcc -std=c11 -O1 -pthread -Iinclude tests/c/threaded_callers.c -Llibeddsa_amd -leddsa_amd -Wl,-rpath,$PWD/libeddsa_amd -o /tmp/threaded_callers || exit 1
+gcc -std=c11 -O1 -pthread -Iinclude tests/c/host_side_stress.c -Llibeddsa_amd -leddsa_amd_debug -Wl,-rpath,$PWD/libeddsa_amd -ldl -o /tmp/host_side_stress || exit 1
+gcc -std=c11 -O1 -pthread -Iinclude tests/c/threaded_callers.c -Llibeddsa_amd -leddsa_amd_debug -Wl,-rpath,$PWD/libeddsa_amd -o /tmp/threaded_callers || exit 1
 rc=0
 for pass in 1 2 3; do
   s=$(date +%s.%N)

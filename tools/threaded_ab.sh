@@ -11,10 +11,10 @@ def golden_msg(i):
     return out[:i]
 open("/tmp/msgs.bin","wb").write(b"".join(golden_msg(i) for i in range(1024)))
 PY
-# the program binds libeddsa.so.0 (the SONAME); each variant gets a directory of its own with that name in it - the product library is not touched
-gcc -std=c11 -O1 -pthread -Iinclude tests/c/threaded_callers.c -Llibeddsa_amd -leddsa_amd -o /tmp/threaded_callers
+# the program binds libeddsa_amd_debug.so (that build's SONAME; variants are debug builds): each gets a directory of its own with that name in it - nothing in the tree is overwritten
+gcc -std=c11 -O1 -pthread -Iinclude tests/c/threaded_callers.c -Llibeddsa_amd -leddsa_amd_debug -o /tmp/threaded_callers
 for rep in 1 2; do for so in "$@"; do
-  d=$(mktemp -d); cp "$so" "$d/libeddsa.so.0"; echo "== $so"
+  d=$(mktemp -d); cp "$so" "$d/libeddsa_amd_debug.so"; echo "== $so"
   for t in 8 32 64 128 256 512; do LD_LIBRARY_PATH="$d" /tmp/threaded_callers tests/golden/ed25519_table.bin /tmp/msgs.bin tests/golden/x25519_table.bin $t 200 48 | grep -v "one caller\|: ok"; done
   rm -rf "$d"
 done; done

@@ -10,7 +10,7 @@ def golden_msg(i):
     return out[:i]
 open("/tmp/msgs.bin","wb").write(b"".join(golden_msg(i) for i in range(1024)))
 PY
-gcc -std=c11 -O1 -pthread -Iinclude tests/c/threaded_callers.c -Llibeddsa_amd -leddsa_amd -Wl,-rpath,$PWD/libeddsa_amd -o /tmp/threaded_callers
+gcc -std=c11 -O1 -pthread -Iinclude tests/c/threaded_callers.c -Llibeddsa_amd -leddsa_amd_debug -Wl,-rpath,$PWD/libeddsa_amd -o /tmp/threaded_callers
 for t in 1 8 64 256; do /tmp/threaded_callers tests/golden/ed25519_table.bin /tmp/msgs.bin tests/golden/x25519_table.bin $t 200 | grep -v "one caller\|: ok"; done
 echo "-- messages of 0 .. 47 bytes (one SHA-512 block per item):"
 for t in 64 256; do /tmp/threaded_callers tests/golden/ed25519_table.bin /tmp/msgs.bin tests/golden/x25519_table.bin $t 200 48 | grep -v "one caller\|: ok"; done

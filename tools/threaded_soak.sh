@@ -9,5 +9,5 @@ def golden_msg(i):
     return out[:i]
 open("/tmp/msgs.bin","wb").write(b"".join(golden_msg(i) for i in range(1024)))
 PY
-gcc -std=c11 -O1 -pthread -Iinclude tests/c/threaded_callers.c -Llibeddsa_amd -leddsa_amd -Wl,-rpath,$PWD/libeddsa_amd -o /tmp/threaded_callers
+gcc -std=c11 -O1 -pthread -Iinclude tests/c/threaded_callers.c -Llibeddsa_amd -leddsa_amd_debug -Wl,-rpath,$PWD/libeddsa_amd -o /tmp/threaded_callers
 for t in 3 17 64 200 256; do /tmp/threaded_callers tests/golden/ed25519_table.bin /tmp/msgs.bin tests/golden/x25519_table.bin $t 1500 | grep -v "one caller"; done

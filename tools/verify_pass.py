@@ -6,6 +6,7 @@ import numpy as np, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import libeddsa_amd as ed, workload
+ed.use_debug_library()   # the hooks (route selection, phase timings, traces) live in libeddsa_amd_debug.so
 L = int(sys.argv[1]); reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 kind = sys.argv[3] if len(sys.argv) > 3 else "mix"
 gap = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0

@@ -5,6 +5,7 @@ ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import libeddsa_amd as ed
+ed.use_debug_library()   # the hooks (route selection, phase timings, traces) live in libeddsa_amd_debug.so
 import workload
 ed.init(0)
 if os.environ.get("OFFCURVE_MODE"): ed.set_offcurve_mode(int(os.environ["OFFCURVE_MODE"]))

@@ -4,6 +4,7 @@ valid signatures only (no key off the curve, so the exact path has nothing to do
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tools"))
 import libeddsa_amd as ed, workload
+ed.use_debug_library()   # the hooks (route selection, phase timings, traces) live in libeddsa_amd_debug.so
 ed.init(0)
 d = lambda a: torch.from_numpy(a).cuda()
 for algo in (0, 1):

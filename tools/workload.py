@@ -140,3 +140,67 @@ def corrupt_for_verify(sig, pub, msg, seed=1, config=2, first=0, edges=True):
     expect = np.ones(n, np.uint8)
     expect[bad] = 0
     return splice_edges(sig, pub, msg, expect, seed, config, first) if edges else expect
+
+
+# ---------------------------------------------------------------------------------------------
+# mixed-order inputs at scale: the inputs on which "v = u t mod 8 l" (csrc/halve.h) and the scalar
+# mod 8 l of csrc/rlc.hip decide the verdict byte.  Test-data construction only: plain affine Edwards arithmetic on
+# Python integers; the expected verdicts come from the oracle.
+# ---------------------------------------------------------------------------------------------
+_D = (-121665 * pow(121666, P - 2, P)) % P
+
+
+def _xrecover(y, sign):
+    x2 = (y * y - 1) * pow(_D * y * y + 1, P - 2, P) % P
+    x = pow(x2, (P + 3) // 8, P)
+    if (x * x - x2) % P:
+        x = x * pow(2, (P - 1) // 4, P) % P
+    assert (x * x - x2) % P == 0
+    return P - x if (x & 1) != sign else x
+
+
+def _dec(enc):
+    v = int.from_bytes(enc, "little")
+    y, sign = v & (2**255 - 1), v >> 255
+    return (_xrecover(y, sign) if y not in (1, P - 1) else 0, y)
+
+
+def _add(p1, p2):
+    (x1, y1), (x2, y2) = p1, p2
+    k = _D * x1 * x2 * y1 * y2 % P
+    return ((x1 * y2 + x2 * y1) * pow(1 + k, P - 2, P) % P, (y1 * y2 + x1 * x2) * pow(1 - k, P - 2, P) % P)
+
+
+def _enc(pt):
+    return int(pt[1] | ((pt[0] & 1) << 255)).to_bytes(32, "little")
+
+
+def add_torsion(sk, pk, sig, msg, seed):
+    """In a third of the items (i % 3 == seed % 3) a random element of the 8-torsion subgroup - the neutral element
+    included - is added to the key A, to the commitment R, or to both (by item), and S is what the honest signer computes for
+    THAT key and commitment: S = r + H(R' || A' || M) a with r, a from the secret key as lib/ed25519-sha512.c:84-123 takes
+    them.  The prime-order parts are genuine, so S B - t A' - R' = -(t T_A + T_R): the reference accepts exactly when
+    t T_A + T_R = 0.  Returns (sig', pk', touched) - copies; `touched` marks the rewritten items."""
+    import hashlib
+    rng = np.random.default_rng(seed)
+    tors = [_dec(bytes.fromhex(h)) for h, _ in SMALL_ORDER]
+    n = sk.shape[0]
+    sig2, pk2 = sig.copy(), pk.copy()
+    touched = np.zeros(n, bool)
+    for i in range(seed % 3, n, 3):
+        kind = int(rng.integers(0, 3))                     # 0: A, 1: R, 2: both
+        ta, tr = tors[int(rng.integers(0, 8))], tors[int(rng.integers(0, 8))]
+        a_enc, r_enc, m = pk[i].tobytes(), sig[i, :32].tobytes(), msg[i].tobytes()
+        if kind != 1:
+            a_enc = _enc(_add(_dec(a_enc), ta))
+        if kind != 0:
+            r_enc = _enc(_add(_dec(r_enc), tr))
+        h = hashlib.sha512(sk[i].tobytes()).digest()
+        a = int.from_bytes(h[:32], "little") & ((1 << 254) - 8) | (1 << 254)
+        r = int.from_bytes(hashlib.sha512(h[32:] + m).digest(), "little") % L
+        t = int.from_bytes(hashlib.sha512(r_enc + a_enc + m).digest(), "little") % L
+        pk2[i] = np.frombuffer(a_enc, np.uint8)
+        sig2[i, :32] = np.frombuffer(r_enc, np.uint8)
+        sig2[i, 32:] = np.frombuffer(((r + t * a) % L).to_bytes(32, "little"), np.uint8)
+        touched[i] = True
+    return sig2, pk2, touched
