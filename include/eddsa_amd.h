@@ -20,11 +20,14 @@
  * msgs[i*msg_len .. (i+1)*msg_len)) or ragged (msg_off[0..n]: item i is
  * msgs[msg_off[i] .. msg_off[i+1])).  Verdicts are one byte per item (1 = accept, 0 = reject).
  * The offset table must not decrease, and msg_off[n] is taken for the size of the message buffer.  A host-pointer call
- * checks its table (chunk by chunk, before the chunk's bytes are touched) and returns -hipErrorInvalidValue for one that
- * decreases or spans more than 2^46 bytes.  A device-pointer call cannot inspect a table in HBM without a pass of its
- * own: its kernels CLAMP every item's span into [0, msg_off[n]) and to a length >= 0 instead, so whatever the table
- * holds no lane reads outside [msgs, msgs + msg_off[n]); an item with an inconsistent span is hashed over the clamped
- * one (its verdict / signature is then meaningless, like the table).
+ * checks its table - the span msg_off[n] - msg_off[0] (at most 2^46 bytes, not negative) before anything is touched, the
+ * order of the entries chunk by chunk, before each chunk's bytes are - and returns -hipErrorInvalidValue for a bad one; a
+ * table that decreases further on is found when its chunk comes up, after earlier chunks have run (outputs unspecified,
+ * as on every error).  A device-pointer call cannot inspect a table in HBM without a pass of its own: its kernels CLAMP
+ * every item's span into [0, msg_off[n]) and to a length >= 0 instead, so whatever the table holds no lane reads outside
+ * the aligned 4-byte words that hold the bytes [msgs, msgs + msg_off[n]) (the hashing kernels load whole words: up to
+ * 3 bytes before an unaligned msgs and after the last byte lie in the same word as a byte of the buffer); an item with an
+ * inconsistent span is hashed over the clamped one (its verdict / signature is then meaningless, like the table).
  *
  * Two flavours of every entry point:
  *   *_batch      host pointers; copies in, runs, copies out, returns when done.

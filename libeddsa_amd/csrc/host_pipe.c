@@ -515,6 +515,12 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
     const int tunable = j->stats == NULL;                       /* (a combination covers a fixed number of items) */
     const size_t stage = tunable && g_pipe_stage ? g_pipe_stage : j->chunk ? j->chunk : PIPE_CHUNK;
     const size_t first = tunable && g_pipe_first ? g_pipe_first : j->first_chunk ? j->first_chunk : PIPE_FIRST_CHUNK;
+    /* The offset table as a whole, before anything is touched: it must not end before it starts, nor span more than 2^46
+     * bytes (include/eddsa_amd.h).  Whether it DEcreases somewhere in between is checked chunk by chunk below, as each chunk is
+     * about to be staged (one pass over the table in step with the copies instead of a second one in front of them): a table
+     * that is bad further on is found after earlier chunks have run, the call then returns -hipErrorInvalidValue and its
+     * outputs are unspecified, as on every error. */
+    if (ragged && (j->msg_off[n] < j->msg_off[0] || j->msg_off[n] - j->msg_off[0] > MSG_BYTES_MAX)) return -(int)hipErrorInvalidValue;
     const size_t msg_total = !j->has_msgs ? 0 : ragged ? (size_t)(j->msg_off[n] - j->msg_off[0]) : n * j->msg_len;
     /* one chunk, one lane (any); several chunks - and the batch verification, whose statistics live in the pipe - all of them */
     const int all = j->stats != NULL || n > first;
@@ -834,9 +840,13 @@ static int combiner_submit(struct engine *e, const struct hjob *j, size_t n)
             /* ... but not without end: a batch holds up to 16 384 requests, and when the cause is the device (lost, out of
              * memory) every retry stages secrets, fails, waits and wipes while all callers stay blocked.  After
              * COMBINE_RETRY_GIVE_UP retries in a row that end with the batch's own error the rest are told that error. */
+            /* Only for errors of the DEVICE: an error a caller can bring about by itself (an invalid argument, a bad offset
+             * table) says nothing about the next request - four faulty callers in a row must not fail everybody behind
+             * them - so such a batch is retried request by request to the end. */
+            const int device_fault = rc != -(int)hipErrorInvalidValue && rc != -(int)hipErrorInvalidDevicePointer;
             int same = 0;
             for (struct creq *r = batch; r; r = r->next) {
-                if (same >= COMBINE_RETRY_GIVE_UP) { r->rc = rc; continue; }
+                if (device_fault && same >= COMBINE_RETRY_GIVE_UP) { r->rc = rc; continue; }
                 struct hjob alone = *r->j;
                 alone.traced = 1;
                 r->rc = pipe_run_on(e, &alone, r->n);

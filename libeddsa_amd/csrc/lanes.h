@@ -52,7 +52,8 @@ ED_DEV void shl256(uint32_t w[8]) {
 // A ragged span is clamped into [0, *end) - *end is the table's own last entry, which the caller vouches for as the size of
 // the message buffer - and to a length that is not negative: a table that is not non-decreasing (the host-pointer entry
 // points refuse one with hipErrorInvalidValue; a table in device memory cannot be inspected without a pass of its own)
-// never makes a lane read outside [msgs, msgs + *end).  Such an item is hashed over the clamped span.
+// never makes a lane read outside the aligned 4-byte words that hold [msgs, msgs + *end) (sha512.h loads a block's words whole: an
+// unaligned span shares its first and last word with up to 3 neighbouring bytes).  Such an item is hashed over the clamped span.
 ED_DEV void ragged_span(uint64_t& lo, uint64_t& hi, const uint64_t* off, const uint64_t* end, size_t item) {
   const uint64_t total = *end;
   lo = off[item]; hi = off[item + 1];

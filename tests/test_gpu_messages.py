@@ -199,6 +199,10 @@ def test_host_calls_refuse_an_offset_table_that_decreases(engine, oracle, n):
         assert engine.library().ed25519_sign_batch(P(out), P(sk_n), P(pk_n), P(blob_n), P(bad), ctypes.c_size_t(0), ctypes.c_size_t(n)) == -1
     huge = off_n.copy(); huge[n] = 1 << 60
     assert raw_verify(engine, ok, sig_n, pk_n, blob_n, huge, n) == -1
+    # the 2^46-byte limit is the whole table's: one whose chunks each stay below it is refused all the same, before anything is
+    # touched (its messages do not exist)
+    steep = (np.arange(n + 1, dtype=np.uint64) * np.uint64((1 << 47) // n))
+    assert raw_verify(engine, ok, sig_n, pk_n, blob_n, steep, n) == -1
     ok[:] = 0
     assert raw_verify(engine, ok, sig_n, pk_n, blob_n, off_n, n) == 0 and ok.all()
     assert engine.secret_residue()[0] == 0
