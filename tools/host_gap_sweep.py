@@ -46,8 +46,14 @@ lib.eddsa_amd_set_pipeline(ctypes.c_size_t(0), ctypes.c_size_t(0))
 ed.set_host_threads(6)
 hs, hp, hm = ed.host_array(sig.shape), ed.host_array(pk.shape), ed.host_array(msg.shape)
 hs[:], hp[:], hm[:] = sig, pk, msg
-for first in (15, 16, 17):
-    lib.eddsa_amd_set_pipeline(ctypes.c_size_t(1 << first), ctypes.c_size_t(0))
-    t, tm, o = timeit(lambda: ed.ed25519_verify_batch(hs, hp, hm)); assert np.array_equal(o, expect)
-    print(f"page-locked caller memory (no staging), first chunk 2^{first}  {n / t / 1e6:6.1f} M/s  best {t * 1e3:5.2f} ms  median {tm * 1e3:5.2f}", flush=True)
+# chunk schedules (first chunk, every later one twice its predecessor up to the cap) and kernel orderings of consecutive chunks
+# (-1 the operation's own = 0 side by side for verify; 1 in chunk order; 2 the next chunk beside the previous main kernel)
+for chain in (-1, 1, 2):
+    lib.eddsa_amd_set_pipeline_chain(chain)
+    for first, cap in ((15, 0), (16, 0), (17, 0), (16, 16), (16, 17), (16, 18), (16, 19), (17, 17), (17, 18), (17, 19), (18, 18), (18, 19)):
+        lib.eddsa_amd_set_pipeline(ctypes.c_size_t(1 << first), ctypes.c_size_t((1 << cap) if cap else 0))
+        t, tm, o = timeit(lambda: ed.ed25519_verify_batch(hs, hp, hm)); assert np.array_equal(o, expect)
+        t2, tm2, o = timeit(lambda: ed.ed25519_verify_batch(sig, pk, msg)); assert np.array_equal(o, expect)
+        print(f"order {chain:2d}, first chunk 2^{first}, cap 2^{cap if cap else 20}: page-locked {n / t / 1e6:6.1f} M/s {t * 1e3:5.2f} ms | malloc {n / t2 / 1e6:6.1f} M/s {t2 * 1e3:5.2f} ms", flush=True)
+lib.eddsa_amd_set_pipeline_chain(-1)
 lib.eddsa_amd_set_pipeline(ctypes.c_size_t(0), ctypes.c_size_t(0))
