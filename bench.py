@@ -698,7 +698,7 @@ def main():
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         # (calls below the library's break-even size skip the combination: then st[1] == m)
-        good = all_ranks_agree(bool(okr.all()) and st[0] + st[1] == m and (st[0] == m or m < (3 << 17)), world, device)
+        good = all_ranks_agree(bool(okr.all()) and st[0] + st[1] == m and (st[0] == m or m < ed.RLC_MIN_ITEMS_DEFAULT), world, device)
         correct = correct and good
         secondary["verify_rlc_all_valid"] = {
             "metric": "ed25519 verifies/sec, opt-in batch verification, the config's items before corruption (all valid)",

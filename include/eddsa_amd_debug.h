@@ -34,10 +34,13 @@ EDDSA_AMD_DECL int eddsa_amd_debug_fail_next_host_call(void);
  * waits, the work-list reset, launches - reports hipErrorUnknown instead of being made; 0 disarms.  The pass must
  * return a negative value and leave the engine usable. */
 EDDSA_AMD_DECL int eddsa_amd_debug_fail_hip_call(int nth);
-/* the hand-off between the waves of k_verify_exact_lane_chain (csrc/kernels.hip): the first hand-off of tile
- * `tile_plus_1 - 1` of every later pass is never published, so the wave that waits for it must give up after its bound
- * and the pass must come back as EDDSA_AMD_STALLED instead of hanging; 0 switches it off.  Waits for the device; acts on
- * the workspaces allocated so far. */
+/* The two places where device code waits for other device code.  (i) The hand-off between the waves of
+ * k_verify_exact_lane_chain (csrc/kernels.hip): the first hand-off of tile `tile_plus_1 - 1` of every later pass is never
+ * published, so the wave that waits for it must give up after its bound and the pass must come back as EDDSA_AMD_STALLED
+ * instead of hanging.  (ii) The batch verification's Horner waves (csrc/rlc.hip: k_rlc_horner), which take the window points
+ * of k_rlc_bucket as they arrive: the flag of window point `tile_plus_1 - 1` of group 0 is never raised, so that group's
+ * wave must give up and hand its groups to the per-item kernels - same verdicts, no error.  0 switches both off.  Waits for
+ * the device; acts on the workspaces allocated so far. */
 EDDSA_AMD_DECL int eddsa_amd_debug_withhold_handoff(int tile_plus_1);
 /* checked HIP calls the verify passes have made since the last eddsa_amd_debug_fail_hip_call (so that a test can walk
  * nth over every one of them) */

@@ -11,6 +11,7 @@ from .api import (  # noqa: F401
     EddsaAmdError,
     DH,
     HOOKS_OFF,
+    RLC_MIN_ITEMS_DEFAULT,
     STALLED,
     debug_withhold_handoff,
     debug_fail_hip_call,

@@ -24,7 +24,7 @@ static int g_default = -1;            /* device of the host-pointer entry points
 static int g_verify_algo = 0;         /* eddsa_amd_set_verify_algo: 0 by pass size (default), 1 full-length windows, 2 half-length scalars */
 static int g_offcurve_mode = 1;       /* eddsa_amd_set_offcurve_mode: 0 reject, 1 exact (default), 2 all exact */
 static int g_profiling;               /* record marks around the three verify kernels */
-static size_t g_rlc_min_items = (size_t)3 << 17;   /* eddsa_amd_set_rlc_min_items: smaller calls go to the per-item kernels */
+static size_t g_rlc_min_items = EDDSA_AMD_RLC_MIN_ITEMS_DEFAULT;   /* eddsa_amd_set_rlc_min_items: smaller calls go to the per-item kernels */
 
 int g_hooks_armed;                     /* eddsa_amd_debug_init: read and written atomically */
 struct multi g_multi;                  /* the device set of the *_multi entry points (eddsa_amd_init_devices) */
@@ -190,6 +190,8 @@ static int rws_reserve(struct vslot *v, size_t items)
     TRY(hipEventSynchronize(v->free));
     rws_release(v);
     TRY(hipMalloc((void **)&v->rws.base, edk_rlc_ws_bytes(cap)));
+    TRY(hipMemset((char *)v->rws.base + edk_rlc_hook_offset(cap), 0, 256));
+    TRY(hipStreamSynchronize(NULL));      /* the pass's stream does not wait for the null stream */
     TRY(hipHostMalloc(&v->rws.host_gok, EDK_RLC_HOST_BYTES, hipHostMallocDefault));
     v->rws.capacity = cap;
 out:
@@ -438,8 +440,9 @@ int eddsa_amd_debug_withhold_handoff(int tile_plus_1)
     TRY(hipDeviceSynchronize());
     for (int i = 0; i < VERIFY_SLOTS; i++) {
         const uint32_t w = tile_plus_1 > 0 ? (uint32_t)tile_plus_1 : 0u;
-        if (!c.e->vs[i].ws.offcount) continue;
-        TRY(hipMemcpy(c.e->vs[i].ws.offcount + EDK_WITHHOLD_WORD, &w, sizeof(w), hipMemcpyHostToDevice));
+        if (c.e->vs[i].ws.offcount) TRY(hipMemcpy(c.e->vs[i].ws.offcount + EDK_WITHHOLD_WORD, &w, sizeof(w), hipMemcpyHostToDevice));
+        if (c.e->vs[i].rws.base)
+            TRY(hipMemcpy((char *)c.e->vs[i].rws.base + edk_rlc_hook_offset(c.e->vs[i].rws.capacity), &w, sizeof(w), hipMemcpyHostToDevice));
     }
 out:
     pthread_mutex_unlock(&c.e->lk);
@@ -512,8 +515,8 @@ void eddsa_amd_set_offcurve_mode(int exact)
     pthread_rwlock_unlock(&g_table);
 }
 
-/* ed25519_verify_batch_rlc[_dev] calls of fewer than `items` items use the per-item kernels (default 3 x 2^17:
- * the measured break-even; 0 = always try the combination) */
+/* ed25519_verify_batch_rlc[_dev] calls of fewer than `items` items use the per-item kernels (default EDDSA_AMD_RLC_MIN_ITEMS_DEFAULT:
+ * above the measured break-even; 0 = always try the combination) */
 void eddsa_amd_set_rlc_min_items(size_t items)
 {
     pthread_rwlock_wrlock(&g_table);
@@ -714,8 +717,8 @@ int rlc_on(struct engine *e, uint8_t *ok, uint32_t *stats, const edk_verify_src 
     int rc = 0;
     if (n == 0) return 0;
     if (n < g_rlc_min_items) {
-        /* the combination has about 2 ms of latency of its own (hash tree, one serial Horner per group): below
-         * ~3 x 2^17 items the per-item kernels are faster (tools/rlc_sizes.py), so such calls go straight to them */
+        /* the combination has about 1.2 ms of latency of its own (hash tree, one serial Horner per group): below
+         * ~150 000 items the per-item kernels are faster (tools/rlc_sizes.py), so such calls go straight to them */
         rc = verify_on(e, ok, all, n, st, NULL, 0);
         if (!rc) { hipError_t er = edk_rlc_note_per_item(stats, n, st); if (er != hipSuccess) rc = -(int)er; }
         return rc;

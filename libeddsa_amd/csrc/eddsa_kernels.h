@@ -114,6 +114,7 @@ typedef struct edk_rlc_ws {
 hipError_t edk_msg_order(const uint32_t** perm, const edk_verify_ws* ws, const uint64_t* msg_off, const uint64_t* msg_end, size_t n,
                          hipStream_t stream);
 size_t edk_rlc_ws_bytes(size_t capacity);
+size_t edk_rlc_hook_offset(size_t capacity);   /* of the workspace's test-hook word (256 bytes to zero at allocation; rlc.hip: k_rlc_bucket) */
 hipError_t edk_rlc_note_per_item(uint32_t* stats, size_t n, hipStream_t stream);
 /* one pass in two halves: edk_verify_rlc enqueues the combination and the copy of the group verdicts to rws->host_gok;
  * the caller synchronises `stream`; edk_verify_rlc_fallback hands the groups that did not pass to the per-item kernels */

@@ -36,8 +36,9 @@
 // digits of that window in LDS (18 KB), hands the buckets to its lanes in pairs by size rank (the fullest
 // with the emptiest ...: a wave takes as long as its busiest lane), each lane adds the points of its two
 // buckets (mixed additions, ed_add_pc's 7 M), and the weighted sum of the 128 buckets is fifteen additions
-// deep through LDS; k_rlc_final then runs Horner over the 48 window points of each group (four lanes per
-// point, quad_lanes.h: 248 dependent doublings are pure latency).
+// deep through LDS; k_rlc_horner runs Horner over the 48 window points of each group (four lanes per
+// point, quad_lanes.h: 248 dependent doublings are pure latency) BESIDE the bucket blocks, window by window
+// as their points arrive.
 // -A_i has 32 windows (z_i t_i mod 8 l, centred: |.| <= 4 l), -R_i 16 (z_i), B one entry per group and window: 48 mixed
 // additions per item instead of the per-item kernel's 252 doublings + 80 additions.  Algorithmic HBM
 // bytes: the same 129 per item as verify.  The per-lane arithmetic (decoding and routing flags,
@@ -57,12 +58,16 @@ constexpr int RLC_SEGS = RLC_SEGS_A + RLC_SEGS_R;   // window points per group: 
 constexpr int RLC_BLOCK = 256;
 constexpr int RLC_TREE_FAN = 64;
 constexpr uint32_t RLC_BASE_IDX = RLC_G;         // list entry that stands for the base point B
+constexpr int RLC_GROUP_WORDS = 64;              // per group: word 0 the routing flag, words 1..48 "window point s is in memory" (k_rlc_bucket)
+constexpr int RLC_HORNER_GROUPS = 16;            // groups per Horner wave (four lanes each)
+constexpr uint32_t RLC_HORNER_PATIENCE = 1u << 20;   // polls (a microsecond or two each) for ONE window before a Horner wave gives its groups up: a second,
+                                                     // where the whole bucket launch takes milliseconds
 
 
 // workspace carving (bytes), capacity = a multiple of 2048 items
 struct rlc_layout {
   size_t groups;
-  size_t ts, leaf, niels_a, niels_r, dig, flags, bsum, bdig, gflags, gok, seg, tree, seed, total;
+  size_t ts, leaf, niels_a, niels_r, dig, flags, bsum, bdig, gflags, gok, seg, tree, hook, total;
 };
 __host__ __device__ inline size_t rlc_align(size_t x) { return (x + 255) & ~(size_t)255; }
 __host__ inline rlc_layout rlc_carve(size_t cap) {
@@ -77,11 +82,11 @@ __host__ inline rlc_layout rlc_carve(size_t cap) {
   L.flags = o;   o += rlc_align(cap);
   L.bsum = o;    o += rlc_align((L.groups * (RLC_G / RLC_BLOCK) + 1) * 40);   // per block of 256 items: sum of z S, 9 words (+1 pad)
   L.bdig = o;    o += rlc_align(L.groups * 32);
-  L.gflags = o;  o += rlc_align(L.groups * 4);
+  L.gflags = o;  o += rlc_align(L.groups * RLC_GROUP_WORDS * 4);         // per group: routing flag, window flags
   L.gok = o;     o += rlc_align(L.groups);
   L.seg = o;     o += rlc_align(L.groups * RLC_SEGS * VERIFY_ENTRY_WORDS * 4);      // window points, cached form (packed)
   L.tree = o;    o += rlc_align((cap / RLC_TREE_FAN + 2) * 32 * 2);
-  L.seed = o;    o += 256;
+  L.hook = o;    o += 256;                                       // word 0: test hook (eddsa_amd_debug_withhold_handoff), zeroed at allocation
   L.total = o;
   return L;
 }
@@ -148,7 +153,7 @@ k_rlc_points(edk_verify_src src, size_t n, uint32_t* niels_a, uint32_t* niels_r,
   fl |= rlc_decode_r_lane(nl, w);
   niels_store(niels_r + 32 * i, nl);
   flags[i] = fl;
-  if (fl & RLC_PER_ITEM) atomicOr(gflags + i / RLC_G, 1u);
+  if (fl & RLC_PER_ITEM) atomicOr(gflags + RLC_GROUP_WORDS * (i / RLC_G), 1u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -270,16 +275,108 @@ ED_DEV void ge_cmov(ge& r, const ge& p, bool flag) {
   fe_cmov(r.X, p.X, flag); fe_cmov(r.Y, p.Y, flag); fe_cmov(r.Z, p.Z, flag); fe_cmov(r.T, p.T, flag);
 }
 
+// Window points pass from the bucket blocks to the Horner waves INSIDE the launch, and the eight XCDs' L2 caches are
+// not coherent with each other: an acquire / release pair at agent scope writes back and invalidates the whole L2
+// (buffer_wbl2 sc1 / buffer_inv sc1) - issued by each of the 6144 blocks it emptied the cache under the other blocks'
+// point loads (tried: + 0.4 ms).  So these few words travel by agent-scope accesses (sc1: written through to and read
+// from memory) and nothing else in the kernel is touched: the writer waits for its stores before it raises the flag,
+// the reader's loads follow a branch on the flag it read.
+ED_DEV void coherent_store8(uint32_t* dst, const uint32_t w[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; j++) __hip_atomic_store(dst + j, w[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+ED_DEV void coherent_load8(uint32_t w[8], const uint32_t* src) {
+#pragma unroll
+  for (int j = 0; j < 8; j++) w[j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// r += entry, a packed cached entry (Y-X | Y+X | 2dT | 2Z) written by another block of this launch (quad_lanes.h: quad_add_entry)
+ED_DEV void quad_add_coherent(fe& r, const uint32_t* e, int q) {
+  uint32_t w[8];
+  coherent_load8(w, e + 8 * q);
+  fe mult, first, m;
+  fe_unpack(mult, w);
+  quad_stage_a_operand(first, r, q);
+  fe_mul(m, first, mult);
+  quad_stage_b(r, m, q);
+}
+
+// R6: per group, Horner over the window points (highest window first; the 16 windows of -R carry the weights of the 16
+// lowest windows of -A): the total must be the neutral element.  248 dependent doublings per group: pure latency, the
+// price of any 253-bit multi-scalar multiplication, so it runs in the four-lanes-per-point form of quad_lanes.h (a
+// doubling is one squaring and one multiplication deep), sixteen groups to a wave.  The kernel runs on the side stream
+// BESIDE k_rlc_bucket (58 registers, no LDS: its eight waves fit next to the bucket blocks' two per SIMD) and takes each
+// window's points as its flags go up - the bucket blocks run in order of weight, so when the last of them is done all that
+// is left is the last windows' share of the chain.  (As a kernel after the bucket blocks the evaluation was 0.26 ms
+// during which the chip did nothing else.  Tried and dropped: run by the bucket block that completes a part of the windows
+// it held that block's wave slot, the SIMD's later blocks started late and the launch ended 0.4 ms later - 6144 blocks are
+// exactly three rounds of the chip's 2048 slots, and for the same reason these waves cannot be blocks of the bucket launch;
+// as kernels between launches of the bucket blocks by weight on two streams the hardware interleaved the launches and the
+// heavy windows were done no sooner.)
+// Forward progress: a bucket block waits for nothing and its launch is queued BEFORE this kernel's, so every flag is
+// raised whether or not the two launches overlap; a wave that has polled RLC_HORNER_PATIENCE times for one window all the
+// same (a fault elsewhere) gives its groups to the per-item kernels, whose verdicts are the reference's in any case.
+__global__ void __launch_bounds__(4 * RLC_HORNER_GROUPS)
+k_rlc_horner(size_t n, const uint32_t* segpts, const uint32_t* gflags, uint8_t* gok, uint32_t* stats) {
+  const size_t groups = (n + RLC_G - 1) / RLC_G;
+  const size_t g = (size_t)blockIdx.x * RLC_HORNER_GROUPS + (threadIdx.x >> 2);
+  const bool live = g < groups;
+  const int q = (int)(threadIdx.x & 3u);
+  const uint32_t* gpts = segpts + (live ? g : 0) * RLC_SEGS * VERIFY_ENTRY_WORDS;
+  const uint32_t* gw = gflags + RLC_GROUP_WORDS * (live ? g : 0);
+  fe r;
+  fe_set(r, (uint32_t)(q & 1));                  // neutral element (0, 1, 0, 1) as (X, Y, T, Z)
+  bool gave_up = false;
+#pragma unroll 1
+  for (int w = RLC_WINDOWS_A - 1; w >= 0 && !gave_up; w--) {
+    if (w != RLC_WINDOWS_A - 1) {
+#pragma unroll 1
+      for (int k = 0; k < 8; k++) quad_dbl(r, q);
+    }
+    const int sa = RLC_WINDOWS_A - 1 - w, sr = RLC_SEGS_A + RLC_WINDOWS_R - 1 - w;
+    uint32_t polls = 0;
+    for (;;) {
+      bool ready = !live || __hip_atomic_load(gw + 1 + sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+      if (w < RLC_WINDOWS_R) ready = ready && (!live || __hip_atomic_load(gw + 1 + sr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
+      if (__all(ready)) break;
+      if (++polls == RLC_HORNER_PATIENCE) { gave_up = true; break; }
+      __builtin_amdgcn_s_sleep(32);
+    }
+    if (gave_up) break;
+    quad_add_coherent(r, gpts + sa * VERIFY_ENTRY_WORDS, q);
+    if (w < RLC_WINDOWS_R) quad_add_coherent(r, gpts + sr * VERIFY_ENTRY_WORDS, q);
+  }
+  // neutral element: X = 0, Y = Z and Z != 0 (lane 0 holds X, lane 1 Y, lane 3 Z), as verify_half_main_quad tests it:
+  // (0, 0, *, 0) is no point, and is unreachable only while every combined point is on the curve
+  fe z, d;
+  fe_quad_perm<3, 3, 3, 3>(z, r);
+  fe_sub(d, r, z);                               // lane 1: Y - Z
+  const bool mine = q == 0 ? fe_iszero(r) : q == 1 ? fe_iszero(d) : q == 3 ? !fe_iszero(r) : true;
+  const int all = (int)mine & __shfl_xor((int)mine, 1);
+  const bool neutral = (all & __shfl_xor(all, 2)) != 0;
+  if (q != 0 || !live) return;
+  const bool ok = neutral && !gave_up && gw[0] == 0;
+  gok[g] = (uint8_t)ok;
+  if (stats) {
+    const uint32_t cnt = (uint32_t)(n - g * RLC_G < (size_t)RLC_G ? n - g * RLC_G : (size_t)RLC_G);
+    atomicAdd(stats + (ok ? 0 : 1), cnt);        // items decided by the combination / by the per-item kernels
+    if (!ok) atomicAdd(stats + 2, 1u);           // groups sent to the per-item kernels
+    else atomicAdd(stats + 3, 1u);               // groups decided by the combination
+  }
+}
+
+
+
 __global__ void __launch_bounds__(RLC_LANES, 2)
 k_rlc_bucket(size_t n, const int8_t* dig, const int8_t* bdig, const uint32_t* niels_a, const uint32_t* niels_r,
-             const uint32_t* base16, uint32_t* segpts) {
+             const uint32_t* base16, uint32_t* segpts, uint32_t* gflags, const uint32_t* hook) {
   __shared__ rlc_lds s;
   const size_t groups = (n + RLC_G - 1) / RLC_G;
-  const int seg = (int)(blockIdx.x / groups);    // window-major
+  // heaviest windows first (by_weight = 0..47): -A's windows 31..16, then windows 15..0 of -A and -R in turn (k_rlc_horner)
+  const int by_weight = (int)(blockIdx.x / groups);
   const size_t g = blockIdx.x % groups;
-  const bool is_a = seg < RLC_SEGS_A;
-  // window of this block; window s of -A and window s - 16 of -R carry the same weight
-  const int w = (is_a ? RLC_WINDOWS_A - 1 - seg : RLC_WINDOWS_R - 1 - (seg - RLC_SEGS_A));
+  const bool is_a = by_weight < 16 || ((by_weight - 16) & 1) == 0;
+  const int w = by_weight < 16 ? RLC_WINDOWS_A - 1 - by_weight : 15 - ((by_weight - 16) >> 1);
+  const int seg = is_a ? RLC_WINDOWS_A - 1 - w : RLC_SEGS_A + RLC_WINDOWS_R - 1 - w;   // the window point's place among the group's
   const uint32_t* pts = (is_a ? niels_a : niels_r) + g * (size_t)RLC_G * 32;
   const int8_t* drow = dig + (g * RLC_WINDOWS + (is_a ? 0 : RLC_WINDOWS_A)) * (size_t)RLC_G;
   const int l = (int)threadIdx.x;
@@ -413,59 +510,27 @@ k_rlc_bucket(size_t n, const int8_t* dig, const int8_t* bdig, const uint32_t* ni
   }
   lds_put(s.pts, acc);
   __syncthreads();
-  if (l == 0) {                                  // the window's weight 2^(8 w) is applied by k_rlc_final
+  if (l == 0) {                                  // the window's weight 2^(8 w) is applied by the Horner wave
     ge o;
     lds_get(o, s.pts, 32);                       // sum of the sa_j: subtracted
     fe_neg(o.X, o.X); fe_carry(o.X);
     fe_neg(o.T, o.T); fe_carry(o.T);
     ge_dbl(acc, acc, true);
     ge_add_full(acc, acc, o);
-    ge_cached c;                                 // stored in cached form (Y-X | Y+X | 2dT | 2Z): what quad_add_entry reads
+    ge_cached c;                                 // stored in cached form (Y-X | Y+X | 2dT | 2Z, packed)
     ge_to_cached(c, acc);
-    cached_store(segpts + (g * RLC_SEGS + seg) * VERIFY_ENTRY_WORDS, 0, c);
-  }
-}
-
-// R6: per group, Horner over the window points (highest window first; the 16 windows of -R carry the
-// weights of the 16 lowest windows of -A): the total must be the neutral element.  248 dependent
-// doublings per group: pure latency, the price of any 253-bit multi-scalar multiplication, so it runs in
-// the four-lanes-per-point form of quad_lanes.h (a doubling is one squaring and one multiplication
-// deep): 0.55 ms with one lane per group, 0.2 ms this way.
-__global__ void __launch_bounds__(256)
-k_rlc_final(size_t n, const uint32_t* segpts, const uint32_t* gflags, uint8_t* gok, uint32_t* stats) {
-  const size_t g = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 2;            // quads are all-or-nothing
-  const size_t groups = (n + RLC_G - 1) / RLC_G;
-  if (g >= groups) return;
-  const int q = (int)(threadIdx.x & 3u);
-  const uint32_t* pts = segpts + g * RLC_SEGS * VERIFY_ENTRY_WORDS;
-  fe r;
-  fe_set(r, (uint32_t)(q & 1));                  // neutral element (0, 1, 0, 1) as (X, Y, T, Z)
-#pragma unroll 1
-  for (int sgm = 0; sgm < RLC_SEGS_A; sgm++) {
-    if (sgm != 0) {
-#pragma unroll 1
-      for (int k = 0; k < 8 * RLC_SEG_WINDOWS; k++) quad_dbl(r, q);
+    uint32_t* dst = segpts + (g * RLC_SEGS + seg) * VERIFY_ENTRY_WORDS;
+    const fe* f[4] = {&c.ymx, &c.ypx, &c.t2d, &c.z2};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint32_t pw[8];
+      fe_pack(pw, *f[k]);
+      coherent_store8(dst + 8 * k, pw);
     }
-    quad_add_entry(r, pts + sgm * VERIFY_ENTRY_WORDS, false, true, q);
-    if (sgm >= RLC_SEGS_A - RLC_SEGS_R)
-      quad_add_entry(r, pts + (RLC_SEGS_A + sgm - (RLC_SEGS_A - RLC_SEGS_R)) * VERIFY_ENTRY_WORDS, false, true, q);
-  }
-  // neutral element: X = 0, Y = Z and Z != 0 (lane 0 holds X, lane 1 Y, lane 3 Z), as verify_half_main_quad tests it:
-  // (0, 0, *, 0) is no point, and is unreachable only while every combined point is on the curve
-  fe z, d;
-  fe_quad_perm<3, 3, 3, 3>(z, r);
-  fe_sub(d, r, z);                               // lane 1: Y - Z
-  const bool mine = q == 0 ? fe_iszero(r) : q == 1 ? fe_iszero(d) : q == 3 ? !fe_iszero(r) : true;
-  const int all = (int)mine & __shfl_xor((int)mine, 1) ;
-  const bool neutral = (all & __shfl_xor(all, 2)) != 0;
-  if (q != 0) return;
-  const bool ok = neutral && gflags[g] == 0;
-  gok[g] = (uint8_t)ok;
-  if (stats) {
-    const uint32_t cnt = (uint32_t)(n - g * RLC_G < (size_t)RLC_G ? n - g * RLC_G : (size_t)RLC_G);
-    atomicAdd(stats + (ok ? 0 : 1), cnt);        // items decided by the combination / by the per-item kernels
-    if (!ok) atomicAdd(stats + 2, 1u);           // groups sent to the per-item kernels
-    else atomicAdd(stats + 3, 1u);               // groups decided by the combination
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the point is in memory before its flag is
+    // (test hook: the flag of window point *hook - 1 of group 0 is never raised; the word is 0 unless a test set it)
+    if (!(g == 0 && *hook == (uint32_t)seg + 1u))
+      __hip_atomic_store(gflags + RLC_GROUP_WORDS * g + 1 + seg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -496,6 +561,7 @@ extern "C" hipError_t edk_rlc_note_per_item(uint32_t* stats, size_t n, hipStream
 }
 
 extern "C" size_t edk_rlc_ws_bytes(size_t capacity) { return capacity ? rlc_carve(capacity).total : 0; }
+extern "C" size_t edk_rlc_hook_offset(size_t capacity) { return rlc_carve(capacity).hook; }
 
 // First half of a pass: everything the combination itself needs, and the copy of the group verdicts to the
 // host (pinned).  The caller synchronises `stream` and then calls edk_verify_rlc_fallback.
@@ -522,7 +588,7 @@ extern "C" hipError_t edk_verify_rlc(uint8_t* ok, uint32_t* stats, const edk_ver
   const unsigned blocks = (unsigned)((n + RLC_BLOCK - 1) / RLC_BLOCK);
   hipError_t e;
 
-  EDK_DO(hipMemsetAsync(gflags, 0, groups * 4, stream));
+  EDK_DO(hipMemsetAsync(gflags, 0, groups * RLC_GROUP_WORDS * 4, stream));
   const uint32_t* perm = nullptr;
   EDK_DO(edk_msg_order(&perm, ws, src.msg_off, src.msg_end, n, stream));
   EDK_LAUNCH(k_rlc_hash, dim3(blocks), dim3(RLC_BLOCK), 0, stream, src, n, ts, leaf, perm);
@@ -546,9 +612,14 @@ extern "C" hipError_t edk_verify_rlc(uint8_t* ok, uint32_t* stats, const edk_ver
   EDK_DO(hipStreamWaitEvent(stream, ws->ev_exact, 0));
   EDK_LAUNCH(k_rlc_scalars, dim3((unsigned)(groups * (RLC_G / RLC_BLOCK))), dim3(RLC_BLOCK), 0, stream, n, ts, seed, flags, dig, bsum);
   EDK_LAUNCH(k_rlc_group_scalar, dim3((unsigned)((groups + 63) / 64)), dim3(64), 0, stream, n, bsum, bdig);
-  EDK_LAUNCH(k_rlc_bucket, dim3((unsigned)(groups * RLC_SEGS)), dim3(RLC_LANES), 0, stream, n, dig, bdig,
-                     niels_a, niels_r, base16, segpts);
-  EDK_LAUNCH(k_rlc_final, dim3((unsigned)((4 * groups + 255) / 256)), dim3(256), 0, stream, n, segpts, gflags, gok, stats);
+  EDK_DO(hipEventRecord(ws->ev_prepared, stream));
+  EDK_LAUNCH(k_rlc_bucket, dim3((unsigned)(groups * RLC_SEGS)), dim3(RLC_LANES), 0, stream, n, dig, bdig, niels_a, niels_r, base16, segpts, gflags,
+             reinterpret_cast<const uint32_t*>(base + L.hook));
+  EDK_DO(hipStreamWaitEvent(ws->side, ws->ev_prepared, 0));    // (queued after the bucket launch: see k_rlc_horner)
+  EDK_LAUNCH(k_rlc_horner, dim3((unsigned)((groups + RLC_HORNER_GROUPS - 1) / RLC_HORNER_GROUPS)), dim3(4 * RLC_HORNER_GROUPS), 0, ws->side,
+             n, segpts, gflags, gok, stats);
+  EDK_DO(hipEventRecord(ws->ev_exact, ws->side));
+  EDK_DO(hipStreamWaitEvent(stream, ws->ev_exact, 0));
   EDK_LAUNCH(k_rlc_verdicts, dim3(blocks), dim3(RLC_BLOCK), 0, stream, n, gok, flags, ok);
 
   // groups the combination did not accept: the per-item kernels decide (edk_verify_rlc_fallback).  This is the

@@ -162,7 +162,7 @@ int main(int argc, char **argv)
         RC(ed25519_verify_batch_rlc(ok, stats, bad, g_pub, shifted, off5, 0, NE));
         for (int i = 0; i < NE; i++) CHECK(ok[i] == (i % 3 != 0), "chunked ragged batch verification: item %d", i);
         CHECK(stats[0] + stats[1] == NE, "batch verification statistics: %u + %u items", stats[0], stats[1]);
-        eddsa_amd_set_rlc_min_items((size_t)3 << 17);
+        eddsa_amd_set_rlc_min_items(EDDSA_AMD_RLC_MIN_ITEMS_DEFAULT);
     }
     {   /* an offset table that runs backwards, in the first chunk and in a later one, and one whose span no buffer holds: the
          * call is refused (hipErrorInvalidValue = 1) before the chunk's bytes are touched - the sanitizers would see the

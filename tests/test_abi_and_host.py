@@ -54,6 +54,24 @@ def test_library_exports_every_declared_symbol():
     assert "$(LIB): $(BUILD)/kernels.o $(BUILD)/rlc.o $(BUILD)/eddsa_amd.o $(BUILD)/host_pipe.o" in mk
 
 
+def test_the_wave_share_constants_match_the_committed_counters():
+    """k_verify_exact_lane_chain takes its share of the wave slots from three cost constants (executed instructions per item, in
+    thousands: its own, k_verify_main_half's, k_verify_main's; csrc/kernels.hip).  They drift when the kernels change: held
+    against the counters committed with the profile of the same sources (profiles/pmc_summary.json: SQ_INSTS_VALU counts wave
+    instructions; the chain's row comes from self-check mode 2, 2^20 items alone on the chip; the main kernel's from config 2)"""
+    import json
+    src = open(os.path.join(ROOT, "libeddsa_amd", "csrc", "kernels.hip")).read()
+    chain = int(re.search(r"EXACT_CHAIN_COST = (\d+);", src).group(1))
+    half, full = (int(x) for x in re.search(r"half_main \? (\d+)u : (\d+)u", src).groups())
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+    per_item = lambda k: pmc[k]["SQ_INSTS_VALU"] * 64 / (1 << 20) / 1000          # noqa: E731
+    assert abs(per_item("ed::k_verify_exact_lane_chain") - chain) < 0.03 * chain
+    assert abs(per_item("ed::k_verify_main_half") - half) < 0.03 * half              # (over the on-curve list: 0.8 % fewer items than 2^20)
+    if pmc.get("ed::k_verify_main", {}).get("SQ_INSTS_VALU"):
+        assert abs(per_item("ed::k_verify_main") - full) < 0.05 * full
+    assert 1.3 < full / half < 1.6                                                    # 252 doublings against 132, both with their additions
+
+
 def test_the_product_header_holds_no_test_hooks():
     """include/eddsa_amd.h lists what a caller binds (the shape of the reference's lib/eddsa.h:44-113:
     nothing but the functions); fault injectors, route selection, probes and traces live in eddsa_amd_debug.h"""

@@ -22,10 +22,10 @@ def device_set(engine):
 
 @pytest.fixture(autouse=True)
 def always_combine(engine):
-    """small batches through the combination itself (by default calls below 3 x 2^17 items use the per-item kernels)"""
+    """small batches through the combination itself (by default calls below 3 x 2^16 items use the per-item kernels)"""
     engine.set_rlc_min_items(0)
     yield
-    engine.set_rlc_min_items(3 << 17)
+    engine.set_rlc_min_items(engine.RLC_MIN_ITEMS_DEFAULT)
 
 
 # EDDSA_FUZZ_EXTRA=k adds k more random cases (a longer soak after kernel changes)

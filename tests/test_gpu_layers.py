@@ -227,7 +227,7 @@ def test_a_failed_hip_call_inside_a_verify_pass_surfaces_as_an_error(probe, orac
         probe.debug_fail_hip_call(0)
         assert np.array_equal(probe.ed25519_verify_batch_rlc(vs, vp, vm).cpu().numpy(), expect)
     finally:
-        probe.set_rlc_min_items(3 << 17)
+        probe.set_rlc_min_items(probe.RLC_MIN_ITEMS_DEFAULT)
     # and nothing on the clean-up paths behind those failures (waiting for what was queued, releasing the slot) failed
     # in turn: HIP calls that have nobody to report to are counted, not ignored
     assert probe.debug_teardown_errors() == (0, 0)

@@ -131,7 +131,7 @@ def test_ragged_batches_are_hashed_in_order_of_length(engine, oracle, n):
         assert ok.cpu().numpy().all() and st[0] == n and st[2] == 0
         assert np.array_equal(engine.ed25519_verify_batch_rlc(dev(sig_n), dev(pk_n), dev(blob), msg_off=d_off).cpu().numpy(), want)
     finally:
-        engine.set_rlc_min_items(3 << 17)
+        engine.set_rlc_min_items(engine.RLC_MIN_ITEMS_DEFAULT)
     out = engine.ed25519_sign_batch(dev(sk_n), dev(pk_n), dev(blob), msg_off=d_off).cpu().numpy()
     assert np.array_equal(out, sig[idx])
     if n <= 70000:
@@ -239,7 +239,7 @@ def test_device_calls_clamp_an_offset_table_that_lies(engine, oracle, n):
     try:
         ok = engine.ed25519_verify_batch_rlc(d["sig"], d["pk"], d["blob"], msg_off=d["off"]).cpu().numpy()
     finally:
-        engine.set_rlc_min_items(3 << 17)
+        engine.set_rlc_min_items(engine.RLC_MIN_ITEMS_DEFAULT)
     assert ok[~touched].all() and not ok[touched].all()
     out = engine.ed25519_sign_batch(d["sk"], d["pk"], d["blob"], msg_off=d["off"]).cpu().numpy()
     assert np.array_equal(out[~touched], sig_n[~touched])

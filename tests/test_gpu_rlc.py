@@ -23,11 +23,11 @@ def dev(a):
 
 @pytest.fixture(autouse=True)
 def always_combine(engine):
-    """these tests drive the combination itself with small batches: switch off the routing of calls below 3 x 2^17
+    """these tests drive the combination itself with small batches: switch off the routing of calls below 3 x 2^16
     items to the per-item kernels (test_small_calls_go_to_the_per_item_kernels checks the default)"""
     engine.set_rlc_min_items(0)
     yield
-    engine.set_rlc_min_items(3 << 17)
+    engine.set_rlc_min_items(engine.RLC_MIN_ITEMS_DEFAULT)
 
 
 def _signed(engine, n, seed, mlen=32):
@@ -55,9 +55,10 @@ def test_all_valid_groups_pass_by_combination(engine):
 
 
 def test_small_calls_go_to_the_per_item_kernels(engine):
-    """default routing: below 3 x 2^17 items the combination's own latency (hash tree, Horner) costs more than it
-    saves, so the call uses the per-item kernels; from 3 x 2^17 on it combines"""
-    engine.set_rlc_min_items(3 << 17)
+    """default routing: below 3 x 2^16 items the combination's own latency (hash tree, Horner) costs more than it
+    saves, so the call uses the per-item kernels; from 3 x 2^16 = 196 608 on it combines"""
+    engine.set_rlc_min_items(engine.RLC_MIN_ITEMS_DEFAULT)
+    assert engine.RLC_MIN_ITEMS_DEFAULT == 3 << 16
     sig, pk, msg = _signed(engine, 400000, 11)
     n = 3 * G
     ok, st = engine.ed25519_verify_batch_rlc(dev(sig[:n]), dev(pk[:n]), dev(msg[:n]), msg_len=32, return_stats=True)
@@ -95,6 +96,28 @@ def test_a_failing_group_is_decided_per_item(engine, oracle):
     assert np.array_equal(ok.cpu().numpy(), want)
     assert st[2] + st[3] == 4 and st[2] in (1, 2) and st[0] + st[1] == n    # group 1 fails only if its R still decodes
     assert np.array_equal(want[G:G + 64], oracle.verify_batch(bad[G:G + 64], pk[G:G + 64], msg2[G:G + 64], 32))
+
+
+def test_a_window_point_that_never_arrives_costs_its_groups_the_combination_not_the_call(engine):
+    """k_rlc_horner takes each group's window points as k_rlc_bucket's blocks raise their flags.  With the test hook keeping
+    the flag of window point 40 of group 0 down, that group's Horner wave (groups 0..15: all four here) gives up after its
+    bound - about a second, where the bucket launch takes milliseconds - and hands its groups to the per-item kernels: the
+    verdict bytes are the same, nothing hangs, nothing is an error, and the statistics say what happened"""
+    n = 4 * G
+    sig, pk, msg = _signed(engine, n, 5)
+    ok, st = engine.ed25519_verify_batch_rlc(dev(sig), dev(pk), dev(msg), msg_len=32, return_stats=True)
+    assert bool(ok.all()) and st == (n, 0, 0, 4)
+    engine.debug_init(0, True)
+    try:
+        assert engine.debug_withhold_handoff(41) == 0
+        ok, st = engine.ed25519_verify_batch_rlc(dev(sig), dev(pk), dev(msg), msg_len=32, return_stats=True)
+        assert bool(ok.all()) and st == (0, n, 4, 0)
+        assert engine.debug_withhold_handoff(0) == 0
+    finally:
+        engine.debug_withhold_handoff(0)
+        engine.debug_init(0, False)
+    ok, st = engine.ed25519_verify_batch_rlc(dev(sig), dev(pk), dev(msg), msg_len=32, return_stats=True)
+    assert bool(ok.all()) and st == (n, 0, 0, 4)
 
 
 def test_routing_of_items_the_combination_cannot_represent(engine, oracle):

@@ -42,7 +42,7 @@ def batch(engine, oracle):
 def restore(engine):
     yield
     engine.set_verify_algo(0)
-    engine.set_rlc_min_items(3 << 17)
+    engine.set_rlc_min_items(engine.RLC_MIN_ITEMS_DEFAULT)
 
 
 def test_every_evaluation_on_a_third_of_the_items_with_torsion(engine, batch):

@@ -6,6 +6,7 @@ sys.path.insert(0, __file__.rsplit("/", 2)[0]); sys.path.insert(0, __file__.rspl
 import libeddsa_amd as ed, workload
 ed.use_debug_library()   # the hooks (route selection, phase timings, traces) live in libeddsa_amd_debug.so
 ed.init(0)
+ed.set_rlc_min_items(0)          # (the routing threshold is what this table decides)
 N = 1 << 21
 sk, msg = workload.sign_inputs(N, seed=1, config=2)
 d_sk, d_msg = torch.from_numpy(sk).cuda(), torch.from_numpy(msg).cuda()
