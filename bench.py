@@ -694,9 +694,11 @@ def main():
             dist.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            okr, st = ed.ed25519_verify_batch_rlc(vs, vp, vm, msg_len=32, return_stats=True)
+            okr = ed.ed25519_verify_batch_rlc(vs, vp, vm, msg_len=32)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        okr2, st = ed.ed25519_verify_batch_rlc(vs, vp, vm, msg_len=32, return_stats=True)   # (the statistics are read back by the host: after the timed passes)
+        okr = okr & okr2
         # (calls below the library's break-even size skip the combination: then st[1] == m)
         good = all_ranks_agree(bool(okr.all()) and st[0] + st[1] == m and (st[0] == m or m < ed.RLC_MIN_ITEMS_DEFAULT), world, device)
         correct = correct and good

@@ -39,8 +39,9 @@ EDDSA_AMD_DECL int eddsa_amd_debug_fail_hip_call(int nth);
  * published, so the wave that waits for it must give up after its bound and the pass must come back as EDDSA_AMD_STALLED
  * instead of hanging.  (ii) The batch verification's Horner waves (csrc/rlc.hip: k_rlc_horner), which take the window points
  * of k_rlc_bucket as they arrive: the flag of window point `tile_plus_1 - 1` of group 0 is never raised, so that group's
- * wave must give up and hand its groups to the per-item kernels - same verdicts, no error.  0 switches both off.  Waits for
- * the device; acts on the workspaces allocated so far. */
+ * wave must give up and leave its groups to k_rlc_final - same verdicts, no error.  0 switches both off.  Waits for the
+ * device; acts on the workspaces allocated so far.  Returns a negative error, or the number of Horner waves that have given up
+ * since the previous call (0 in a process whose launches overlap as they should). */
 EDDSA_AMD_DECL int eddsa_amd_debug_withhold_handoff(int tile_plus_1);
 /* checked HIP calls the verify passes have made since the last eddsa_amd_debug_fail_hip_call (so that a test can walk
  * nth over every one of them) */

@@ -151,8 +151,9 @@ STALLED = -100003
 
 
 def debug_withhold_handoff(tile_plus_1):
-    """the first hand-off of that tile of k_verify_exact_lane_chain is never published in the passes that follow (0: off);
-    HOOKS_OFF when not armed"""
+    """the first hand-off of that tile of k_verify_exact_lane_chain is never published, and the flag of that window point of
+    group 0 of the batch verification never raised, in the passes that follow (0: off); HOOKS_OFF when not armed, otherwise
+    the number of Horner waves of the batch verification that gave up since the previous call"""
     return int(_hooks().eddsa_amd_debug_withhold_handoff(int(tile_plus_1)))
 
 
@@ -482,8 +483,8 @@ def ed25519_verify_batch_rlc(sigs, pubs, msgs, msg_off=None, msg_len=None, retur
         _, off, mlen = _msg_args(msgs, msg_off, msg_len, n, True)
         _torch_off_check(off, n)
         ok = torch.empty((n,), dtype=torch.uint8, device=sigs.device)
-        stats = torch.zeros((4,), dtype=torch.int32, device=sigs.device)
-        _check(lib.ed25519_verify_batch_rlc_dev(_c_ptr(ok.data_ptr()), _c_ptr(stats.data_ptr()), _c_ptr(sigs.data_ptr()),
+        stats = torch.zeros((4,), dtype=torch.int32, device=sigs.device) if return_stats else None   # (NULL: not counted)
+        _check(lib.ed25519_verify_batch_rlc_dev(_c_ptr(ok.data_ptr()), _c_ptr(stats.data_ptr()) if return_stats else None, _c_ptr(sigs.data_ptr()),
                                                 _c_ptr(pubs.data_ptr()), _c_ptr(msgs.data_ptr()),
                                                 _c_ptr(off.data_ptr()) if off is not None else None,
                                                 _c_size(mlen), _c_size(n), _stream()), "ed25519_verify_batch_rlc")

@@ -433,7 +433,7 @@ int eddsa_amd_debug_hip_calls(void)
 int eddsa_amd_debug_withhold_handoff(int tile_plus_1)
 {
     struct call c;
-    int rc;
+    int rc, gave_up = 0;
     if (!__atomic_load_n(&g_hooks_armed, __ATOMIC_ACQUIRE)) return EDDSA_AMD_HOOKS_OFF;
     if ((rc = enter(&c, -1))) return rc;
     pthread_mutex_lock(&c.e->lk);
@@ -441,9 +441,16 @@ int eddsa_amd_debug_withhold_handoff(int tile_plus_1)
     for (int i = 0; i < VERIFY_SLOTS; i++) {
         const uint32_t w = tile_plus_1 > 0 ? (uint32_t)tile_plus_1 : 0u;
         if (c.e->vs[i].ws.offcount) TRY(hipMemcpy(c.e->vs[i].ws.offcount + EDK_WITHHOLD_WORD, &w, sizeof(w), hipMemcpyHostToDevice));
-        if (c.e->vs[i].rws.base)
-            TRY(hipMemcpy((char *)c.e->vs[i].rws.base + edk_rlc_hook_offset(c.e->vs[i].rws.capacity), &w, sizeof(w), hipMemcpyHostToDevice));
+        if (c.e->vs[i].rws.base) {
+            uint32_t *hook = (uint32_t *)((char *)c.e->vs[i].rws.base + edk_rlc_hook_offset(c.e->vs[i].rws.capacity));
+            uint32_t two[2] = { 0, 0 };
+            TRY(hipMemcpy(two, hook, sizeof(two), hipMemcpyDeviceToHost));
+            gave_up += (int)two[1];
+            two[0] = w; two[1] = 0;
+            TRY(hipMemcpy(hook, two, sizeof(two), hipMemcpyHostToDevice));
+        }
     }
+    rc = gave_up;
 out:
     pthread_mutex_unlock(&c.e->lk);
     leave(&c);

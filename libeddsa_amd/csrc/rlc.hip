@@ -60,8 +60,9 @@ constexpr int RLC_TREE_FAN = 64;
 constexpr uint32_t RLC_BASE_IDX = RLC_G;         // list entry that stands for the base point B
 constexpr int RLC_GROUP_WORDS = 64;              // per group: word 0 the routing flag, words 1..48 "window point s is in memory" (k_rlc_bucket)
 constexpr int RLC_HORNER_GROUPS = 16;            // groups per Horner wave (four lanes each)
-constexpr uint32_t RLC_HORNER_PATIENCE = 1u << 20;   // polls (a microsecond or two each) for ONE window before a Horner wave gives its groups up: a second,
-                                                     // where the whole bucket launch takes milliseconds
+constexpr uint32_t RLC_HORNER_PATIENCE = 1u << 15;   // polls (0.4 us each, measured) for ONE window before a wave of k_rlc_horner leaves its groups
+                                                     // to k_rlc_final: 14 ms, where the whole bucket launch takes 2
+constexpr uint8_t RLC_UNDECIDED = 2;             // gok[g]: k_rlc_horner gave the group up
 
 
 // workspace carving (bytes), capacity = a multiple of 2048 items
@@ -86,7 +87,7 @@ __host__ inline rlc_layout rlc_carve(size_t cap) {
   L.gok = o;     o += rlc_align(L.groups);
   L.seg = o;     o += rlc_align(L.groups * RLC_SEGS * VERIFY_ENTRY_WORDS * 4);      // window points, cached form (packed)
   L.tree = o;    o += rlc_align((cap / RLC_TREE_FAN + 2) * 32 * 2);
-  L.hook = o;    o += 256;                                       // word 0: test hook (eddsa_amd_debug_withhold_handoff), zeroed at allocation
+  L.hook = o;    o += 256;                                       // word 0: test hook (eddsa_amd_debug_withhold_handoff); word 1: waves of k_rlc_horner that gave up; zeroed at allocation
   L.total = o;
   return L;
 }
@@ -300,6 +301,28 @@ ED_DEV void quad_add_coherent(fe& r, const uint32_t* e, int q) {
   quad_stage_b(r, m, q);
 }
 
+// the group's verdict from the total r = (X, Y, T, Z) across the quad: accepted when r is the neutral element and no item
+// of the group sent it to the per-item kernels
+ED_DEV void rlc_group_verdict(const fe& r, int q, bool live, size_t g, size_t n, const uint32_t* gflags, uint8_t* gok, uint32_t* stats) {
+  // neutral element: X = 0, Y = Z and Z != 0 (lane 0 holds X, lane 1 Y, lane 3 Z), as verify_half_main_quad tests it:
+  // (0, 0, *, 0) is no point, and is unreachable only while every combined point is on the curve
+  fe z, d;
+  fe_quad_perm<3, 3, 3, 3>(z, r);
+  fe_sub(d, r, z);                               // lane 1: Y - Z
+  const bool mine = q == 0 ? fe_iszero(r) : q == 1 ? fe_iszero(d) : q == 3 ? !fe_iszero(r) : true;
+  const int all = (int)mine & __shfl_xor((int)mine, 1);
+  const bool neutral = (all & __shfl_xor(all, 2)) != 0;
+  if (q != 0 || !live) return;
+  const bool ok = neutral && gflags[RLC_GROUP_WORDS * g] == 0;
+  gok[g] = (uint8_t)ok;
+  if (stats) {
+    const uint32_t cnt = (uint32_t)(n - g * RLC_G < (size_t)RLC_G ? n - g * RLC_G : (size_t)RLC_G);
+    atomicAdd(stats + (ok ? 0 : 1), cnt);        // items decided by the combination / by the per-item kernels
+    if (!ok) atomicAdd(stats + 2, 1u);           // groups sent to the per-item kernels
+    else atomicAdd(stats + 3, 1u);               // groups decided by the combination
+  }
+}
+
 // R6: per group, Horner over the window points (highest window first; the 16 windows of -R carry the weights of the 16
 // lowest windows of -A): the total must be the neutral element.  248 dependent doublings per group: pure latency, the
 // price of any 253-bit multi-scalar multiplication, so it runs in the four-lanes-per-point form of quad_lanes.h (a
@@ -313,10 +336,13 @@ ED_DEV void quad_add_coherent(fe& r, const uint32_t* e, int q) {
 // as kernels between launches of the bucket blocks by weight on two streams the hardware interleaved the launches and the
 // heavy windows were done no sooner.)
 // Forward progress: a bucket block waits for nothing and its launch is queued BEFORE this kernel's, so every flag is
-// raised whether or not the two launches overlap; a wave that has polled RLC_HORNER_PATIENCE times for one window all the
-// same (a fault elsewhere) gives its groups to the per-item kernels, whose verdicts are the reference's in any case.
+// raised whether or not the two launches overlap.  Where they do not - a profiler collecting counters runs one kernel at
+// a time, in an order of its own, and may run this one FIRST - a wave that has polled RLC_HORNER_PATIENCE times for one
+// window marks its groups RLC_UNDECIDED and ends; k_rlc_final, queued behind both launches on the pass's stream, then
+// evaluates those groups the way round 5 evaluated all of them (and ends at once when there are none): the pass costs
+// the patience and the old 0.26 ms, the verdicts are the same.
 __global__ void __launch_bounds__(4 * RLC_HORNER_GROUPS)
-k_rlc_horner(size_t n, const uint32_t* segpts, const uint32_t* gflags, uint8_t* gok, uint32_t* stats) {
+k_rlc_horner(size_t n, const uint32_t* segpts, const uint32_t* gflags, uint8_t* gok, uint32_t* stats, uint32_t* giveups) {
   const size_t groups = (n + RLC_G - 1) / RLC_G;
   const size_t g = (size_t)blockIdx.x * RLC_HORNER_GROUPS + (threadIdx.x >> 2);
   const bool live = g < groups;
@@ -345,26 +371,37 @@ k_rlc_horner(size_t n, const uint32_t* segpts, const uint32_t* gflags, uint8_t* 
     quad_add_coherent(r, gpts + sa * VERIFY_ENTRY_WORDS, q);
     if (w < RLC_WINDOWS_R) quad_add_coherent(r, gpts + sr * VERIFY_ENTRY_WORDS, q);
   }
-  // neutral element: X = 0, Y = Z and Z != 0 (lane 0 holds X, lane 1 Y, lane 3 Z), as verify_half_main_quad tests it:
-  // (0, 0, *, 0) is no point, and is unreachable only while every combined point is on the curve
-  fe z, d;
-  fe_quad_perm<3, 3, 3, 3>(z, r);
-  fe_sub(d, r, z);                               // lane 1: Y - Z
-  const bool mine = q == 0 ? fe_iszero(r) : q == 1 ? fe_iszero(d) : q == 3 ? !fe_iszero(r) : true;
-  const int all = (int)mine & __shfl_xor((int)mine, 1);
-  const bool neutral = (all & __shfl_xor(all, 2)) != 0;
-  if (q != 0 || !live) return;
-  const bool ok = neutral && !gave_up && gw[0] == 0;
-  gok[g] = (uint8_t)ok;
-  if (stats) {
-    const uint32_t cnt = (uint32_t)(n - g * RLC_G < (size_t)RLC_G ? n - g * RLC_G : (size_t)RLC_G);
-    atomicAdd(stats + (ok ? 0 : 1), cnt);        // items decided by the combination / by the per-item kernels
-    if (!ok) atomicAdd(stats + 2, 1u);           // groups sent to the per-item kernels
-    else atomicAdd(stats + 3, 1u);               // groups decided by the combination
+  if (gave_up) {
+    if (q == 0 && live) gok[g] = RLC_UNDECIDED;
+    if (threadIdx.x == 0) atomicAdd(giveups, 1u);
+    return;
   }
+  rlc_group_verdict(r, q, live, g, n, gflags, gok, stats);
 }
 
-
+// the groups k_rlc_horner left undecided (none, unless the two launches did not overlap: see there), after both launches:
+// every window point is in memory, plain loads
+__global__ void __launch_bounds__(4 * RLC_HORNER_GROUPS)
+k_rlc_final(size_t n, const uint32_t* segpts, const uint32_t* gflags, uint8_t* gok, uint32_t* stats) {
+  const size_t groups = (n + RLC_G - 1) / RLC_G;
+  const size_t g = (size_t)blockIdx.x * RLC_HORNER_GROUPS + (threadIdx.x >> 2);
+  const bool live = g < groups && gok[g] == RLC_UNDECIDED;
+  if (!__any(live)) return;
+  const int q = (int)(threadIdx.x & 3u);
+  const uint32_t* gpts = segpts + (live ? g : 0) * RLC_SEGS * VERIFY_ENTRY_WORDS;
+  fe r;
+  fe_set(r, (uint32_t)(q & 1));
+#pragma unroll 1
+  for (int w = RLC_WINDOWS_A - 1; w >= 0; w--) {
+    if (w != RLC_WINDOWS_A - 1) {
+#pragma unroll 1
+      for (int k = 0; k < 8; k++) quad_dbl(r, q);
+    }
+    quad_add_entry(r, gpts + (RLC_WINDOWS_A - 1 - w) * VERIFY_ENTRY_WORDS, false, true, q);
+    if (w < RLC_WINDOWS_R) quad_add_entry(r, gpts + (RLC_SEGS_A + RLC_WINDOWS_R - 1 - w) * VERIFY_ENTRY_WORDS, false, true, q);
+  }
+  rlc_group_verdict(r, q, live, g, n, gflags, gok, stats);
+}
 
 __global__ void __launch_bounds__(RLC_LANES, 2)
 k_rlc_bucket(size_t n, const int8_t* dig, const int8_t* bdig, const uint32_t* niels_a, const uint32_t* niels_r,
@@ -617,9 +654,11 @@ extern "C" hipError_t edk_verify_rlc(uint8_t* ok, uint32_t* stats, const edk_ver
              reinterpret_cast<const uint32_t*>(base + L.hook));
   EDK_DO(hipStreamWaitEvent(ws->side, ws->ev_prepared, 0));    // (queued after the bucket launch: see k_rlc_horner)
   EDK_LAUNCH(k_rlc_horner, dim3((unsigned)((groups + RLC_HORNER_GROUPS - 1) / RLC_HORNER_GROUPS)), dim3(4 * RLC_HORNER_GROUPS), 0, ws->side,
-             n, segpts, gflags, gok, stats);
+             n, segpts, gflags, gok, stats, reinterpret_cast<uint32_t*>(base + L.hook) + 1);
   EDK_DO(hipEventRecord(ws->ev_exact, ws->side));
   EDK_DO(hipStreamWaitEvent(stream, ws->ev_exact, 0));
+  EDK_LAUNCH(k_rlc_final, dim3((unsigned)((groups + RLC_HORNER_GROUPS - 1) / RLC_HORNER_GROUPS)), dim3(4 * RLC_HORNER_GROUPS), 0, stream,
+             n, segpts, gflags, gok, stats);
   EDK_LAUNCH(k_rlc_verdicts, dim3(blocks), dim3(RLC_BLOCK), 0, stream, n, gok, flags, ok);
 
   // groups the combination did not accept: the per-item kernels decide (edk_verify_rlc_fallback).  This is the

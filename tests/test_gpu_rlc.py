@@ -98,26 +98,30 @@ def test_a_failing_group_is_decided_per_item(engine, oracle):
     assert np.array_equal(want[G:G + 64], oracle.verify_batch(bad[G:G + 64], pk[G:G + 64], msg2[G:G + 64], 32))
 
 
-def test_a_window_point_that_never_arrives_costs_its_groups_the_combination_not_the_call(engine):
+def test_a_window_flag_that_is_never_raised_costs_the_pass_a_wait_not_its_result(engine):
     """k_rlc_horner takes each group's window points as k_rlc_bucket's blocks raise their flags.  With the test hook keeping
-    the flag of window point 40 of group 0 down, that group's Horner wave (groups 0..15: all four here) gives up after its
-    bound - about a second, where the bucket launch takes milliseconds - and hands its groups to the per-item kernels: the
-    verdict bytes are the same, nothing hangs, nothing is an error, and the statistics say what happened"""
+    the flag of window point 40 of group 0 down, that group's Horner wave (groups 0..15: all four here) polls for its bound -
+    14 ms, where the bucket launch takes 2 - marks its groups undecided and ends; k_rlc_final, queued behind both
+    launches, evaluates them from memory.  Same verdicts, same statistics, nothing hangs, nothing is an error - and the hook
+    reports the wave that gave up (none in the passes before and after)"""
     n = 4 * G
     sig, pk, msg = _signed(engine, n, 5)
-    ok, st = engine.ed25519_verify_batch_rlc(dev(sig), dev(pk), dev(msg), msg_len=32, return_stats=True)
-    assert bool(ok.all()) and st == (n, 0, 0, 4)
     engine.debug_init(0, True)
     try:
-        assert engine.debug_withhold_handoff(41) == 0
         ok, st = engine.ed25519_verify_batch_rlc(dev(sig), dev(pk), dev(msg), msg_len=32, return_stats=True)
-        assert bool(ok.all()) and st == (0, n, 4, 0)
+        assert bool(ok.all()) and st == (n, 0, 0, 4)
+        assert engine.debug_withhold_handoff(41) == 0                    # (no wave gave up so far)
+        bad = sig.copy(); bad[2 * G + 5, 40] ^= 1                        # ... and a group that fails, decided by the same route
+        ok, st = engine.ed25519_verify_batch_rlc(dev(bad), dev(pk), dev(msg), msg_len=32, return_stats=True)
+        want = np.ones(n, np.uint8); want[2 * G + 5] = 0
+        assert np.array_equal(ok.cpu().numpy(), want) and st == (3 * G, G, 1, 3)
+        assert engine.debug_withhold_handoff(0) == 1                     # one wave (groups 0..15) gave up, once
+        ok, st = engine.ed25519_verify_batch_rlc(dev(sig), dev(pk), dev(msg), msg_len=32, return_stats=True)
+        assert bool(ok.all()) and st == (n, 0, 0, 4)
         assert engine.debug_withhold_handoff(0) == 0
     finally:
         engine.debug_withhold_handoff(0)
         engine.debug_init(0, False)
-    ok, st = engine.ed25519_verify_batch_rlc(dev(sig), dev(pk), dev(msg), msg_len=32, return_stats=True)
-    assert bool(ok.all()) and st == (n, 0, 0, 4)
 
 
 def test_routing_of_items_the_combination_cannot_represent(engine, oracle):
