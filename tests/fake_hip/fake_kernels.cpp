@@ -189,6 +189,7 @@ hipError_t edk_verify(uint8_t* ok, const edk_verify_src* src, size_t n, const ui
 }
 
 size_t edk_rlc_ws_bytes(size_t capacity) { return capacity ? capacity : 0; }
+size_t edk_rlc_hook_offset(size_t) { return 0; }                       // (this build's workspace is `capacity` bytes: the hook words at its start)
 hipError_t edk_rlc_note_per_item(uint32_t* stats, size_t n, hipStream_t stream) {
   own_stream(stream);
   if (stats && n) { own(stats, 16, "statistics"); enq(stream, [=] { stats[1] += (uint32_t)n; stats[2] += (uint32_t)((n + 8191) / 8192); }); }
