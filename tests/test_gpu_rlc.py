@@ -124,6 +124,45 @@ def test_a_window_flag_that_is_never_raised_costs_the_pass_a_wait_not_its_result
         engine.debug_init(0, False)
 
 
+def test_concurrent_combinations_on_three_streams(engine):
+    """Three host threads, a stream each, six passes each, at once: every pass has its own workspace, bucket launch and Horner
+    kernel, and a Horner kernel polls flags that only ITS pass's bucket blocks raise - which may still be waiting for another
+    pass's blocks to leave the chip.  Every pass must return its own verdicts (one thread's batch is all valid, one has a
+    failing group, one a group with a small-order key that goes per item), with the statistics of a pass run alone"""
+    import threading
+    import torch
+    n = 6 * G + 300
+    sig, pk, msg = _signed(engine, n, 77)
+    cases = []
+    for kind in range(3):
+        s2, p2 = sig.copy(), pk.copy()
+        want = np.ones(n, np.uint8)
+        if kind == 1:
+            s2[2 * G + 9, 35] ^= 4; want[2 * G + 9] = 0
+        if kind == 2:
+            p2[4 * G + 1] = np.frombuffer(bytes.fromhex("0100000000000000000000000000000000000000000000000000000000000000"), np.uint8)
+            want[4 * G + 1] = 0                                   # the neutral element as a key: its group is decided per item
+        ok, st = engine.ed25519_verify_batch_rlc(dev(s2), dev(p2), dev(msg), msg_len=32, return_stats=True)
+        assert np.array_equal(ok.cpu().numpy(), want), kind
+        cases.append((dev(s2), dev(p2), torch.from_numpy(want).cuda(), st))
+    dm = dev(msg)
+    errs = []
+
+    def worker(kind):
+        s2, p2, want, st0 = cases[kind]
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            for r in range(6):
+                ok, st = engine.ed25519_verify_batch_rlc(s2, p2, dm, msg_len=32, return_stats=True)
+                stream.synchronize()
+                if not torch.equal(ok, want) or st != st0:
+                    errs.append((kind, r, int((ok != want).sum()), st, st0))
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not errs, errs[:4]
+
+
 def test_routing_of_items_the_combination_cannot_represent(engine, oracle):
     """non-canonical / off-curve R: rejected at once, the group still passes by combination; off-curve or
     small-order A, small-order R: the whole group goes to the per-item kernels"""
