@@ -617,8 +617,9 @@ static int pipe_run_on(struct engine *e, const struct hjob *j, size_t n)
             TRY(hipStreamSynchronize(p->lane[0].st));
             memcpy(j->stats, p->h_stats, 16);
         }
-        /* every lane of the call has been waited for: what its kernels reported (a hand-off given up) is this call's error */
-        if ((rc = take_async_error(e))) goto out;
+        /* every lane of the call has been waited for: what a verify pass's kernels reported (a hand-off given up) is this
+         * call's error (the other operations' kernels have nothing to report: a sign call does not take a verify call's word) */
+        if (j->out_w == 1 && (rc = take_async_error(e))) goto out;
     }
 out:
     if (rc) {
