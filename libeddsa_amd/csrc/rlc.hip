@@ -327,7 +327,7 @@ ED_DEV void rlc_group_verdict(const fe& r, int q, bool live, size_t g, size_t n,
 // lowest windows of -A): the total must be the neutral element.  248 dependent doublings per group: pure latency, the
 // price of any 253-bit multi-scalar multiplication, so it runs in the four-lanes-per-point form of quad_lanes.h (a
 // doubling is one squaring and one multiplication deep), sixteen groups to a wave.  The kernel runs on the side stream
-// BESIDE k_rlc_bucket (58 registers, no LDS: its eight waves fit next to the bucket blocks' two per SIMD) and takes each
+// BESIDE k_rlc_bucket (60 registers, no LDS: its eight waves fit next to the bucket blocks' two per SIMD) and takes each
 // window's points as its flags go up - the bucket blocks run in order of weight, so when the last of them is done all that
 // is left is the last windows' share of the chain.  (As a kernel after the bucket blocks the evaluation was 0.26 ms
 // during which the chip did nothing else.  Tried and dropped: run by the bucket block that completes a part of the windows
