@@ -164,11 +164,11 @@ EDDSA_AMD_DECL int ed25519_verify_records(uint8_t *ok, const uint8_t *records, s
  * stats (4 words, may be NULL) receives: items decided by the combination, items decided per item,
  * groups sent to the per-item kernels, groups decided by the combination.
  * The device-pointer form synchronises `stream` once per pass (it reads the group verdicts).
- * The combination has about 1.2 ms of latency of its own (hash tree over the batch, one serial Horner per
- * group), so it pays from about 150 000 items (x1.3 at 2^18, x2.0 at 2^19, x2.1 from 2^20): calls with fewer items than
+ * The combination has about 1 ms of latency of its own (hash tree over the batch, one serial Horner per
+ * group), so it pays from about 2^17 items (x1.5 at 2^18, x2.1 at 2^19, x2.2 from 2^20): calls with fewer items than
  * eddsa_amd_set_rlc_min_items (default EDDSA_AMD_RLC_MIN_ITEMS_DEFAULT; 0 = always combine) go straight to the per-item
  * kernels. */
-#define EDDSA_AMD_RLC_MIN_ITEMS_DEFAULT ((size_t)3 << 16)
+#define EDDSA_AMD_RLC_MIN_ITEMS_DEFAULT ((size_t)5 << 15)
 EDDSA_AMD_DECL int ed25519_verify_batch_rlc(uint8_t *ok, uint32_t stats[4], const uint8_t *sigs,
                                             const uint8_t *pubs, const uint8_t *msgs,
                                             const uint64_t *msg_off, size_t msg_len, size_t n);

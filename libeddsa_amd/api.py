@@ -237,12 +237,12 @@ def halve_rejected():
     return int(out.value)
 
 
-RLC_MIN_ITEMS_DEFAULT = 3 << 16                 # EDDSA_AMD_RLC_MIN_ITEMS_DEFAULT, include/eddsa_amd.h
+RLC_MIN_ITEMS_DEFAULT = 5 << 15                 # EDDSA_AMD_RLC_MIN_ITEMS_DEFAULT, include/eddsa_amd.h
 
 
 def set_rlc_min_items(items):
-    """ed25519_verify_batch_rlc calls with fewer items go straight to the per-item kernels (default 3 x 2^16: above the
-    measured break-even of about 150 000 items; 0 = always try the combination)"""
+    """ed25519_verify_batch_rlc calls with fewer items go straight to the per-item kernels (default 5 x 2^15 = 163 840: above the
+    measured break-even of about 2^17 items; 0 = always try the combination)"""
     library().eddsa_amd_set_rlc_min_items(_c_size(int(items)))
 
 

@@ -724,8 +724,8 @@ int rlc_on(struct engine *e, uint8_t *ok, uint32_t *stats, const edk_verify_src 
     int rc = 0;
     if (n == 0) return 0;
     if (n < g_rlc_min_items) {
-        /* the combination has about 1.2 ms of latency of its own (hash tree, one serial Horner per group): below
-         * ~150 000 items the per-item kernels are faster (tools/rlc_sizes.py), so such calls go straight to them */
+        /* the combination has about 1 ms of latency of its own (hash tree, one serial Horner per group): below
+         * ~2^17 items the per-item kernels are faster (tools/rlc_sizes.py), so such calls go straight to them */
         rc = verify_on(e, ok, all, n, st, NULL, 0);
         if (!rc) { hipError_t er = edk_rlc_note_per_item(stats, n, st); if (er != hipSuccess) rc = -(int)er; }
         return rc;

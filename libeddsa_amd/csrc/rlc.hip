@@ -56,7 +56,6 @@ constexpr int RLC_SEG_WINDOWS = 1;               // windows per workgroup (2 and
 constexpr int RLC_SEGS_A = RLC_WINDOWS_A / RLC_SEG_WINDOWS, RLC_SEGS_R = RLC_WINDOWS_R / RLC_SEG_WINDOWS;
 constexpr int RLC_SEGS = RLC_SEGS_A + RLC_SEGS_R;   // window points per group: 32 for -A, 16 for -R
 constexpr int RLC_BLOCK = 256;
-constexpr int RLC_TREE_FAN = 64;
 constexpr uint32_t RLC_BASE_IDX = RLC_G;         // list entry that stands for the base point B
 constexpr int RLC_GROUP_WORDS = 64;              // per group: word 0 the routing flag, words 1..48 "window point s is in memory" (k_rlc_bucket)
 constexpr int RLC_HORNER_GROUPS = 16;            // groups per Horner wave (four lanes each)
@@ -125,7 +124,10 @@ k_rlc_hash(edk_verify_src src, size_t n, uint32_t* ts, uint32_t* leaf, const uin
   l[0] = make_uint4(lf[0], lf[1], lf[2], lf[3]); l[1] = make_uint4(lf[4], lf[5], lf[6], lf[7]);
 }
 
-// R2: one level of the hash tree: node j = SHA-512(children 64 j .. 64 j + 63)[0..32)
+// R2: one level of the hash tree: node j = SHA-512(children 16 j .. 16 j + 15)[0..32).  (A lane hashes its children's 512 bytes
+// block after block: the tree is latency, five blocks per level and five levels at 2^20 items.  With a fan-in of 64 - 17 blocks
+// per level, three levels and a fourth of one node - it ran 0.6-1.0 ms beside k_rlc_points and was the critical path of passes
+// below 2^19 items: 2^17 items 1.48 -> 1.32 ms, 2^18 1.80 -> 1.62, 2^20 4.47 -> 4.41: profiles/r06_rlc_bucket.txt.)
 __global__ void __launch_bounds__(64)
 k_rlc_tree(const uint32_t* in, uint32_t* out, size_t count) {
   const size_t j = (size_t)blockIdx.x * 64 + threadIdx.x;

@@ -12,6 +12,7 @@ namespace ed {
 
 enum : uint8_t { RLC_R_VALID = 1, RLC_PER_ITEM = 2 };
 constexpr int RLC_WINDOWS_A = 32, RLC_WINDOWS_R = 16, RLC_WINDOWS = RLC_WINDOWS_A + RLC_WINDOWS_R;
+constexpr int RLC_TREE_FAN = 16;                // children per node of the batch hash tree (rlc.hip: k_rlc_tree)
 
 ED_DEV bool ge_is_neutral(const ge& p) {
   fe d;

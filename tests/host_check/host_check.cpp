@@ -425,7 +425,7 @@ void hc_rlc_scalars(int8_t dig_a[32], int8_t dig_r[16], uint8_t zs[32], const ui
 }
 
 // The whole check of rlc.hip for ONE group of n <= 64 items with fixed-length messages, every step taken from
-// rlc_lanes.h: leaves -> seed (one tree level), points and flags, coefficients and digits, then
+// rlc_lanes.h: leaves -> seed (the hash tree), points and flags, coefficients and digits, then
 //   sum_w 256^w ( sum_i digA[i][w] (-A_i) + sum_i digR[i][w] (-R_i) + digB[w] B )
 // by Horner with plain additions.  Returns 1 if the total is the neutral element and no item is flagged for the
 // per-item path, 0 otherwise; valid_r[i] receives the RLC_R_VALID flag of item i.
@@ -442,7 +442,22 @@ int hc_rlc_group(uint8_t* valid_r, const uint8_t* sigs, const uint8_t* pubs, con
     valid_r[i] = fl[i] & RLC_R_VALID;
   }
   uint32_t seed16[16];
-  sha512_prefix_msg<0>(seed16, nullptr, reinterpret_cast<const uint8_t*>(leaves.data()), 32 * (size_t)n);   // k_rlc_tree, one level
+  {                                              // rlc.hip: k_rlc_tree, level by level until one node is left
+    std::vector<uint32_t> level = leaves;
+    size_t count = (size_t)n;
+    do {
+      const size_t next = (count + RLC_TREE_FAN - 1) / RLC_TREE_FAN;
+      std::vector<uint32_t> up(8 * next);
+      for (size_t j = 0; j < next; j++) {
+        const size_t lo = j * RLC_TREE_FAN, cnt = count - lo < (size_t)RLC_TREE_FAN ? count - lo : (size_t)RLC_TREE_FAN;
+        sha512_prefix_msg<0>(seed16, nullptr, reinterpret_cast<const uint8_t*>(level.data() + 8 * lo), 32 * cnt);
+        for (int k = 0; k < 8; k++) up[8 * j + k] = seed16[k];
+      }
+      level = up;
+      count = next;
+    } while (count > 1);
+    for (int k = 0; k < 8; k++) seed16[k] = level[k];
+  }
   std::vector<int8_t> da(32 * n), dr(16 * n);
   uint32_t sum[16] = {0};
   bool flagged = false;

@@ -22,7 +22,7 @@ def device_set(engine):
 
 @pytest.fixture(autouse=True)
 def always_combine(engine):
-    """small batches through the combination itself (by default calls below 3 x 2^16 items use the per-item kernels)"""
+    """small batches through the combination itself (by default calls below 5 x 2^15 items use the per-item kernels)"""
     engine.set_rlc_min_items(0)
     yield
     engine.set_rlc_min_items(engine.RLC_MIN_ITEMS_DEFAULT)

@@ -23,7 +23,7 @@ def dev(a):
 
 @pytest.fixture(autouse=True)
 def always_combine(engine):
-    """these tests drive the combination itself with small batches: switch off the routing of calls below 3 x 2^16
+    """these tests drive the combination itself with small batches: switch off the routing of calls below 5 x 2^15
     items to the per-item kernels (test_small_calls_go_to_the_per_item_kernels checks the default)"""
     engine.set_rlc_min_items(0)
     yield
@@ -55,10 +55,10 @@ def test_all_valid_groups_pass_by_combination(engine):
 
 
 def test_small_calls_go_to_the_per_item_kernels(engine):
-    """default routing: below 3 x 2^16 items the combination's own latency (hash tree, Horner) costs more than it
-    saves, so the call uses the per-item kernels; from 3 x 2^16 = 196 608 on it combines"""
+    """default routing: below 5 x 2^15 items the combination's own latency (hash tree, Horner) costs more than it
+    saves, so the call uses the per-item kernels; from 5 x 2^15 = 163 840 on it combines"""
     engine.set_rlc_min_items(engine.RLC_MIN_ITEMS_DEFAULT)
-    assert engine.RLC_MIN_ITEMS_DEFAULT == 3 << 16
+    assert engine.RLC_MIN_ITEMS_DEFAULT == 5 << 15
     sig, pk, msg = _signed(engine, 400000, 11)
     n = 3 * G
     ok, st = engine.ed25519_verify_batch_rlc(dev(sig[:n]), dev(pk[:n]), dev(msg[:n]), msg_len=32, return_stats=True)
